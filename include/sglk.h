@@ -1,0 +1,302 @@
+/*
+ * sglk -- MI355X (gfx950) native kernels for SGLang's RadixAttention + quantized-matmul decode path.
+ *
+ * C ABI of libsglk.so.  Plain pointers and sizes only; every device pointer is a HIP device address,
+ * `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every launcher returns 0 on
+ * success or a negative SGLK_E* code and leaves a message readable through sglk_last_error().
+ * No launcher allocates, frees or synchronises, so all of them may be captured into a HIP graph.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository kexinchu/sglang-security).
+ */
+#ifndef SGLK_H_
+#define SGLK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGLK_API __attribute__((visibility("default")))
+
+/* dtype codes */
+#define SGLK_F32 0
+#define SGLK_F16 1
+#define SGLK_BF16 2
+#define SGLK_FP8_E4M3 3 /* OCP e4m3fn: the native fp8 of gfx950 */
+
+/* error codes */
+#define SGLK_OK 0
+#define SGLK_EINVAL (-1)  /* bad shape / alignment / dtype: the reference raises RuntimeError here */
+#define SGLK_EHIP (-2)    /* a HIP runtime call failed */
+#define SGLK_EUNSUP (-3)  /* valid request this build has no kernel for */
+
+SGLK_API const char* sglk_last_error(void);
+SGLK_API int sglk_version(void);
+/* number of compute units of the current device (TritonAttnBackend.device_core_count,
+ * python/sglang/srt/layers/attention/triton_backend.py:233) */
+SGLK_API int sglk_device_cu_count(void);
+
+/* ------------------------------------------------------------------ A0: attention metadata ---- */
+
+/* kv_indices[kv_indptr[b] + j] = req_to_token[req_pool_indices[b], kv_start[b] + j], j < lens[b].
+ * Replaces create_flashinfer_kv_indices_triton, python/sglang/srt/layers/attention/utils.py:5-41.
+ * idx/lens/start may be int32 or int64 (the *_is64 flags); kv_start may be NULL. */
+SGLK_API int sglk_create_kv_indices(const int32_t* req_to_token, int64_t row_stride,
+                                    const void* req_pool_indices, int idx_is64, const void* lens,
+                                    int lens_is64, const int32_t* kv_indptr, const void* kv_start,
+                                    int start_is64, int32_t* kv_indices, int bs, void* stream);
+
+/* kv_indptr[0] = 0, kv_indptr[1+b] = sum_{i<=b} seq_lens[i].
+ * Replaces `kv_indptr[1:bs+1] = torch.cumsum(seq_lens)`, triton_backend.py:283. */
+SGLK_API int sglk_kv_indptr_cumsum(const void* seq_lens, int lens_is64, int32_t* kv_indptr, int bs,
+                                   void* stream);
+
+/* Per-request split count. Replaces get_num_kv_splits_triton, triton_backend.py:23-72, 235-269. */
+SGLK_API int sglk_get_num_kv_splits(int32_t* num_kv_splits, const void* seq_lens, int lens_is64,
+                                    int num_seq, int num_group, int num_head, int num_kv_head,
+                                    int max_kv_splits, int device_core_count, void* stream);
+
+/* One launch for the three above (graph replay refreshes metadata at fixed addresses,
+ * triton_backend.py init_forward_metadata_replay_cuda_graph). */
+SGLK_API int sglk_decode_metadata(const int32_t* req_to_token, int64_t row_stride,
+                                  const void* req_pool_indices, int idx_is64, const void* seq_lens,
+                                  int lens_is64, int32_t* kv_indptr, int32_t* kv_indices,
+                                  int32_t* num_kv_splits, int bs, int num_head, int num_kv_head,
+                                  int max_kv_splits, int device_core_count, void* stream);
+
+/* ------------------------------------------------------------------ A1: decode attention ------ */
+
+/* o[b,h,:] = softmax(sm_scale * q[b,h] . K[idx(b)]^T  [logit_cap * tanh(./logit_cap)]) . V[idx(b)]
+ * with GQA head mapping h -> h / (Hq/Hkv), split-KV partials in attn_logits [B,Hq,max_kv_splits,Dv]
+ * fp32 and attn_lse [B,Hq,max_kv_splits] fp32, merged by LSE.
+ * Replaces decode_attention_fwd, python/sglang/srt/layers/attention/triton_ops/decode_attention.py:682-733
+ * (== decode_attention_cpu, sgl-kernel/csrc/cpu/decode.cpp:1064-1207, without its KV write).
+ * Strides are in elements; the last dimension of every tensor is contiguous. */
+SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                   const int32_t* kv_indptr, const int32_t* kv_indices,
+                                   float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                                   int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
+                                   int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n,
+                                   int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                   int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+                                   float logit_cap, int dtype, void* stream);
+
+/* Radix-prefix-shared decode: requests are partitioned into groups (group_indptr [G+1] over the
+ * batch, requests of a group contiguous); the first prefix_lens[g] KV slots of every request in
+ * group g are the same pool slots (a radix-tree hit), so that part of K/V is read once per group
+ * and multiplied against all of the group's query heads on the matrix cores; the per-request
+ * remainder is walked per request, and the two partial results are merged by LSE
+ * (merge_state_v2 arithmetic, sgl-kernel/csrc/attention/merge_attn_states.cu:31-106).
+ * Same result as sglk_decode_attention on the same inputs (fp tolerance); no counterpart kernel in
+ * the reference, whose decode walks every request's full kv_indices
+ * (triton_ops/decode_attention.py:107-150).
+ * workspace: fp32, sglk_decode_shared_workspace_bytes() bytes. */
+SGLK_API int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits);
+SGLK_API int sglk_decode_attention_shared_prefix(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, const int32_t* group_indptr, const int32_t* prefix_lens, int G,
+    float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream);
+
+/* Longest common prefix (in slots) of the batch's req_to_token rows, one group covering the whole
+ * batch: out[0] = min over b of the first j with req_to_token[idx[b], j] != req_to_token[idx[0], j],
+ * capped at min(seq_lens) - 1.  Device-side helper for the shared-prefix path when the scheduler
+ * does not hand over radix-tree groups. */
+SGLK_API int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_stride,
+                                    const void* req_pool_indices, int idx_is64, const void* seq_lens,
+                                    int lens_is64, int bs, int32_t* out, void* stream);
+
+/* ------------------------------------------------------------------ A2: extend attention ------ */
+
+/* Prefill with a cached prefix: stage 1 over the prefix through kv_indices, stage 2 causal over the
+ * contiguous new tokens.  Replaces extend_attention_fwd,
+ * python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438
+ * (== extend_attention_cpu, sgl-kernel/csrc/cpu/extend.cpp:481-621).  custom_mask unsupported. */
+SGLK_API int sglk_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend,
+                                   void* o_extend, const void* k_buffer, const void* v_buffer,
+                                   const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                   const int32_t* kv_indices, int B, int Hq, int Hkv, int D, int Dv,
+                                   int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                   int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h,
+                                   int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n,
+                                   int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                   int max_extend_len, float sm_scale, float logit_cap, int causal,
+                                   int dtype, void* stream);
+
+/* ------------------------------------------------------------------ A3: merge_state ----------- */
+
+/* LSE merge of two partial attention results, v:[n,h,d] (dtype), s:[n,h] fp32; s_out may be NULL.
+ * Replaces merge_state_v2, sgl-kernel/csrc/attention/merge_attn_states.cu:182-204
+ * (python/sgl_kernel/attention.py:31-51). */
+SGLK_API int sglk_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b,
+                              void* v_out, float* s_out, int64_t n, int h, int d, int dtype,
+                              void* stream);
+
+/* ------------------------------------------------------------------ P1: KV pool write --------- */
+
+/* k_buffer[loc[t]] = k[t], v_buffer[loc[t]] = v[t]  (rows of Hkv*D / Hkv*Dv elements).
+ * Replaces MHATokenToKVPool.set_kv_buffer, python/sglang/srt/mem_cache/memory_pool.py:378-412. */
+SGLK_API int sglk_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const void* v,
+                                const void* loc, int loc_is64, int64_t tokens, int row_k, int row_v,
+                                int64_t kbuf_stride_n, int64_t vbuf_stride_n, int64_t k_stride_t,
+                                int64_t v_stride_t, int elem_bytes, void* stream);
+
+/* ------------------------------------------------------------------ E1: elementwise ----------- */
+
+/* Replaces rmsnorm / fused_add_rmsnorm, sgl-kernel/python/sgl_kernel/elementwise.py:9-83
+ * (arithmetic: python/sglang/srt/layers/layernorm.py:88-107). */
+SGLK_API int sglk_rmsnorm(void* out, const void* x, const void* weight, int64_t rows, int hidden,
+                          int64_t x_stride, int64_t out_stride, float eps, int gemma, int dtype,
+                          void* stream);
+SGLK_API int sglk_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t rows,
+                                    int hidden, float eps, int gemma, int dtype, void* stream);
+
+/* out[..., :d] = act(x[..., :d]) * x[..., d:]; act: 0 silu, 1 gelu(tanh), 2 gelu(erf).
+ * Replaces silu_and_mul & co, sgl-kernel/csrc/elementwise/activation.cu:22-50. */
+SGLK_API int sglk_act_and_mul(void* out, const void* x, int64_t rows, int d, int act, int dtype,
+                              void* stream);
+
+/* In-place RoPE on q [T,Hq,hs] and k [T,Hk,hs] from cos_sin_cache [max_pos, rot] fp32.
+ * Replaces apply_rope_pos_ids_cos_sin_cache, sgl-kernel/csrc/elementwise/rope.cu:22-89. */
+SGLK_API int sglk_rope(void* q, void* k, const float* cos_sin_cache, const int64_t* positions,
+                       int64_t tokens, int q_heads, int k_heads, int head_size, int rot_dim,
+                       int64_t q_stride_t, int64_t k_stride_t, int interleave, int dtype,
+                       void* stream);
+
+/* RoPE on q,k of a fused qkv activation [T, (Hq+2Hkv)*hs] and scatter of the rotated k and of v
+ * into the pool rows loc[t] in one launch (RadixAttention decode: rotary_emb + set_kv_buffer,
+ * python/sglang/srt/models/llama.py:170-175 + memory_pool.py:378-412). */
+SGLK_API int sglk_rope_and_store_kv(void* qkv, const float* cos_sin_cache, const int64_t* positions,
+                                    void* k_buffer, void* v_buffer, const void* loc, int loc_is64,
+                                    int64_t tokens, int q_heads, int kv_heads, int head_size,
+                                    int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                                    int interleave, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ G1: AWQ int4 -------------- */
+
+/* out[r, 8c+j] = ((qweight[r,c] >> 4*ORD[j]) & 15) - ((qzeros[r/G,c] >> 4*ORD[j]) & 15)) * scales[r/G,8c+j]
+ * ORD = {0,4,1,5,2,6,3,7}.  Replaces awq_dequantize, sgl-kernel/csrc/gemm/awq_kernel.cu:184-219. */
+SGLK_API int sglk_awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros,
+                                 void* out, int rows, int qcols, int group_size, int dtype,
+                                 void* stream);
+
+/* One-time re-layout of an AWQ weight for the fused GEMM (done in process_weights_after_loading).
+ * packed: rows*qcols int32 (same byte count as qweight). */
+SGLK_API int sglk_awq_repack(const int32_t* qweight, int32_t* packed, int rows, int qcols,
+                             void* stream);
+
+/* out[M,N] = x[M,K] @ dequant(W) (+bias) with the int4 weights dequantised in registers and fed to
+ * the matrix cores; W in the sglk_awq_repack layout.  Fuses AWQLinearMethod.apply,
+ * python/sglang/srt/layers/quantization/awq.py:197-215 (awq_dequantize + torch.matmul).
+ * workspace: fp32 split-K partials, sglk_awq_gemm_workspace_bytes() bytes (may be 0 -> NULL). */
+SGLK_API int64_t sglk_awq_gemm_workspace_bytes(int M, int N, int K);
+SGLK_API int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales,
+                           const int32_t* qzeros, const void* bias, void* out, float* workspace,
+                           int M, int N, int K, int group_size, int64_t x_stride, int64_t out_stride,
+                           int dtype, void* stream);
+
+/* Skinny dense GEMM out[M,N] = x[M,K] @ W[N,K]^T (+bias), bf16/fp16, for the unquantised lm_head and
+ * the bf16 configuration (UnquantizedLinearMethod.apply, python/sglang/srt/layers/linear.py:170-186;
+ * CPU twin weight_packed_linear, sgl-kernel/csrc/cpu/gemm.cpp). */
+SGLK_API int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N,
+                                int K, int64_t x_stride, int64_t w_stride, int64_t out_stride,
+                                int dtype, void* stream);
+
+/* ------------------------------------------------------------------ G2/G3: fp8 ---------------- */
+
+/* Replaces sgl_per_token_quant_fp8, sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:78-106. */
+SGLK_API int sglk_per_token_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int hidden,
+                                      int dtype, void* stream);
+/* Replaces sgl_per_token_group_quant_fp8, sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:96-197.
+ * scale_col_major: scales laid out [hidden/group, rows] instead of [rows, hidden/group]. */
+SGLK_API int sglk_per_token_group_quant_fp8(const void* x, void* q, float* scales, int64_t rows,
+                                            int hidden, int group_size, float eps, float fp8_min,
+                                            float fp8_max, int scale_col_major, int dtype,
+                                            void* stream);
+/* Replaces sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu. */
+SGLK_API int sglk_per_tensor_quant_fp8(const void* x, void* q, float* scale, int64_t numel,
+                                       int is_static, int dtype, void* stream);
+/* out = (A @ B) * scales_a[M] * scales_b[N] (+bias); A [M,K] e4m3 row-major, B given as [N,K]
+ * row-major (the reference's column-major [K,N]).  Replaces fp8_scaled_mm,
+ * sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146. */
+SGLK_API int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* scales_a,
+                                const float* scales_b, const void* bias, void* out, int M, int N,
+                                int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
+                                int out_dtype, void* stream);
+/* DeepSeek block-scaled form: scales_a [M, K/128] (stride given, row- or M-major), scales_b
+ * [N/128, K/128] or its transpose.  Replaces fp8_blockwise_scaled_mm,
+ * sgl-kernel/csrc/gemm/fp8_blockwise_gemm_kernel.cu:345-423. */
+SGLK_API int sglk_fp8_blockwise_scaled_mm(const void* a, const void* b_nk, const float* scales_a,
+                                          const float* scales_b, void* out, int M, int N, int K,
+                                          int64_t sa_stride_m, int64_t sa_stride_k,
+                                          int64_t sb_stride_n, int64_t sb_stride_k, int out_dtype,
+                                          void* stream);
+
+/* ------------------------------------------------------------------ C1: custom all-reduce ----- */
+
+/* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.
+ * Replaces the ROCm op set of sgl-kernel/csrc/torch_extension_rocm.cc:25-55
+ * (python/sgl_kernel/allreduce.py:5-50; device code custom_all_reduce_hip.cuh:155-575). */
+SGLK_API int64_t sglk_ar_meta_size(void);
+/* meta_ptrs[w]: every rank's signal buffer as mapped into THIS process (uncached device memory,
+ * sglk_ar_meta_size() + staging bytes); returns an opaque handle (0 on failure). */
+SGLK_API int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi);
+SGLK_API int sglk_ar_dispose(int64_t fa);
+/* data_ptrs[w]: every rank's registered input buffer for `local` (peer mappings). */
+SGLK_API int sglk_ar_register_buffer(int64_t fa, void* local, void* const* data_ptrs);
+SGLK_API int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, int dtype,
+                                void* stream);
+/* IPC plumbing (hipIpcGetMemHandle / hipIpcOpenMemHandle / uncached allocation) */
+SGLK_API int sglk_ipc_handle_bytes(void);
+SGLK_API int sglk_ipc_get_handle(void* dev_ptr, void* handle_out);
+SGLK_API void* sglk_ipc_open_handle(const void* handle);
+SGLK_API int sglk_ipc_close(void* mapped);
+SGLK_API void* sglk_alloc_uncached(int64_t bytes);
+SGLK_API int sglk_free_uncached(void* p);
+
+/* ------------------------------------------------------------------ R1-R4: radix tree (host) -- */
+
+/* Native prefix tree behind RadixCache (python/sglang/srt/mem_cache/radix_cache.py:77-653,
+ * tree_node.py:28-79).  Host-side, no GPU.  Node handles are stable int64 ids (root = 0).
+ * compat: 1 reproduces the fork's behaviour bit for bit (fuzzy key match with up to 11 mismatches,
+ * private root, 1024-token chunks); 0 is the exact-match upstream behaviour. */
+SGLK_API int64_t sglk_radix_create(int compat_fork);
+SGLK_API void sglk_radix_destroy(int64_t tree);
+SGLK_API void sglk_radix_reset(int64_t tree);
+SGLK_API void sglk_radix_set_epoch(int64_t tree, int64_t epoch);
+/* match_prefix (radix_cache.py:120-150,333-390).  user_id < 0: no user given.  Writes up to `cap`
+ * matched slots into out_slots, returns the matched length; *last_node receives the node handle;
+ * slots released by the entropy check (radix_cache.py:393-411) are appended to the free queue. */
+SGLK_API int64_t sglk_radix_match_prefix(int64_t tree, const int32_t* key, int64_t key_len,
+                                         int64_t user_id, int64_t* out_slots, int64_t cap,
+                                         int64_t* last_node);
+/* insert (radix_cache.py:152-158,501-564): returns the matched prefix length; ids of nodes created
+ * (to be submitted to the privacy judge, radix_cache.py:544-548) are written to new_nodes. */
+SGLK_API int64_t sglk_radix_insert(int64_t tree, const int32_t* key, const int64_t* slots,
+                                   int64_t len, int64_t user_id, int64_t* new_nodes,
+                                   int64_t new_cap, int64_t* n_new);
+SGLK_API int64_t sglk_radix_inc_lock_ref(int64_t tree, int64_t node);
+SGLK_API int64_t sglk_radix_dec_lock_ref(int64_t tree, int64_t node);
+/* evict (radix_cache.py:249-283): frees leaves in epoch order until num_tokens are released; the
+ * released slots are appended to the free queue. */
+SGLK_API void sglk_radix_evict(int64_t tree, int64_t num_tokens);
+/* drain the free queue (slots handed back to TokenToKVPoolAllocator.free) */
+SGLK_API int64_t sglk_radix_take_freed(int64_t tree, int64_t* out, int64_t cap);
+SGLK_API int64_t sglk_radix_evictable_size(int64_t tree);
+SGLK_API int64_t sglk_radix_protected_size(int64_t tree);
+SGLK_API int64_t sglk_radix_total_size(int64_t tree);
+/* SafeKV node state (tree_node.py:50-52; private_client.py:125-140 flips these asynchronously) */
+SGLK_API int sglk_radix_node_set_privacy(int64_t tree, int64_t node, int is_private, int need_check);
+SGLK_API int sglk_radix_node_get(int64_t tree, int64_t node, int64_t* fields /*[12]*/);
+SGLK_API int64_t sglk_radix_node_key(int64_t tree, int64_t node, int32_t* key_out, int64_t* val_out,
+                                     int64_t cap);
+/* pre-order dump, children ordered by first token: per node 12 int64 fields (see sglk_radix_node_get) */
+SGLK_API int64_t sglk_radix_dump(int64_t tree, int64_t* node_ids, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGLK_H_ */

@@ -1,0 +1,251 @@
+"""TEST INFRASTRUCTURE ONLY: ctypes front-end to the C oracle (oracle/oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product package never does: it fails loudly when the HIP library is missing instead.
+
+All functions take and return CPU torch tensors; half-precision inputs are widened to fp32
+exactly, and outputs are rounded to the activation dtype where the reference rounds.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_SRC_PATH = os.path.join(_HERE, "oracle.c")
+
+
+def build(force: bool = False) -> str:
+    """Compile oracle.c with gcc (seconds)."""
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(_SRC_PATH):
+        subprocess.check_call(
+            ["gcc", "-O2", "-fPIC", "-shared", "-fopenmp", _SRC_PATH, "-o", _LIB_PATH, "-lm"]
+        )
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = C.CDLL(_LIB_PATH)
+    return _lib
+
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+
+
+def _f32(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().cpu().to(torch.float32).numpy())
+
+
+def _i32(t) -> np.ndarray:
+    return np.ascontiguousarray(torch.as_tensor(t).detach().cpu().to(torch.int32).numpy())
+
+
+def _i64(t) -> np.ndarray:
+    return np.ascontiguousarray(torch.as_tensor(t).detach().cpu().to(torch.int64).numpy())
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _raw16(t: torch.Tensor) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().cpu().contiguous().view(torch.int16).numpy()).view(np.uint16)
+
+
+def create_kv_indices(req_to_token, req_pool_indices, lens, kv_indptr, kv_start=None):
+    r2t = _i32(req_to_token)
+    idx, ln, ptr = _i64(req_pool_indices), _i64(lens), _i32(kv_indptr)
+    st = None if kv_start is None else _i64(kv_start)
+    out = np.zeros(int(ptr[len(ln)]), dtype=np.int32)
+    lib().oracle_create_kv_indices(_p(r2t), C.c_int64(r2t.shape[1]), _p(idx), _p(ln), _p(ptr), _p(st), _p(out), C.c_int(len(ln)))
+    return torch.from_numpy(out)
+
+
+def get_num_kv_splits(seq_lens, num_group, num_head, num_kv_head, max_kv_splits, device_core_count):
+    sl = _i64(seq_lens)
+    out = np.zeros(len(sl) * num_group, dtype=np.int32)
+    lib().oracle_get_num_kv_splits(_p(out), _p(sl), C.c_int(len(sl)), C.c_int(num_group), C.c_int(num_head),
+                                   C.c_int(num_kv_head), C.c_int(max_kv_splits), C.c_int(device_core_count))
+    return torch.from_numpy(out)
+
+
+def decode_attention(q, k_buffer, v_buffer, kv_indptr, kv_indices, num_kv_splits, sm_scale, logit_cap=0.0,
+                     return_lse=False):
+    """fp32 result [B,Hq,Dv] (not rounded to the activation type)."""
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    qf, kf, vf = _f32(q), _f32(k_buffer), _f32(v_buffer)
+    ptr, ind = _i32(kv_indptr), _i32(kv_indices)
+    ns = None if num_kv_splits is None else _i32(num_kv_splits)
+    o = np.zeros((B, Hq, Dv), dtype=np.float32)
+    lse = np.zeros((B, Hq), dtype=np.float32)
+    lib().oracle_decode_attention(_p(qf), _p(kf), _p(vf), _p(o), _p(lse), _p(ptr), _p(ind), _p(ns),
+                                  C.c_int(B), C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(Dv),
+                                  C.c_float(sm_scale), C.c_float(logit_cap))
+    if return_lse:
+        return torch.from_numpy(o), torch.from_numpy(lse)
+    return torch.from_numpy(o)
+
+
+def extend_attention(q_ext, k_ext, v_ext, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, sm_scale,
+                     logit_cap=0.0, causal=True):
+    T, Hq, D = q_ext.shape
+    Hkv, Dv = v_ext.shape[1], v_ext.shape[2]
+    o = np.zeros((T, Hq, Dv), dtype=np.float32)
+    a = [_f32(q_ext), _f32(k_ext), _f32(v_ext)]
+    kb, vb = _f32(k_buffer), _f32(v_buffer)
+    qo, kp, ki = _i32(qo_indptr), _i32(kv_indptr), _i32(kv_indices)
+    lib().oracle_extend_attention(_p(a[0]), _p(a[1]), _p(a[2]), _p(o), _p(kb), _p(vb), _p(qo), _p(kp), _p(ki),
+                                  C.c_int(len(qo) - 1), C.c_int(Hq), C.c_int(Hkv), C.c_int(D), C.c_int(Dv),
+                                  C.c_float(sm_scale), C.c_float(logit_cap), C.c_int(1 if causal else 0))
+    return torch.from_numpy(o)
+
+
+def merge_state(v_a, s_a, v_b, s_b):
+    n, h, d = v_a.shape
+    va, vb, sa, sb = _f32(v_a), _f32(v_b), _f32(s_a), _f32(s_b)
+    vo = np.zeros_like(va)
+    so = np.zeros_like(sa)
+    lib().oracle_merge_state(_p(va), _p(sa), _p(vb), _p(sb), _p(vo), _p(so), C.c_int64(n * h), C.c_int(d))
+    return torch.from_numpy(vo), torch.from_numpy(so)
+
+
+def awq_dequantize(qweight, scales, qzeros):
+    rows, qcols = qweight.shape
+    group = rows // scales.shape[0]
+    qw, qz = _i32(qweight), _i32(qzeros)
+    sc = _raw16(scales)
+    out = np.zeros((rows, qcols * 8), dtype=np.uint16)
+    lib().oracle_awq_dequantize(_p(qw), _p(sc), _p(qz), _p(out), C.c_int(rows), C.c_int(qcols), C.c_int(group),
+                                C.c_int(_DT[scales.dtype]))
+    return torch.from_numpy(out.view(np.int16)).view(scales.dtype)
+
+
+def half_matmul(x, w, bias=None):
+    """x:[M,K] @ w:[K,N] (half/bf16), fp32 accumulate, rounded once to x.dtype."""
+    M, K = x.shape
+    N = w.shape[1]
+    xf = _f32(x)
+    wr = _raw16(w.to(x.dtype))
+    bf = None if bias is None else _f32(bias)
+    out = np.zeros((M, N), dtype=np.float32)
+    lib().oracle_half_matmul(_p(xf), _p(wr), _p(bf), _p(out), C.c_int(M), C.c_int(K), C.c_int(N), C.c_int(_DT[x.dtype]))
+    return torch.from_numpy(out).to(x.dtype)
+
+
+def awq_gemm(x, qweight, scales, qzeros, bias=None):
+    return half_matmul(x, awq_dequantize(qweight, scales, qzeros), bias)
+
+
+def rmsnorm(x, weight, eps):
+    xf, wf = _f32(x), _f32(weight)
+    out = np.zeros_like(xf)
+    lib().oracle_rmsnorm(_p(xf), _p(wf), _p(out), C.c_int64(xf.shape[0]), C.c_int(xf.shape[1]), C.c_float(eps),
+                         C.c_int(_DT[x.dtype]))
+    return torch.from_numpy(out).to(x.dtype)
+
+
+def fused_add_rmsnorm(x, residual, weight, eps):
+    """Returns (normed, new_residual); inputs untouched."""
+    xf, rf, wf = _f32(x).copy(), _f32(residual).copy(), _f32(weight)
+    lib().oracle_fused_add_rmsnorm(_p(xf), _p(rf), _p(wf), C.c_int64(xf.shape[0]), C.c_int(xf.shape[1]),
+                                   C.c_float(eps), C.c_int(_DT[x.dtype]))
+    return torch.from_numpy(xf).to(x.dtype), torch.from_numpy(rf).to(x.dtype)
+
+
+def silu_and_mul(x):
+    d = x.shape[-1] // 2
+    xf = _f32(x.reshape(-1, 2 * d))
+    out = np.zeros((xf.shape[0], d), dtype=np.float32)
+    lib().oracle_silu_and_mul(_p(xf), _p(out), C.c_int64(xf.shape[0]), C.c_int(d), C.c_int(_DT[x.dtype]))
+    return torch.from_numpy(out).to(x.dtype).reshape(*x.shape[:-1], d)
+
+
+def rope(x, positions, cos_sin_cache, head_size, is_neox=True):
+    """x: [tokens, heads*head_size]; returns rotated copy."""
+    tokens = x.shape[0]
+    heads = x.shape[1] // head_size
+    xf = _f32(x).copy()
+    pos, cs = _i64(positions), _f32(cos_sin_cache)
+    lib().oracle_rope(_p(xf), _p(pos), _p(cs), C.c_int64(tokens), C.c_int(heads), C.c_int(head_size),
+                      C.c_int(cs.shape[1]), C.c_int(0 if is_neox else 1), C.c_int(_DT[x.dtype]))
+    return torch.from_numpy(xf).to(x.dtype)
+
+
+def e4m3_decode(q: torch.Tensor) -> torch.Tensor:
+    raw = np.ascontiguousarray(q.detach().cpu().contiguous().view(torch.uint8).numpy())
+    out = np.zeros(raw.shape, dtype=np.float32)
+    lib().oracle_e4m3_decode(_p(raw), _p(out), C.c_int64(raw.size))
+    return torch.from_numpy(out)
+
+
+def e4m3_encode(x: torch.Tensor) -> torch.Tensor:
+    xf = _f32(x)
+    out = np.zeros(xf.shape, dtype=np.uint8)
+    lib().oracle_e4m3_encode(_p(xf), _p(out), C.c_int64(xf.size))
+    return torch.from_numpy(out).view(torch.float8_e4m3fn)
+
+
+def per_token_quant_fp8(x, fp8_max=448.0):
+    xf = _f32(x)
+    q = np.zeros(xf.shape, dtype=np.uint8)
+    s = np.zeros((xf.shape[0],), dtype=np.float32)
+    lib().oracle_per_token_quant_fp8(_p(xf), _p(q), _p(s), C.c_int64(xf.shape[0]), C.c_int(xf.shape[1]), C.c_float(fp8_max))
+    return torch.from_numpy(q).view(torch.float8_e4m3fn), torch.from_numpy(s).reshape(-1, 1)
+
+
+def per_token_group_quant_fp8(x, group_size, eps=1e-10, fp8_min=-448.0, fp8_max=448.0):
+    xf = _f32(x)
+    q = np.zeros(xf.shape, dtype=np.uint8)
+    s = np.zeros((xf.shape[0], xf.shape[1] // group_size), dtype=np.float32)
+    lib().oracle_per_token_group_quant_fp8(_p(xf), _p(q), _p(s), C.c_int64(xf.shape[0]), C.c_int(xf.shape[1]),
+                                           C.c_int(group_size), C.c_float(eps), C.c_float(fp8_min), C.c_float(fp8_max))
+    return torch.from_numpy(q).view(torch.float8_e4m3fn), torch.from_numpy(s)
+
+
+def fp8_scaled_mm(a, b, scale_a, scale_b, out_dtype, bias=None):
+    """a:[M,K] e4m3; b:[K,N] e4m3 column-major (i.e. b.t() contiguous), as the reference takes it."""
+    M, K = a.shape
+    N = b.shape[1]
+    ar = np.ascontiguousarray(a.detach().cpu().contiguous().view(torch.uint8).numpy())
+    br = np.ascontiguousarray(b.detach().cpu().t().contiguous().view(torch.uint8).numpy())
+    sa, sb = _f32(scale_a.reshape(-1)), _f32(scale_b.reshape(-1))
+    bf = None if bias is None else _f32(bias)
+    out = np.zeros((M, N), dtype=np.float32)
+    lib().oracle_fp8_scaled_mm(_p(ar), _p(br), _p(sa), _p(sb), _p(bf), _p(out), C.c_int(M), C.c_int(N), C.c_int(K),
+                               C.c_int(_DT[out_dtype]))
+    return torch.from_numpy(out).to(out_dtype)
+
+
+def fp8_blockwise_mm(a, b_nk, a_scales, b_scales, out_dtype, block_n=128, block_k=128):
+    """a:[M,K], a_scales:[M,K/bk]; b_nk:[N,K], b_scales:[N/bn,K/bk]."""
+    M, K = a.shape
+    N = b_nk.shape[0]
+    ar = np.ascontiguousarray(a.detach().cpu().contiguous().view(torch.uint8).numpy())
+    br = np.ascontiguousarray(b_nk.detach().cpu().contiguous().view(torch.uint8).numpy())
+    sa, sb = _f32(a_scales), _f32(b_scales)
+    out = np.zeros((M, N), dtype=np.float32)
+    lib().oracle_fp8_blockwise_mm(_p(ar), _p(br), _p(sa), _p(sb), _p(out), C.c_int(M), C.c_int(N), C.c_int(K),
+                                  C.c_int(block_n), C.c_int(block_k), C.c_int(_DT[out_dtype]))
+    return torch.from_numpy(out).to(out_dtype)
+
+
+def allreduce_sum(bufs, dtype):
+    arrs = [_f32(b) for b in bufs]
+    n = arrs[0].size
+    ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    out = np.zeros(arrs[0].shape, dtype=np.float32)
+    lib().oracle_allreduce_sum(ptrs, C.c_int(len(arrs)), _p(out), C.c_int64(n), C.c_int(_DT[dtype]))
+    return torch.from_numpy(out).to(dtype)

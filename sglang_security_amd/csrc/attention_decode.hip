@@ -1,0 +1,580 @@
+// Paged (token-granular) decode attention and its metadata kernels.
+//
+// Data layout in HBM (the reference's pool, python/sglang/srt/mem_cache/memory_pool.py:277-296):
+//   k_buffer [N, Hkv, D], v_buffer [N, Hkv, Dv] -- one row per token slot, slot 0 a dummy row;
+//   kv_indices[kv_indptr[b] .. kv_indptr[b+1]) lists request b's slots in sequence order.
+//
+// Fast path (16-bit types, D = Dv = 128, any GQA group): one wave per (request, kv head, split).
+// The wave walks its slots in tiles of 32 tokens: each K/V row (256 B) is fetched by 16 lanes as
+// one contiguous 16-byte piece per lane (4 whole rows per wave instruction), parked in registers
+// while the previous tile is being multiplied, then written to a wave-private, XOR-swizzled LDS
+// tile.  S^T = K.Q^T and O^T += V^T.P^T run on the matrix cores (v_mfma_f32_16x16x32): the K tile
+// is read by rows (ds_read_b128), the V tile by columns (ds_read_b64_tr_b16), and the S^T
+// accumulator registers are, as they stand, the P^T operand of the second product.  Softmax
+// statistics live one head per lane (online max / sum, exp2 domain), combined across the four
+// 16-lane groups with wave shuffles.
+//
+// Everything else (fp32, odd head sizes, MLA 576/512) takes the generic wave-per-(request, head,
+// split) kernel.  Partials are merged by log-sum-exp in a second kernel, as in the reference
+// (triton_ops/decode_attention.py:497-557).
+#include "common.h"
+
+namespace sglk {
+
+static constexpr int kMinBlockKV = 32;  // decode_attention.py:40 (_MIN_BLOCK_KV)
+
+__device__ __forceinline__ int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+
+// ---------------------------------------------------------------------------------------------
+// metadata
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) create_kv_indices_kernel(const int32_t* __restrict__ req_to_token,
+                                                                int64_t row_stride, const void* req_pool_indices,
+                                                                int idx_is64, const void* lens, int lens_is64,
+                                                                const int32_t* __restrict__ kv_indptr,
+                                                                const void* kv_start, int start_is64,
+                                                                int32_t* __restrict__ kv_indices) {
+  const int b = blockIdx.x;
+  const int64_t row = ld_idx(req_pool_indices, idx_is64, b);
+  const int64_t n = ld_idx(lens, lens_is64, b);
+  const int64_t st = kv_start ? ld_idx(kv_start, start_is64, b) : 0;
+  const int32_t* src = req_to_token + row * row_stride + st;
+  int32_t* dst = kv_indices + kv_indptr[b];
+  for (int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.y * 256) dst[j] = src[j];
+}
+
+// inclusive scan of up to any bs by one block (bs is a batch size: at most a few thousand)
+__global__ void __launch_bounds__(256) cumsum_kernel(const void* seq_lens, int lens_is64, int32_t* kv_indptr, int bs) {
+  __shared__ int32_t part[256];
+  const int per = (bs + 255) / 256;
+  const int lo = threadIdx.x * per, hi = min(lo + per, bs);
+  int32_t s = 0;
+  for (int i = lo; i < hi; ++i) s += (int32_t)ld_idx(seq_lens, lens_is64, i);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t run = 0;
+    for (int i = 0; i < 256; ++i) {
+      const int32_t v = part[i];
+      part[i] = run;
+      run += v;
+    }
+    kv_indptr[0] = 0;
+  }
+  __syncthreads();
+  int32_t run = part[threadIdx.x];
+  for (int i = lo; i < hi; ++i) {
+    run += (int32_t)ld_idx(seq_lens, lens_is64, i);
+    kv_indptr[i + 1] = run;
+  }
+}
+
+// get_num_kv_splits_triton (triton_backend.py:23-72): one block, integer arithmetic except the
+// log2 growth heuristic which the reference evaluates in fp32.
+__device__ __forceinline__ void num_kv_splits_body(int32_t* num_kv_splits, const void* seq_lens, int lens_is64,
+                                                   int num_seq, int num_group, int num_head, int num_kv_head,
+                                                   int max_kv_splits, int device_core_count, int* red) {
+  int mx = 0;
+  for (int i = threadIdx.x; i < num_seq; i += blockDim.x) mx = max(mx, (int)ld_idx(seq_lens, lens_is64, i));
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const int max_len = red[0];
+  __syncthreads();
+  int mn = max_len;
+  for (int i = threadIdx.x; i < num_seq; i += blockDim.x) mn = min(mn, (int)ld_idx(seq_lens, lens_is64, i));
+  red[threadIdx.x] = mn;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = min(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  int min_len = red[0];
+  __syncthreads();
+  if ((int64_t)max_len * 8 < (int64_t)min_len * 10) min_len = max_len;
+  if (min_len < 1) min_len = 1;
+  const int splits1 = min(cdiv_i(max_len, min_len), max_kv_splits);
+  const int chunk1 = max(cdiv_i(max_len, max(splits1, 1)), 1);
+  const float ext_seq_len = (float)max_len / 64.0f;
+  const float lg = fmaxf(log2f(ext_seq_len), 1.0f);
+  const int ext_cores = (int)((float)device_core_count * lg);
+  int block_h = 16;
+  const int group = num_head / num_kv_head;
+  int64_t token_grid;
+  if (group == 1) {
+    token_grid = (int64_t)num_seq * num_group * num_head;
+  } else {
+    block_h = min(block_h, group);
+    token_grid = (int64_t)num_seq * num_group * cdiv_i(num_head, block_h);
+  }
+  const int splits2 = (int)min((int64_t)((ext_cores + token_grid - 1) / token_grid), (int64_t)max_kv_splits);
+  const int chunk2 = max(cdiv_i(max_len, max(splits2, 1)), 1);
+  for (int i = threadIdx.x; i < num_seq; i += blockDim.x) {
+    const int L = (int)ld_idx(seq_lens, lens_is64, i);
+    const int v = max(cdiv_i(L, chunk1), cdiv_i(L, chunk2));
+    for (int g = 0; g < num_group; ++g) num_kv_splits[i * num_group + g] = v;
+  }
+}
+
+__global__ void __launch_bounds__(256) num_kv_splits_kernel(int32_t* num_kv_splits, const void* seq_lens,
+                                                            int lens_is64, int num_seq, int num_group, int num_head,
+                                                            int num_kv_head, int max_kv_splits, int device_core_count) {
+  __shared__ int red[256];
+  num_kv_splits_body(num_kv_splits, seq_lens, lens_is64, num_seq, num_group, num_head, num_kv_head, max_kv_splits,
+                     device_core_count, red);
+}
+
+// Longest common slot prefix of the batch (one group = whole batch). out[0] is pre-set by the launcher's
+// memset-free protocol: block 0 thread 0 seeds nothing; every block atomically lowers out[0].
+__global__ void __launch_bounds__(256) common_prefix_kernel(const int32_t* __restrict__ req_to_token,
+                                                            int64_t row_stride, const void* req_pool_indices,
+                                                            int idx_is64, const void* seq_lens, int lens_is64, int bs,
+                                                            int32_t* out) {
+  // one block per request: first mismatch against request 0
+  __shared__ int red[256];
+  const int b = blockIdx.x;
+  const int64_t r0 = ld_idx(req_pool_indices, idx_is64, 0), rb = ld_idx(req_pool_indices, idx_is64, b);
+  const int len0 = (int)ld_idx(seq_lens, lens_is64, 0), lenb = (int)ld_idx(seq_lens, lens_is64, b);
+  const int n = min(len0, lenb) - 1;  // the newest token is never shared
+  const int32_t* a = req_to_token + r0 * row_stride;
+  const int32_t* c = req_to_token + rb * row_stride;
+  int first = n < 0 ? 0 : n;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (a[j] != c[j]) {
+      first = j;
+      break;
+    }
+  }
+  red[threadIdx.x] = first;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = min(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMin(out, red[0]);
+}
+
+__global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
+
+// ---------------------------------------------------------------------------------------------
+// generic stage 1: one wave per (request, query head, split); any head size, any float type
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DV_PER_LANE>
+__global__ void __launch_bounds__(64) decode_stage1_generic(
+    const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
+    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
+    float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv, int D,
+    int Dv, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+    int64_t v_stride_h, float sm_scale, float logit_cap) {
+  extern __shared__ float qs[];  // D floats
+  const int b = blockIdx.x, h = blockIdx.y, split = blockIdx.z;
+  const int lane = threadIdx.x;
+  const int kvh = h / (Hq / Hkv);
+  const int start = kv_indptr[b];
+  const int len = kv_indptr[b + 1] - start;
+  const int splits = max(num_kv_splits[b], 1);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int s0 = per_split * split, s1 = min(s0 + per_split, len);
+  if (s1 <= s0) return;
+  for (int d = lane; d < D; d += 64) qs[d] = ld<T>(q, (int64_t)b * q_stride_b + (int64_t)h * q_stride_h + d);
+  __syncthreads();
+  float m = -INFINITY, l = 0.f;
+  float acc[DV_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < DV_PER_LANE; ++i) acc[i] = 0.f;
+  for (int t0 = s0; t0 < s1; t0 += 64) {
+    const int tok = t0 + lane;
+    const bool valid = tok < s1;
+    const int64_t loc = valid ? (int64_t)kv_indices[start + tok] : 0;
+    float s = 0.f;
+    if (valid) {
+      const int64_t kb = loc * k_stride_n + (int64_t)kvh * k_stride_h;
+      for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(k_buffer, kb + d);
+      s *= sm_scale;
+      if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
+    } else {
+      s = -INFINITY;
+    }
+    const float m_new = fmaxf(m, wave_max(s));
+    const float alpha = expf(m - m_new);
+    const float p = valid ? expf(s - m_new) : 0.f;
+    l = l * alpha + wave_sum(p);
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < DV_PER_LANE; ++i) acc[i] *= alpha;
+    const int cnt = min(64, s1 - t0);
+    for (int j = 0; j < cnt; ++j) {
+      const float pj = __shfl(p, j, 64);
+      const int64_t lj = __shfl((long long)loc, j, 64);
+      const int64_t vb = lj * v_stride_n + (int64_t)kvh * v_stride_h;
+#pragma unroll
+      for (int i = 0; i < DV_PER_LANE; ++i) {
+        const int d = lane + 64 * i;
+        if (d < Dv) acc[i] += pj * ld<T>(v_buffer, vb + d);
+      }
+    }
+  }
+  const int64_t ob = (((int64_t)b * Hq + h) * max_kv_splits + split);
+#pragma unroll
+  for (int i = 0; i < DV_PER_LANE; ++i) {
+    const int d = lane + 64 * i;
+    if (d < Dv) attn_logits[ob * Dv + d] = acc[i] / l;
+  }
+  if (lane == 0) attn_lse[ob] = m + logf(l);
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage 2: LSE merge of the split partials (decode_attention.py:497-557)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(128) decode_stage2(const float* __restrict__ attn_logits,
+                                                     const float* __restrict__ attn_lse, void* __restrict__ o,
+                                                     const int32_t* __restrict__ kv_indptr,
+                                                     const int32_t* __restrict__ num_kv_splits, int max_kv_splits,
+                                                     int Hq, int Dv, int64_t o_stride_b, int64_t o_stride_h) {
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int len = kv_indptr[b + 1] - kv_indptr[b];
+  const int splits = max(num_kv_splits[b], 1);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int64_t base = ((int64_t)b * Hq + h) * max_kv_splits;
+  for (int d = threadIdx.x; d < Dv; d += 128) {
+    float e_sum = 0.f, e_max = -INFINITY, acc = 0.f;
+    for (int s = 0; s < max_kv_splits; ++s) {
+      const int s0 = per_split * s, s1 = min(s0 + per_split, len);
+      if (s1 > s0) {
+        const float tv = attn_logits[(base + s) * Dv + d];
+        const float tl = attn_lse[base + s];
+        const float n_max = fmaxf(tl, e_max);
+        const float old = expf(e_max - n_max), w = expf(tl - n_max);
+        acc = acc * old + w * tv;
+        e_sum = e_sum * old + w;
+        e_max = n_max;
+      }
+    }
+    st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d, acc / e_sum);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast path: D = Dv = 128, 16-bit types, matrix cores, wave-private LDS tiles
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<bf16_t> {
+  using frag = bfloat8;
+  static __device__ __forceinline__ float4v mma(short8 a, short8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfloat8, a), __builtin_bit_cast(bfloat8, b), c, 0,
+                                                   0, 0);
+  }
+};
+template <>
+struct Mfma16<f16_t> {
+  using frag = half8;
+  static __device__ __forceinline__ float4v mma(short8 a, short8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0,
+                                                  0);
+  }
+};
+
+typedef __attribute__((address_space(3))) short4v* lds_short4_ptr;
+
+__device__ __forceinline__ short4v lds_read_tr16(const char* p) {
+  // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered
+  // column-major (lane i of the group receives column i of the four rows).  EXEC must be full.
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(p));
+}
+
+static constexpr int kTile = 32;                 // tokens per tile
+static constexpr int kRowBytes = 256;            // 128 x 16-bit
+static constexpr int kTileBytes = kTile * kRowBytes;  // 8 KiB each for K and V
+static constexpr int kWavesPerBlock = 4;
+static constexpr int kLdsPerWave = 2 * kTileBytes;  // K tile + V tile
+
+// K tile: 16-byte chunk c of row r sits at chunk slot c ^ (r & 15): the row reads of one MFMA
+// operand (16 rows, same chunk) then fall on 16 different slots of the 256-byte bank row.
+__device__ __forceinline__ int k_off(int r, int c) { return r * kRowBytes + ((c ^ (r & 15)) << 4); }
+// V tile: 32-byte granule g of row r sits at granule slot g ^ (r & 7): the transposed reads of one
+// 32-lane half (8 rows, same granule) fall on 8 different 32-byte slots.
+__device__ __forceinline__ int v_off(int r, int byte_in_row) {
+  const int g = byte_in_row >> 5;
+  return r * kRowBytes + (((g ^ (r & 7)) << 5) | (byte_in_row & 31));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
+    const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
+    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
+    float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv,
+    int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+    int64_t v_stride_h, float sm_scale, float logit_cap) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  char* kl = lds_all + wid * kLdsPerWave;
+  char* vl = kl + kTileBytes;
+
+  const int b = blockIdx.x;
+  const int kvh = blockIdx.y / head_tiles, ht = blockIdx.y - kvh * head_tiles;
+  const int split = blockIdx.z * kWavesPerBlock + wid;
+  const int group = Hq / Hkv;
+  const int start = kv_indptr[b];
+  const int len = kv_indptr[b + 1] - start;
+  const int splits = max(num_kv_splits[b], 1);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int s0 = per_split * split, s1 = min(s0 + per_split, len);
+  // wave-uniform exit; no block-level synchronisation is used below
+  if (split >= max_kv_splits || s1 <= s0) return;
+
+  const int hl = lane & 15;  // operand column: query head within this head tile / token within a 16-token half
+  const int g = lane >> 4;   // 16-lane group
+  const int head_in_group = ht * 16 + hl;
+  const bool head_ok = head_in_group < group;
+  const int head = kvh * group + head_in_group;
+
+  // Q^T operand: lane (hl, g) holds q[head][32*ks + 8*g .. +8) for ks = 0..3
+  short8 qf[4];
+  {
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (head_ok)
+        qf[ks] = *reinterpret_cast<const short8*>(qp + 32 * ks + 8 * g);
+      else
+        qf[ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  const float LOG2E = 1.4426950408889634f;
+  const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+
+  float m = -INFINITY;  // running max (log2 domain), replicated over the four lane groups
+  float lsum = 0.f;     // this lane's share of the running sum
+  float4v oacc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) oacc[n] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h;
+  const uint16_t* vbase = reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h;
+  const int32_t* idx = kv_indices + start;
+  const int chunk = lane & 15;  // 16-byte piece of the row this lane fetches
+
+  int4v kreg[8], vreg[8];
+  // fetch tile starting at token t0 into registers: instruction i covers rows 4i + g
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int tok = t0 + 4 * i + g;
+      tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
+      const int64_t slot = idx[tok];
+      kreg[i] = *reinterpret_cast<const int4v*>(kbase + slot * k_stride_n + chunk * 8);
+      vreg[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 4 * i + g;
+      *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[i];
+      *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[i];
+    }
+  };
+
+  fetch(s0);
+  for (int t0 = s0; t0 < s1; t0 += kTile) {
+    park();
+    if (t0 + kTile < s1) fetch(t0 + kTile);  // next tile's rows fly while this one is multiplied
+
+    // ---- S^T = K . Q^T : two 16-token halves, lane (hl, g) gets tokens 16*hh + 4*g + r of head hl
+    float4v sacc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
+        sacc[hh] = Mfma16<T>::mma(kf, qf[ks], sacc[hh]);
+      }
+    }
+    // ---- scale / cap / mask, online softmax (exp2 domain)
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = sacc[hh][r] * qk_scale;
+        if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
+        const int tok = t0 + 16 * hh + 4 * g + r;
+        s = tok < s1 ? s : -INFINITY;
+        sv[hh * 4 + r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);  // finite: token t0 of this tile is always valid
+    const float alpha = exp2f(m - m_new);
+    m = m_new;
+    float psum = 0.f;
+    short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p = exp2f(sv[j] - m_new);
+      psum += p;
+      pf[j] = (short)Conv<T>::from_f32(p);
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
+    // ---- O^T += V^T . P^T : eight 16-column blocks of V, read transposed
+    const int i16 = lane & 15;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int byte_in_row = 32 * n + 8 * (i16 & 3);
+      const short4v lo = lds_read_tr16(vl + v_off(4 * g + (i16 >> 2), byte_in_row));
+      const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (i16 >> 2), byte_in_row));
+      const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
+    }
+  }
+
+  // ---- epilogue: total sum over the four lane groups, normalise, store partial
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (head_ok) {
+    const float inv = 1.0f / lsum;
+    const int64_t ob = ((int64_t)b * Hq + head) * max_kv_splits + split;
+    float* dst = attn_logits + ob * 128;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      // lane (hl, g) holds O[head][16n + 4g + r], r = 0..3
+      *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[n] * inv;
+    }
+    if (g == 0) attn_lse[ob] = (m + log2f(lsum)) * 0.6931471805599453f;
+  }
+}
+
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" {
+
+int sglk_create_kv_indices(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,
+                           const void* lens, int lens_is64, const int32_t* kv_indptr, const void* kv_start,
+                           int start_is64, int32_t* kv_indices, int bs, void* stream) {
+  SGLK_CHECK(req_to_token && req_pool_indices && lens && kv_indptr, "create_kv_indices: null pointer");
+  SGLK_CHECK(bs >= 0, "create_kv_indices: negative batch");
+  if (bs == 0) return SGLK_OK;
+  SGLK_CHECK(kv_indices, "create_kv_indices: null output");
+  hipLaunchKernelGGL(create_kv_indices_kernel, dim3(bs, 4), dim3(256), 0, (hipStream_t)stream, req_to_token,
+                     row_stride, req_pool_indices, idx_is64, lens, lens_is64, kv_indptr, kv_start, start_is64,
+                     kv_indices);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_kv_indptr_cumsum(const void* seq_lens, int lens_is64, int32_t* kv_indptr, int bs, void* stream) {
+  SGLK_CHECK(seq_lens && kv_indptr && bs >= 0, "kv_indptr_cumsum: bad arguments");
+  hipLaunchKernelGGL(cumsum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, seq_lens, lens_is64, kv_indptr, bs);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_get_num_kv_splits(int32_t* num_kv_splits, const void* seq_lens, int lens_is64, int num_seq, int num_group,
+                           int num_head, int num_kv_head, int max_kv_splits, int device_core_count, void* stream) {
+  SGLK_CHECK(num_kv_splits && seq_lens, "get_num_kv_splits: null pointer");
+  SGLK_CHECK(num_seq > 0 && num_group > 0 && num_head > 0 && num_kv_head > 0 && max_kv_splits > 0,
+             "get_num_kv_splits: bad sizes");
+  hipLaunchKernelGGL(num_kv_splits_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, num_kv_splits, seq_lens,
+                     lens_is64, num_seq, num_group, num_head, num_kv_head, max_kv_splits, device_core_count);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_decode_metadata(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,
+                         const void* seq_lens, int lens_is64, int32_t* kv_indptr, int32_t* kv_indices,
+                         int32_t* num_kv_splits, int bs, int num_head, int num_kv_head, int max_kv_splits,
+                         int device_core_count, void* stream) {
+  SGLK_CHECK(bs > 0, "decode_metadata: empty batch");
+  int rc = sglk_kv_indptr_cumsum(seq_lens, lens_is64, kv_indptr, bs, stream);
+  if (rc) return rc;
+  rc = sglk_get_num_kv_splits(num_kv_splits, seq_lens, lens_is64, bs, 1, num_head, num_kv_head, max_kv_splits,
+                              device_core_count, stream);
+  if (rc) return rc;
+  return sglk_create_kv_indices(req_to_token, row_stride, req_pool_indices, idx_is64, seq_lens, lens_is64, kv_indptr,
+                                nullptr, 0, kv_indices, bs, stream);
+}
+
+int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,
+                           const void* seq_lens, int lens_is64, int bs, int32_t* out, void* stream) {
+  SGLK_CHECK(req_to_token && req_pool_indices && seq_lens && out && bs > 0, "common_prefix_len: bad arguments");
+  hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, out, 0x7fffffff);
+  hipLaunchKernelGGL(common_prefix_kernel, dim3(bs), dim3(256), 0, (hipStream_t)stream, req_to_token, row_stride,
+                     req_pool_indices, idx_is64, seq_lens, lens_is64, bs, out);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+                          const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                          int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+                          int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                          int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+                          int dtype, void* stream) {
+  SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && attn_logits && attn_lse && num_kv_splits,
+             "decode_attention: null pointer");
+  SGLK_CHECK(B >= 0 && Hq > 0 && Hkv > 0 && D > 0 && Dv > 0, "decode_attention: bad shape");
+  SGLK_CHECK(Hq % Hkv == 0, "decode_attention: Hq %d not a multiple of Hkv %d", Hq, Hkv);
+  SGLK_CHECK(max_kv_splits > 0, "decode_attention: max_kv_splits must be positive");
+  SGLK_CHECK(Dv <= 1024 && D <= 4096, "decode_attention: head size too large");
+  if (B == 0) return SGLK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int group = Hq / Hkv;
+  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
+                    aligned16(k_buffer) && aligned16(v_buffer) && aligned16(attn_logits) && (q_stride_b % 8 == 0) &&
+                    (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) && (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) &&
+                    (v_stride_h % 8 == 0);
+  if (fast) {
+    const int head_tiles = (group + 15) / 16;
+    dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
+    const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
+                                          k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse,
+                                          num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h,
+                                          k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap));
+  } else {
+    dim3 grid(B, Hq, max_kv_splits);
+    const size_t lds = (size_t)D * sizeof(float);
+    const int per_lane = (Dv + 63) / 64;
+#define SGLK_GEN(N)                                                                                               \
+  hipLaunchKernelGGL((decode_stage1_generic<T, N>), grid, dim3(64), lds, s, q, k_buffer, v_buffer, kv_indptr,     \
+                     kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, D, Dv, q_stride_b, \
+                     q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap)
+    SGLK_DISPATCH_FLOAT(dtype, T, {
+      if (per_lane <= 1) {
+        SGLK_GEN(1);
+      } else if (per_lane <= 2) {
+        SGLK_GEN(2);
+      } else if (per_lane <= 4) {
+        SGLK_GEN(4);
+      } else if (per_lane <= 8) {
+        SGLK_GEN(8);
+      } else {
+        SGLK_GEN(16);
+      }
+    });
+#undef SGLK_GEN
+  }
+  SGLK_LAUNCH_CHECK();
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((decode_stage2<T>), dim3(B, Hq), dim3(128), 0, s, attn_logits, attn_lse, o,
+                                         kv_indptr, num_kv_splits, max_kv_splits, Hq, Dv, o_stride_b, o_stride_h));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+}

@@ -1,0 +1,425 @@
+// Row-wise and elementwise kernels of the decode path: RMSNorm (plain / fused residual add),
+// gated activations, rotary embedding, KV-pool row scatter, LSE merge of two partial attentions.
+// All are HBM-bound byte movers: 16-byte accesses per lane, fp32 arithmetic, one rounding to the
+// activation type where the reference rounds.
+#include "common.h"
+
+namespace sglk {
+
+// ---------------------------------------------------------------------------------------------
+// block reduction (sum) for blocks of up to 1024 threads
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = (lane < nw) ? red[lane] : 0.f;
+  t = wave_sum(t);
+  __syncthreads();
+  return t;
+}
+
+// RMSNorm: out = (x * rsqrt(mean(x^2) + eps)) * w     (layernorm.py:101-103 of the reference)
+// FUSED:   s = x + residual (fp32); residual = round(s); out from the UNROUNDED s (layernorm.py:96-99)
+template <typename T, bool FUSED, bool VEC>
+__global__ void __launch_bounds__(256) rmsnorm_kernel(void* __restrict__ out, const void* __restrict__ xin,
+                                                      void* __restrict__ residual, const void* __restrict__ w,
+                                                      int hidden, int64_t x_stride, int64_t out_stride, float eps,
+                                                      int gemma) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  using R = typename Raw<T>::type;
+  const R* x = reinterpret_cast<const R*>(xin) + row * x_stride;
+  R* o = reinterpret_cast<R*>(out) + row * out_stride;
+  R* res = FUSED ? reinterpret_cast<R*>(residual) + row * x_stride : nullptr;
+  const R* wr = reinterpret_cast<const R*>(w);
+  float ss = 0.f;
+  constexpr int MAXV = 4;  // 256 threads * 8 elems * 4 = 8192 elements kept in registers
+  float keep[MAXV][8];
+  if constexpr (VEC) {
+    // rows of up to 8192 elements live in registers between the two passes (statically indexed);
+    // the launcher routes longer rows to the scalar form.
+    const int nvec = hidden >> 3;
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+      const int v = threadIdx.x + it * 256;
+      if (v < nvec) {
+        short8 xv = reinterpret_cast<const short8*>(x)[v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keep[it][j] = Conv<T>::to_f32((uint16_t)xv[j]);
+        if constexpr (FUSED) {
+          short8 rv = reinterpret_cast<const short8*>(res)[v];
+          short8 ro;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            keep[it][j] += Conv<T>::to_f32((uint16_t)rv[j]);
+            ro[j] = (short)Conv<T>::from_f32(keep[it][j]);
+          }
+          reinterpret_cast<short8*>(res)[v] = ro;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += keep[it][j] * keep[it][j];
+      }
+    }
+    const float tot = block_sum(ss, red);
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+#pragma unroll
+    for (int it = 0; it < MAXV; ++it) {
+      const int v = threadIdx.x + it * 256;
+      if (v < nvec) {
+        short8 wv = reinterpret_cast<const short8*>(wr)[v];
+        short8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float wf = Conv<T>::to_f32((uint16_t)wv[j]);
+          if (gemma) wf += 1.0f;
+          ov[j] = (short)Conv<T>::from_f32((keep[it][j] * inv) * wf);
+        }
+        reinterpret_cast<short8*>(o)[v] = ov;
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < hidden; i += 256) {
+      float f = Conv<T>::to_f32(x[i]);
+      if constexpr (FUSED) f += Conv<T>::to_f32(res[i]);
+      ss += f * f;
+    }
+    const float tot = block_sum(ss, red);
+    const float inv = rsqrtf(tot / (float)hidden + eps);
+    for (int i = threadIdx.x; i < hidden; i += 256) {
+      float f = Conv<T>::to_f32(x[i]);
+      if constexpr (FUSED) {
+        f += Conv<T>::to_f32(res[i]);
+        res[i] = Conv<T>::from_f32(f);
+      }
+      float wf = Conv<T>::to_f32(wr[i]);
+      if (gemma) wf += 1.0f;
+      o[i] = Conv<T>::from_f32((f * inv) * wf);
+    }
+  }
+}
+
+template <typename T>
+static int launch_rmsnorm(void* out, const void* x, void* residual, const void* w, int64_t rows, int hidden,
+                          int64_t x_stride, int64_t out_stride, float eps, int gemma, hipStream_t s) {
+  if (rows == 0) return SGLK_OK;
+  const bool fused = residual != nullptr;
+  const bool vec = sizeof(typename Raw<T>::type) == 2 && (hidden % 8 == 0) && hidden <= 8192 && aligned16(x) &&
+                   aligned16(out) &&
+                   aligned16(w) && (x_stride % 8 == 0) && (out_stride % 8 == 0) && (!fused || aligned16(residual));
+  dim3 grid((unsigned)rows), block(256);
+  if (vec) {
+    if (fused)
+      hipLaunchKernelGGL((rmsnorm_kernel<T, true, true>), grid, block, 0, s, out, x, residual, w, hidden, x_stride,
+                         out_stride, eps, gemma);
+    else
+      hipLaunchKernelGGL((rmsnorm_kernel<T, false, true>), grid, block, 0, s, out, x, residual, w, hidden, x_stride,
+                         out_stride, eps, gemma);
+  } else {
+    if (fused)
+      hipLaunchKernelGGL((rmsnorm_kernel<T, true, false>), grid, block, 0, s, out, x, residual, w, hidden, x_stride,
+                         out_stride, eps, gemma);
+    else
+      hipLaunchKernelGGL((rmsnorm_kernel<T, false, false>), grid, block, 0, s, out, x, residual, w, hidden, x_stride,
+                         out_stride, eps, gemma);
+  }
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// act_and_mul: out = act(x[:, :d]) * x[:, d:]; act rounded to T before the product
+// (activation.cu:22-50 of the reference: silu returns T, then T*T)
+// ---------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float act_fn(float v) {
+  if constexpr (ACT == 0) return v / (1.0f + __expf(-v));
+  if constexpr (ACT == 1) {
+    const float k = 0.7978845608028654f;  // sqrt(2/pi)
+    return 0.5f * v * (1.0f + tanhf(k * (v + 0.044715f * v * v * v)));
+  }
+  return 0.5f * v * (1.0f + erff(v * 0.7071067811865476f));
+}
+
+template <typename T, int ACT, bool VEC>
+__global__ void __launch_bounds__(256) act_and_mul_kernel(void* __restrict__ out, const void* __restrict__ xin,
+                                                          int64_t rows, int d) {
+  using R = typename Raw<T>::type;
+  const R* x = reinterpret_cast<const R*>(xin);
+  R* o = reinterpret_cast<R*>(out);
+  if constexpr (VEC) {
+    const int nv = d >> 3;
+    const int64_t total = rows * nv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / nv;
+      const int c = (int)(i - r * nv);
+      short8 a = reinterpret_cast<const short8*>(x + r * 2 * d)[c];
+      short8 g = reinterpret_cast<const short8*>(x + r * 2 * d + d)[c];
+      short8 ov;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float s = Conv<T>::to_f32(Conv<T>::from_f32(act_fn<ACT>(Conv<T>::to_f32((uint16_t)a[j]))));
+        ov[j] = (short)Conv<T>::from_f32(s * Conv<T>::to_f32((uint16_t)g[j]));
+      }
+      reinterpret_cast<short8*>(o + r * d)[c] = ov;
+    }
+  } else {
+    const int64_t total = rows * d;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / d;
+      const int c = (int)(i - r * d);
+      const float s = Conv<T>::to_f32(Conv<T>::from_f32(act_fn<ACT>(Conv<T>::to_f32(x[r * 2 * d + c]))));
+      o[r * d + c] = Conv<T>::from_f32(s * Conv<T>::to_f32(x[r * 2 * d + d + c]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rotary embedding (rope.cu:22-89 of the reference): cos_sin_cache[pos] = [cos(rot/2) | sin(rot/2)]
+// one block per token; threads sweep (head, pair)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void rope_rows(typename Raw<T>::type* base, int heads, int head_size, int half,
+                                          const float* cs, int interleave) {
+  const int per = heads * half;
+  for (int i = threadIdx.x; i < per; i += blockDim.x) {
+    const int h = i / half, p = i - h * half;
+    const int a = interleave ? 2 * p : p, b = interleave ? 2 * p + 1 : p + half;
+    typename Raw<T>::type* v = base + (int64_t)h * head_size;
+    const float c = cs[p], s = cs[half + p];
+    const float xa = Conv<T>::to_f32(v[a]), xb = Conv<T>::to_f32(v[b]);
+    v[a] = Conv<T>::from_f32(xa * c - xb * s);
+    v[b] = Conv<T>::from_f32(xb * c + xa * s);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) rope_kernel(void* q, void* k, const float* __restrict__ cos_sin,
+                                                   const int64_t* __restrict__ positions, int q_heads, int k_heads,
+                                                   int head_size, int rot, int64_t q_stride_t, int64_t k_stride_t,
+                                                   int interleave) {
+  using R = typename Raw<T>::type;
+  const int64_t t = blockIdx.x;
+  const float* cs = cos_sin + positions[t] * rot;
+  rope_rows<T>(reinterpret_cast<R*>(q) + t * q_stride_t, q_heads, head_size, rot / 2, cs, interleave);
+  if (k) rope_rows<T>(reinterpret_cast<R*>(k) + t * k_stride_t, k_heads, head_size, rot / 2, cs, interleave);
+}
+
+// rope on the q and k slices of a fused qkv row, then scatter rotated k and v into pool rows loc[t]
+template <typename T>
+__global__ void __launch_bounds__(256) rope_store_kernel(void* qkv, const float* __restrict__ cos_sin,
+                                                         const int64_t* __restrict__ positions, void* k_buffer,
+                                                         void* v_buffer, const void* loc, int loc_is64, int q_heads,
+                                                         int kv_heads, int head_size, int rot, int64_t kbuf_stride_n,
+                                                         int64_t vbuf_stride_n, int interleave) {
+  using R = typename Raw<T>::type;
+  const int64_t t = blockIdx.x;
+  const int64_t row = (int64_t)(q_heads + 2 * kv_heads) * head_size;
+  R* base = reinterpret_cast<R*>(qkv) + t * row;
+  const float* cs = cos_sin + positions[t] * rot;
+  const int half = rot / 2;
+  const int64_t slot = ld_idx(loc, loc_is64, t);
+  R* kdst = reinterpret_cast<R*>(k_buffer) + slot * kbuf_stride_n;
+  R* vdst = reinterpret_cast<R*>(v_buffer) + slot * vbuf_stride_n;
+  // q heads and k heads are contiguous: rotate (q_heads + kv_heads) heads; k pairs also go to the pool
+  const int nrot = (q_heads + kv_heads) * half;
+  for (int i = threadIdx.x; i < nrot; i += 256) {
+    const int h = i / half, p = i - h * half;
+    const int a = interleave ? 2 * p : p, b = interleave ? 2 * p + 1 : p + half;
+    R* v = base + (int64_t)h * head_size;
+    const float c = cs[p], s = cs[half + p];
+    const float xa = Conv<T>::to_f32(v[a]), xb = Conv<T>::to_f32(v[b]);
+    const R ra = Conv<T>::from_f32(xa * c - xb * s), rb = Conv<T>::from_f32(xb * c + xa * s);
+    v[a] = ra;
+    v[b] = rb;
+    if (h >= q_heads) {
+      R* kd = kdst + (int64_t)(h - q_heads) * head_size;
+      kd[a] = ra;
+      kd[b] = rb;
+    }
+  }
+  // pass-through dims of k (rot < head_size) and all of v
+  if (rot < head_size) {
+    const int pass = head_size - rot;
+    for (int i = threadIdx.x; i < kv_heads * pass; i += 256) {
+      const int h = i / pass, p = rot + (i - h * pass);
+      kdst[(int64_t)h * head_size + p] = base[(int64_t)(q_heads + h) * head_size + p];
+    }
+  }
+  const R* vsrc = base + (int64_t)(q_heads + kv_heads) * head_size;
+  const int nv = kv_heads * head_size;
+  if ((nv % 8 == 0) && aligned16(vsrc) && aligned16(vdst)) {
+    for (int i = threadIdx.x; i < (nv >> 3); i += 256)
+      reinterpret_cast<short8*>(vdst)[i] = reinterpret_cast<const short8*>(vsrc)[i];
+  } else {
+    for (int i = threadIdx.x; i < nv; i += 256) vdst[i] = vsrc[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// KV pool row scatter (memory_pool.py:378-412): one block per token, 16-byte copies
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) set_kv_kernel(char* k_buffer, char* v_buffer, const char* k, const char* v,
+                                                     const void* loc, int loc_is64, int64_t row_k_bytes,
+                                                     int64_t row_v_bytes, int64_t kbuf_stride, int64_t vbuf_stride,
+                                                     int64_t k_stride, int64_t v_stride, int vec) {
+  const int64_t t = blockIdx.x;
+  const int64_t slot = ld_idx(loc, loc_is64, t);
+  char* kd = k_buffer + slot * kbuf_stride;
+  char* vd = v_buffer + slot * vbuf_stride;
+  const char* ks = k + t * k_stride;
+  const char* vs = v + t * v_stride;
+  if (vec) {
+    for (int64_t i = threadIdx.x; i < (row_k_bytes >> 4); i += 256)
+      reinterpret_cast<int4v*>(kd)[i] = reinterpret_cast<const int4v*>(ks)[i];
+    for (int64_t i = threadIdx.x; i < (row_v_bytes >> 4); i += 256)
+      reinterpret_cast<int4v*>(vd)[i] = reinterpret_cast<const int4v*>(vs)[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < row_k_bytes; i += 256) kd[i] = ks[i];
+    for (int64_t i = threadIdx.x; i < row_v_bytes; i += 256) vd[i] = vs[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// merge_state (merge_attn_states.cu:31-106 of the reference)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) merge_state_kernel(const void* __restrict__ v_a, const float* __restrict__ s_a,
+                                                          const void* __restrict__ v_b, const float* __restrict__ s_b,
+                                                          void* __restrict__ v_out, float* __restrict__ s_out,
+                                                          int64_t nh, int d) {
+  const int64_t total = nh * d;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / d;
+    float pa = s_a[r], pb = s_b[r];
+    pa = isinf(pa) ? -INFINITY : pa;
+    pb = isinf(pb) ? -INFINITY : pb;
+    const float mx = fmaxf(pa, pb);
+    const float ea = expf(pa - mx), eb = expf(pb - mx);
+    const float sum = ea + eb;
+    const float wa = ea / sum, wb = eb / sum;
+    st<T>(v_out, i, ld<T>(v_a, i) * wa + ld<T>(v_b, i) * wb);
+    if (s_out != nullptr && i == r * d) s_out[r] = logf(sum) + mx;
+  }
+}
+
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" {
+
+int sglk_rmsnorm(void* out, const void* x, const void* weight, int64_t rows, int hidden, int64_t x_stride,
+                 int64_t out_stride, float eps, int gemma, int dtype, void* stream) {
+  SGLK_CHECK(out && x && weight, "rmsnorm: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0, "rmsnorm: bad shape rows=%lld hidden=%d", (long long)rows, hidden);
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      return launch_rmsnorm<T>(out, x, nullptr, weight, rows, hidden, x_stride, out_stride, eps, gemma,
+                                               (hipStream_t)stream));
+  return SGLK_OK;
+}
+
+int sglk_fused_add_rmsnorm(void* x, void* residual, const void* weight, int64_t rows, int hidden, float eps, int gemma,
+                           int dtype, void* stream) {
+  SGLK_CHECK(x && residual && weight, "fused_add_rmsnorm: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0, "fused_add_rmsnorm: bad shape");
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      return launch_rmsnorm<T>(x, x, residual, weight, rows, hidden, hidden, hidden, eps, gemma,
+                                               (hipStream_t)stream));
+  return SGLK_OK;
+}
+
+int sglk_act_and_mul(void* out, const void* x, int64_t rows, int d, int act, int dtype, void* stream) {
+  SGLK_CHECK(out && x, "act_and_mul: null pointer");
+  SGLK_CHECK(rows >= 0 && d > 0, "act_and_mul: bad shape");
+  SGLK_CHECK(act >= 0 && act <= 2, "act_and_mul: unknown activation %d", act);
+  // the reference requires 16-byte aligned rows (python/sgl_kernel/elementwise.py:172-173)
+  SGLK_CHECK(((int64_t)d * elem_size(dtype)) % 16 == 0, "The pointers must be multiple of 16 bytes.");
+  if (rows == 0) return SGLK_OK;
+  const bool vec = dtype != SGLK_F32 && aligned16(out) && aligned16(x);
+  const int64_t work = vec ? rows * (d >> 3) : rows * d;
+  int blocks = (int)((work + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+#define SGLK_ACT_LAUNCH(ACT)                                                                                      \
+  if (vec)                                                                                                        \
+    hipLaunchKernelGGL((act_and_mul_kernel<T, ACT, true>), dim3(blocks), dim3(256), 0, s, out, x, rows, d);       \
+  else                                                                                                            \
+    hipLaunchKernelGGL((act_and_mul_kernel<T, ACT, false>), dim3(blocks), dim3(256), 0, s, out, x, rows, d);
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    if (act == 0) {
+      SGLK_ACT_LAUNCH(0)
+    } else if (act == 1) {
+      SGLK_ACT_LAUNCH(1)
+    } else {
+      SGLK_ACT_LAUNCH(2)
+    }
+  });
+#undef SGLK_ACT_LAUNCH
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_rope(void* q, void* k, const float* cos_sin_cache, const int64_t* positions, int64_t tokens, int q_heads,
+              int k_heads, int head_size, int rot_dim, int64_t q_stride_t, int64_t k_stride_t, int interleave,
+              int dtype, void* stream) {
+  SGLK_CHECK(q && cos_sin_cache && positions, "rope: null pointer");
+  SGLK_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope: bad rotary dim %d (head_size %d)",
+             rot_dim, head_size);
+  if (tokens == 0) return SGLK_OK;
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((rope_kernel<T>), dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, q,
+                                         k, cos_sin_cache, positions, q_heads, k_heads, head_size, rot_dim, q_stride_t,
+                                         k_stride_t, interleave));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_rope_and_store_kv(void* qkv, const float* cos_sin_cache, const int64_t* positions, void* k_buffer,
+                           void* v_buffer, const void* loc, int loc_is64, int64_t tokens, int q_heads, int kv_heads,
+                           int head_size, int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n, int interleave,
+                           int dtype, void* stream) {
+  SGLK_CHECK(qkv && cos_sin_cache && positions && k_buffer && v_buffer && loc, "rope_and_store_kv: null pointer");
+  SGLK_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope_and_store_kv: bad rotary dim");
+  if (tokens == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((rope_store_kernel<T>), dim3((unsigned)tokens), dim3(256), 0,
+                                        (hipStream_t)stream, qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc,
+                                        loc_is64, q_heads, kv_heads, head_size, rot_dim, kbuf_stride_n, vbuf_stride_n,
+                                        interleave));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const void* v, const void* loc, int loc_is64,
+                       int64_t tokens, int row_k, int row_v, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                       int64_t k_stride_t, int64_t v_stride_t, int elem_bytes, void* stream) {
+  SGLK_CHECK(k_buffer && v_buffer && k && v && loc, "set_kv_buffer: null pointer");
+  SGLK_CHECK(elem_bytes == 1 || elem_bytes == 2 || elem_bytes == 4, "set_kv_buffer: bad element size");
+  if (tokens == 0) return SGLK_OK;
+  const int64_t rk = (int64_t)row_k * elem_bytes, rv = (int64_t)row_v * elem_bytes;
+  const int64_t kb = kbuf_stride_n * elem_bytes, vb = vbuf_stride_n * elem_bytes, ks = k_stride_t * elem_bytes,
+                vs = v_stride_t * elem_bytes;
+  const int vec = (rk % 16 == 0) && (rv % 16 == 0) && (kb % 16 == 0) && (vb % 16 == 0) && (ks % 16 == 0) &&
+                  (vs % 16 == 0) && aligned16(k_buffer) && aligned16(v_buffer) && aligned16(k) && aligned16(v);
+  hipLaunchKernelGGL(set_kv_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (char*)k_buffer,
+                     (char*)v_buffer, (const char*)k, (const char*)v, loc, loc_is64, rk, rv, kb, vb, ks, vs, vec);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b, void* v_out, float* s_out,
+                     int64_t n, int h, int d, int dtype, void* stream) {
+  SGLK_CHECK(v_a && s_a && v_b && s_b && v_out, "merge_state: null pointer");
+  const int64_t nh = n * h;
+  if (nh == 0) return SGLK_OK;
+  int blocks = (int)((nh * d + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((merge_state_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, v_a,
+                                         s_a, v_b, s_b, v_out, s_out, nh, d));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+}

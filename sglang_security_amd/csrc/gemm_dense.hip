@@ -1,0 +1,164 @@
+// Skinny dense GEMM  out[M,N] = x[M,K] @ W[N,K]^T (+bias)  for 16-bit types: the unquantised lm_head
+// and the bf16 configuration at decode batch sizes.  HBM-bound on W: every wave streams a strip of 16
+// weight rows straight into MFMA operand registers (64 contiguous bytes per lane per 128-k block, no
+// LDS round trip for the operand that is read once), while the activations, which every wave
+// re-reads, are staged through an XOR-swizzled LDS tile shared by the block.
+#include "common.h"
+
+namespace sglk {
+
+template <typename T>
+struct DenseMma;
+template <>
+struct DenseMma<bf16_t> {
+  static __device__ __forceinline__ float4v mma(int4v a, int4v b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfloat8, a), __builtin_bit_cast(bfloat8, b), c, 0,
+                                                   0, 0);
+  }
+};
+template <>
+struct DenseMma<f16_t> {
+  static __device__ __forceinline__ float4v mma(int4v a, int4v b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0,
+                                                  0);
+  }
+};
+
+static constexpr int kDenseXTile = 64 * 256;
+__device__ __forceinline__ int dx_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
+
+template <typename T>
+__global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ w,
+                                                               const uint16_t* __restrict__ bias,
+                                                               uint16_t* __restrict__ out, float* __restrict__ partial,
+                                                               int M, int Mpad, int N, int K, int kb_per_split,
+                                                               int64_t x_stride, int64_t w_stride, int64_t out_stride) {
+  __shared__ __attribute__((aligned(16))) char xs[2 * kDenseXTile];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int kblocks = K / 128;
+  const int m0 = blockIdx.z * 64;
+  const int kb0 = blockIdx.y * kb_per_split;
+  const int nkb = min(kb_per_split, kblocks - kb0);
+  const int n = (blockIdx.x * 4 + wid) * 16 + i16;  // weight row (output column) of this lane
+  const bool n_ok = n < N;
+
+  const int xr = threadIdx.x >> 2, xq = threadIdx.x & 3;
+  const bool xrow_ok = (m0 + xr) < M;
+  const uint16_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
+  int4v xreg[4];
+  auto x_fetch = [&](int kb) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      xreg[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * kb + 8 * c) : int4v{0, 0, 0, 0};
+  };
+  auto x_park = [&](int buf) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<int4v*>(xs + buf * kDenseXTile + dx_off(xr, 4 * xq + c)) = xreg[c];
+  };
+
+  // lane (i16, g) owns bytes [64g, 64g+64) of its weight row in every 128-k block
+  const uint16_t* wsrc = w + (int64_t)(n_ok ? n : 0) * w_stride + 128 * (int64_t)kb0 + 32 * g;
+  constexpr int PF = 4;
+  int4v wq[PF][4];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < nkb) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wq[p][c] = *reinterpret_cast<const int4v*>(wsrc + 128 * p + 8 * c);
+    }
+
+  float4v oacc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) oacc[mt] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  x_fetch(kb0);
+  x_park(0);
+  __syncthreads();
+
+  for (int base = 0; base < nkb; base += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int j = base + p;
+      if (j < nkb) {
+        const int buf = j & 1;
+        if (j + 1 < nkb) x_fetch(kb0 + j + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          // k-slots of step ks: k = 128*kb + 32*g + 8*ks + e  <->  activation chunk 4*g + ks
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int4v af = *reinterpret_cast<const int4v*>(xs + buf * kDenseXTile + dx_off(16 * mt + i16, 4 * g + ks));
+            oacc[mt] = DenseMma<T>::mma(af, wq[p][ks], oacc[mt]);
+          }
+        }
+        if (j + PF < nkb) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) wq[p][c] = *reinterpret_cast<const int4v*>(wsrc + 128 * (int64_t)(j + PF) + 8 * c);
+        }
+        if (j + 1 < nkb) x_park(buf ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  const bool direct = partial == nullptr;
+  const float bv = (direct && bias && n_ok) ? Conv<T>::to_f32(bias[n]) : 0.f;
+  if (n_ok) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * mt + 4 * g + r;
+        if (direct) {
+          if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(oacc[mt][r] + bv);
+        } else {
+          partial[((int64_t)blockIdx.y * Mpad + m) * N + n] = oacc[mt][r];
+        }
+      }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) dense_reduce_kernel(const float* __restrict__ partial,
+                                                           const uint16_t* __restrict__ bias,
+                                                           uint16_t* __restrict__ out, int M, int Mpad, int N,
+                                                           int splits, int64_t out_stride) {
+  const int64_t total = (int64_t)M * N;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int m = (int)(i / N), c = (int)(i - (int64_t)m * N);
+    float a = 0.f;
+    for (int s = 0; s < splits; ++s) a += partial[((int64_t)s * Mpad + m) * N + c];
+    if (bias) a += Conv<T>::to_f32(bias[c]);
+    out[(int64_t)m * out_stride + c] = Conv<T>::from_f32(a);
+  }
+}
+
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" {
+
+// Dense split-K needs scratch; this entry point keeps the weights' whole K in one block when N gives
+// enough blocks (lm_head: 2004 blocks) and otherwise runs unsplit as well: the strips are 16 rows of W,
+// so even N = 4096 yields 64 blocks x 4 waves.  (The AWQ path owns the split-K machinery.)
+int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
+                       int64_t x_stride, int64_t w_stride, int64_t out_stride, int dtype, void* stream) {
+  SGLK_CHECK(x && w && out, "dense_gemm_nt: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0, "dense_gemm_nt: bad shape");
+  SGLK_CHECK(K % 128 == 0, "dense_gemm_nt: K=%d must be a multiple of 128", K);
+  SGLK_CHECK(aligned16(x) && aligned16(w) && x_stride % 8 == 0 && w_stride % 8 == 0,
+             "dense_gemm_nt: rows must be 16-byte aligned");
+  const int mblocks = (M + 63) / 64;
+  dim3 grid((N + 63) / 64, 1, mblocks);
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((dense_gemm_nt_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
+                                        (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out,
+                                        (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride, w_stride,
+                                        out_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+}

@@ -1,0 +1,310 @@
+"""Tensor-level entry points over the C ABI: argument checks, pointer extraction, launch on torch's
+current stream.  torch is plumbing here (device memory + streams); all arithmetic is in libsglk.so.
+
+Function names and argument order follow the reference callers they replace (cited per function).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import SglkError, check, dtype_code, lib
+
+
+def _ptr(t: Optional[torch.Tensor]) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise SglkError("sglk ops run on the GPU only; got a CPU tensor (there is no CPU fallback)")
+
+
+def _is64(t: torch.Tensor) -> int:
+    if t.dtype == torch.int64:
+        return 1
+    if t.dtype == torch.int32:
+        return 0
+    raise SglkError(f"index tensor must be int32 or int64, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------- A0
+def create_kv_indices(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_start_idx, kv_indices):
+    """create_flashinfer_kv_indices_triton[(bs,)](...) -- layers/attention/utils.py:5-41."""
+    _need_gpu(req_to_token, req_pool_indices, page_kernel_lens, kv_indptr, kv_indices)
+    if req_to_token.dtype != torch.int32 or kv_indices.dtype != torch.int32 or kv_indptr.dtype != torch.int32:
+        raise SglkError("req_to_token, kv_indptr and kv_indices must be int32")
+    bs = req_pool_indices.shape[0]
+    check(lib().sglk_create_kv_indices(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices),
+        _ptr(page_kernel_lens), _is64(page_kernel_lens), _ptr(kv_indptr), _ptr(kv_start_idx),
+        0 if kv_start_idx is None else _is64(kv_start_idx), _ptr(kv_indices), bs, _stream(req_to_token)),
+        "create_kv_indices")
+
+
+def kv_indptr_cumsum(seq_lens, kv_indptr):
+    _need_gpu(seq_lens, kv_indptr)
+    check(lib().sglk_kv_indptr_cumsum(_ptr(seq_lens), _is64(seq_lens), _ptr(kv_indptr), seq_lens.shape[0],
+                                      _stream(seq_lens)), "kv_indptr_cumsum")
+
+
+def get_num_kv_splits(num_kv_splits, seq_lens, num_head, num_kv_head, max_kv_splits, device_core_count):
+    """TritonAttnBackend.get_num_kv_splits -- triton_backend.py:235-269."""
+    _need_gpu(num_kv_splits, seq_lens)
+    num_token, num_seq = num_kv_splits.shape[0], seq_lens.shape[0]
+    num_group = num_token // num_seq
+    assert num_group * num_seq == num_token, f"num_seq({num_seq}), num_token({num_token}), something goes wrong!"
+    check(lib().sglk_get_num_kv_splits(_ptr(num_kv_splits), _ptr(seq_lens), _is64(seq_lens), num_seq, num_group,
+                                       num_head, num_kv_head, max_kv_splits, device_core_count,
+                                       _stream(seq_lens)), "get_num_kv_splits")
+
+
+def decode_metadata(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits, num_head,
+                    num_kv_head, max_kv_splits, device_core_count):
+    _need_gpu(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits)
+    check(lib().sglk_decode_metadata(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices),
+        _ptr(seq_lens), _is64(seq_lens), _ptr(kv_indptr), _ptr(kv_indices), _ptr(num_kv_splits),
+        seq_lens.shape[0], num_head, num_kv_head, max_kv_splits, device_core_count, _stream(seq_lens)),
+        "decode_metadata")
+
+
+def common_prefix_len(req_to_token, req_pool_indices, seq_lens, out):
+    _need_gpu(req_to_token, req_pool_indices, seq_lens, out)
+    check(lib().sglk_common_prefix_len(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices),
+                                       _is64(req_pool_indices), _ptr(seq_lens), _is64(seq_lens),
+                                       seq_lens.shape[0], _ptr(out), _stream(seq_lens)), "common_prefix_len")
+
+
+# ------------------------------------------------------------------------------------------- A1
+def _last_dim_contig(t, name):
+    if t.stride(-1) != 1:
+        raise SglkError(f"{name}: last dimension must be contiguous")
+
+
+def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                         max_kv_splits, sm_scale, logit_cap=0.0):
+    """Same signature as triton_ops/decode_attention.py:682-733."""
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits)
+    assert max_kv_splits == attn_logits.shape[2]
+    assert q.shape[0] <= kv_indptr.shape[0] - 1
+    assert q.shape[0] <= attn_logits.shape[0]
+    for t, n in ((q, "q"), (k_buffer, "k_buffer"), (v_buffer, "v_buffer"), (o, "o")):
+        _last_dim_contig(t, n)
+    if not (q.dtype == k_buffer.dtype == v_buffer.dtype == o.dtype):
+        raise SglkError("decode_attention: q, k_buffer, v_buffer, o must share a dtype")
+    if attn_logits.dtype != torch.float32 or attn_lse.dtype != torch.float32 or not attn_logits.is_contiguous():
+        raise SglkError("decode_attention: attn_logits / attn_lse must be contiguous fp32")
+    if kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32 or num_kv_splits.dtype != torch.int32:
+        raise SglkError("decode_attention: kv_indptr, kv_indices, num_kv_splits must be int32")
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    if attn_logits.shape[1] != Hq or attn_logits.shape[3] != Dv:
+        raise SglkError("decode_attention: attn_logits must be [B, Hq, max_kv_splits, Dv]")
+    check(lib().sglk_decode_attention(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(attn_logits),
+        _ptr(attn_lse), _ptr(num_kv_splits), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
+        k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
+        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _stream(q)), "decode_attention")
+
+
+def decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits) -> int:
+    return int(lib().sglk_decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits))
+
+
+def decode_attention_shared_prefix(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens,
+                                   workspace, max_kv_splits, sm_scale, logit_cap=0.0):
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, workspace)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    G = group_indptr.shape[0] - 1
+    need = decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits)
+    if workspace.numel() * workspace.element_size() < need:
+        raise SglkError(f"decode_attention_shared_prefix: workspace too small ({need} bytes needed)")
+    check(lib().sglk_decode_attention_shared_prefix(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr),
+        _ptr(prefix_lens), G, _ptr(workspace), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
+        k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
+        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _stream(q)), "decode_attention_shared_prefix")
+
+
+# ------------------------------------------------------------------------------------------- A2
+def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
+                         kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale=None,
+                         logit_cap=0.0, skip_prefix_custom_mask=True, sliding_window_size=-1):
+    """Same signature as triton_ops/extend_attention.py:306-438; custom masks / sliding window unsupported."""
+    if custom_mask is not None:
+        raise SglkError("extend_attention: custom_mask is not supported")
+    if sliding_window_size is not None and sliding_window_size > 0:
+        raise SglkError("extend_attention: sliding window is not supported")
+    _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
+    T, Hq, D = q_extend.shape
+    Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
+    if sm_scale is None:
+        sm_scale = 1.0 / (D ** 0.5)
+    B = qo_indptr.shape[0] - 1
+    check(lib().sglk_extend_attention(
+        _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), B, Hq, Hkv, D, Dv,
+        q_extend.stride(0), q_extend.stride(1), k_extend.stride(0), k_extend.stride(1),
+        v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
+        k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
+        int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0,
+        dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention")
+
+
+# ------------------------------------------------------------------------------------------- A3
+def merge_state(v_a, s_a, v_b, s_b, v_merged, s_merged):
+    _need_gpu(v_a, s_a, v_b, s_b, v_merged)
+    n, h, d = v_a.shape
+    for t in (v_a, v_b, v_merged, s_a, s_b):
+        if not t.is_contiguous():
+            raise SglkError("merge_state: tensors must be contiguous")
+    check(lib().sglk_merge_state(_ptr(v_a), _ptr(s_a), _ptr(v_b), _ptr(s_b), _ptr(v_merged), _ptr(s_merged), n, h, d,
+                                 dtype_code(v_a.dtype), _stream(v_a)), "merge_state")
+
+
+# ------------------------------------------------------------------------------------------- P1
+def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v):
+    """k_buffer[loc] = cache_k; v_buffer[loc] = cache_v -- memory_pool.py:378-412."""
+    _need_gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    if cache_k.dtype != k_buffer.dtype:
+        cache_k = cache_k.to(k_buffer.dtype)
+        cache_v = cache_v.to(v_buffer.dtype)
+    T = loc.shape[0]
+    ck = cache_k.reshape(T, -1)
+    cv = cache_v.reshape(T, -1)
+    if ck.stride(1) != 1 or cv.stride(1) != 1:
+        raise SglkError("set_kv_buffer: cache_k/cache_v rows must be contiguous")
+    kb = k_buffer.view(k_buffer.shape[0], -1)
+    vb = v_buffer.view(v_buffer.shape[0], -1)
+    check(lib().sglk_set_kv_buffer(_ptr(kb), _ptr(vb), _ptr(ck), _ptr(cv), _ptr(loc), _is64(loc), T, ck.shape[1],
+                                   cv.shape[1], kb.stride(0), vb.stride(0), ck.stride(0), cv.stride(0),
+                                   k_buffer.element_size(), _stream(k_buffer)), "set_kv_buffer")
+
+
+# ------------------------------------------------------------------------------------------- E1
+def rmsnorm(out, x, weight, eps, gemma=False):
+    _need_gpu(out, x, weight)
+    x2 = x.view(-1, x.shape[-1])
+    o2 = out.view(-1, out.shape[-1])
+    if x2.stride(1) != 1 or o2.stride(1) != 1 or not weight.is_contiguous():
+        raise SglkError("rmsnorm: rows must be contiguous")
+    check(lib().sglk_rmsnorm(_ptr(o2), _ptr(x2), _ptr(weight), x2.shape[0], x2.shape[1], x2.stride(0), o2.stride(0),
+                             float(eps), 1 if gemma else 0, dtype_code(x.dtype), _stream(x)), "rmsnorm")
+
+
+def fused_add_rmsnorm(x, residual, weight, eps, gemma=False):
+    _need_gpu(x, residual, weight)
+    if not (x.is_contiguous() and residual.is_contiguous() and weight.is_contiguous()):
+        raise SglkError("fused_add_rmsnorm: tensors must be contiguous")
+    hidden = x.shape[-1]
+    check(lib().sglk_fused_add_rmsnorm(_ptr(x), _ptr(residual), _ptr(weight), x.numel() // hidden, hidden,
+                                       float(eps), 1 if gemma else 0, dtype_code(x.dtype), _stream(x)),
+          "fused_add_rmsnorm")
+
+
+def act_and_mul(out, x, act: int):
+    _need_gpu(out, x)
+    if not (x.is_contiguous() and out.is_contiguous()):
+        raise SglkError("act_and_mul: tensors must be contiguous")
+    d = x.shape[-1] // 2
+    check(lib().sglk_act_and_mul(_ptr(out), _ptr(x), x.numel() // (2 * d), d, act, dtype_code(x.dtype), _stream(x)),
+          "act_and_mul")
+
+
+def rope(q, k, cos_sin_cache, positions, head_size, interleave):
+    """q:[T,Hq*hs] (or [T,Hq,hs]) and k rotated in place."""
+    _need_gpu(q, cos_sin_cache, positions)
+    if positions.dtype != torch.int64:
+        positions = positions.long()
+    T = q.shape[0]
+    q2 = q.view(T, -1)
+    k2 = None if k is None else k.view(T, -1)
+    check(lib().sglk_rope(_ptr(q2), _ptr(k2), _ptr(cos_sin_cache), _ptr(positions), T, q2.shape[1] // head_size,
+                          0 if k2 is None else k2.shape[1] // head_size, head_size, cos_sin_cache.shape[1],
+                          q2.stride(0), 0 if k2 is None else k2.stride(0), 1 if interleave else 0,
+                          dtype_code(q.dtype), _stream(q)), "rope")
+
+
+def rope_and_store_kv(qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc, q_heads, kv_heads, head_size,
+                      interleave=False):
+    _need_gpu(qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc)
+    if not qkv.is_contiguous() or positions.dtype != torch.int64:
+        raise SglkError("rope_and_store_kv: qkv must be contiguous and positions int64")
+    kb = k_buffer.view(k_buffer.shape[0], -1)
+    vb = v_buffer.view(v_buffer.shape[0], -1)
+    check(lib().sglk_rope_and_store_kv(_ptr(qkv), _ptr(cos_sin_cache), _ptr(positions), _ptr(kb), _ptr(vb), _ptr(loc),
+                                       _is64(loc), qkv.shape[0], q_heads, kv_heads, head_size,
+                                       cos_sin_cache.shape[1], kb.stride(0), vb.stride(0), 1 if interleave else 0,
+                                       dtype_code(qkv.dtype), _stream(qkv)), "rope_and_store_kv")
+
+
+# ------------------------------------------------------------------------------------------- G1
+def awq_dequantize(qweight, scales, qzeros):
+    """-> [K, N] in scales.dtype; sgl-kernel/csrc/gemm/awq_kernel.cu:184-219."""
+    _need_gpu(qweight, scales, qzeros)
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32:
+        raise SglkError("awq_dequantize: qweight/qzeros must be int32")
+    if not (qweight.is_contiguous() and scales.is_contiguous() and qzeros.is_contiguous()):
+        raise SglkError("awq_dequantize: tensors must be contiguous")
+    rows, qcols = qweight.shape
+    group = rows // scales.shape[0]
+    out = torch.empty((rows, qcols * 8), dtype=scales.dtype, device=scales.device)
+    check(lib().sglk_awq_dequantize(_ptr(qweight), _ptr(scales), _ptr(qzeros), _ptr(out), rows, qcols, group,
+                                    dtype_code(scales.dtype), _stream(qweight)), "awq_dequantize")
+    return out
+
+
+def awq_repack(qweight):
+    _need_gpu(qweight)
+    if qweight.dtype != torch.int32 or not qweight.is_contiguous():
+        raise SglkError("awq_repack: qweight must be contiguous int32")
+    packed = torch.empty_like(qweight)
+    check(lib().sglk_awq_repack(_ptr(qweight), _ptr(packed), qweight.shape[0], qweight.shape[1], _stream(qweight)),
+          "awq_repack")
+    return packed
+
+
+def awq_gemm_workspace_bytes(M, N, K) -> int:
+    return int(lib().sglk_awq_gemm_workspace_bytes(M, N, K))
+
+
+def awq_gemm(x, packed, scales, qzeros, bias=None, out=None, workspace=None):
+    """x:[M,K] @ W -> [M,N]; packed from awq_repack(qweight)."""
+    _need_gpu(x, packed, scales, qzeros)
+    M, K = x.shape
+    N = scales.shape[1]
+    group = K // scales.shape[0]
+    if x.dtype != scales.dtype:
+        raise SglkError("awq_gemm: activation and scale dtypes differ")
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    need = awq_gemm_workspace_bytes(M, N, K)
+    if workspace is None:
+        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise SglkError(f"awq_gemm: workspace too small ({need} bytes needed)")
+    check(lib().sglk_awq_gemm(_ptr(x), _ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(out),
+                              _ptr(workspace), M, N, K, group, x.stride(0), out.stride(0), dtype_code(x.dtype),
+                              _stream(x)), "awq_gemm")
+    return out
+
+
+def dense_gemm_nt(x, w, bias=None, out=None):
+    """x:[M,K] @ w:[N,K]^T."""
+    _need_gpu(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib().sglk_dense_gemm_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x.stride(0), w.stride(0),
+                                   out.stride(0), dtype_code(x.dtype), _stream(x)), "dense_gemm_nt")
+    return out

@@ -1,0 +1,234 @@
+"""GPU parity: metadata kernels (bit-exact) and paged decode attention (fp tolerance) through the C ABI,
+against the committed golden vectors (reference Triton / CPU kernels) and the C oracle on seeded inputs.
+
+Tolerances are the reference's own: kv-index gather torch.equal (test/srt/test_create_kvindices.py:64);
+decode attention atol 3e-2 + cosine > 0.99 on bf16 (test/srt/cpu/test_decode.py:136-140).  Against the
+fp32 Triton vector the kernel is additionally held to 2e-2 absolute (bf16 output rounding of |o| <~ 4)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from sglang_security_amd import ops
+
+    return ops
+
+
+@pytest.mark.parametrize("name", ["kv_indices_small", "kv_indices_ragged"])
+@pytest.mark.parametrize("idx_dtype", [torch.int32, torch.int64])
+def test_create_kv_indices_golden(golden, name, idx_dtype):
+    ops = _ops()
+    g = golden(name)
+    r2t = g["req_to_token"].to(DEV)
+    idx = g["req_pool_indices"].to(idx_dtype).to(DEV)
+    lens = g["lens"].to(idx_dtype).to(DEV)
+    ptr = g["kv_indptr"].to(DEV)
+    out = torch.full((int(g["kv_indptr"][-1]),), -1, dtype=torch.int32, device=DEV)
+    ops.create_kv_indices(r2t, idx, lens, ptr, None, out)
+    assert torch.equal(out.cpu(), g["expect"])
+    out2 = torch.full_like(out, -1)
+    ops.create_kv_indices(r2t, idx, lens, ptr, g["kv_start"].to(idx_dtype).to(DEV), out2)
+    assert torch.equal(out2.cpu(), g["expect_start"])
+
+
+@pytest.mark.parametrize("bs", [1, 37, 1786])
+def test_create_kv_indices_reference_shapes(bs):
+    """The reference's own test shape: 4096 x 4096 table, batch {1, 37, 1786} (test_create_kvindices.py:18-71)."""
+    import oracle
+
+    ops = _ops()
+    torch.manual_seed(42)
+    max_batch, max_ctx = 4096, 4096
+    r2t = torch.arange(max_batch * max_ctx, dtype=torch.int32).reshape(max_batch, max_ctx)
+    idx = torch.randperm(max_batch)[:bs].to(torch.int32)
+    lens = torch.randint(1, max_ctx, (bs,), dtype=torch.int32)
+    ptr = torch.zeros(bs + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(lens, 0)
+    want = oracle.create_kv_indices(r2t, idx, lens, ptr)
+    out = torch.empty(int(ptr[-1]), dtype=torch.int32, device=DEV)
+    ptr_d = torch.zeros(bs + 1, dtype=torch.int32, device=DEV)
+    ops.kv_indptr_cumsum(lens.to(DEV), ptr_d)
+    assert torch.equal(ptr_d.cpu(), ptr)
+    ops.create_kv_indices(r2t.to(DEV), idx.to(DEV), lens.to(DEV), ptr_d, None, out)
+    assert torch.equal(out.cpu(), want)
+
+
+def test_num_kv_splits_golden():
+    import json
+    import os
+
+    from conftest import GOLDEN
+
+    ops = _ops()
+    cases = json.load(open(os.path.join(GOLDEN, "num_kv_splits.json")))
+    for c in cases:
+        sl = torch.tensor(c["seq_lens"], dtype=torch.int64, device=DEV)
+        out = torch.zeros(len(c["seq_lens"]), dtype=torch.int32, device=DEV)
+        ops.get_num_kv_splits(out, sl, c["num_head"], c["num_kv_head"], c["max_kv_splits"], c["device_core_count"])
+        assert out.cpu().tolist() == c["expect"], c
+
+
+def _run_decode(ops, g, dtype, max_splits=8, splits=None):
+    q = g["q"].to(dtype).to(DEV)
+    kb, vb = g["k_buffer"].to(dtype).to(DEV), g["v_buffer"].to(dtype).to(DEV)
+    B, Hq, D = q.shape
+    Dv = vb.shape[-1]
+    o = torch.zeros(B, Hq, Dv, dtype=dtype, device=DEV)
+    al = torch.empty(B, Hq, max_splits, Dv, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, max_splits, dtype=torch.float32, device=DEV)
+    ns = (g["num_kv_splits"] if splits is None else splits).to(torch.int32).to(DEV)
+    ops.decode_attention_fwd(q, kb, vb, o, g["kv_indptr"].to(DEV), g["kv_indices"].to(DEV), al, lse, ns, max_splits,
+                             g["sm_scale"], g["logit_cap"])
+    torch.cuda.synchronize()
+    return o.float().cpu()
+
+
+DECODE_CASES = ["gqa128", "mha64", "mqa_cap", "mla", "odd", "shared", "gqa_q05"]
+
+
+@pytest.mark.parametrize("case", DECODE_CASES)
+def test_decode_attention_golden_bf16(golden, case):
+    ops = _ops()
+    g = golden("decode_" + case)
+    o = _run_decode(ops, g, torch.bfloat16)
+    ref32 = g["expect_triton_f32"]
+    assert torch.isfinite(o).all()
+    assert (o - ref32).abs().max().item() < 2e-2
+    cpu = g["expect_cpu_bf16"].float()
+    cos = torch.nn.functional.cosine_similarity(o.flatten(), cpu.flatten(), dim=0)
+    assert cos.item() > 0.99
+    torch.testing.assert_close(o, cpu, atol=3e-2, rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["gqa128", "odd", "mha64"])
+def test_decode_attention_golden_f32_f16(golden, case):
+    ops = _ops()
+    g = golden("decode_" + case)
+    o32 = _run_decode(ops, g, torch.float32)
+    assert (o32 - g["expect_triton_f32"]).abs().max().item() < 2e-5
+    o16 = _run_decode(ops, g, torch.float16)
+    assert (o16 - g["expect_triton_f32"]).abs().max().item() < 4e-3
+
+
+def _synthetic_batch(B, Hq, Hkv, D, prefix, suffix_lo, suffix_hi, dtype, seed=0, ragged=True):
+    gen = torch.Generator().manual_seed(seed)
+    lens = [prefix + int(torch.randint(suffix_lo, suffix_hi + 1, (1,), generator=gen)) for _ in range(B)]
+    if not ragged:
+        lens = [prefix + suffix_hi] * B
+    n = 1 + prefix + sum(L - prefix for L in lens) + 3
+    kb = torch.randn(n, Hkv, D, generator=gen).to(dtype)
+    vb = torch.randn(n, Hkv, D, generator=gen).to(dtype)
+    q = torch.randn(B, Hq, D, generator=gen).to(dtype)
+    r2t = torch.zeros(B, max(lens) + 4, dtype=torch.int32)
+    nxt = 1 + prefix
+    for b, L in enumerate(lens):
+        r2t[b, :prefix] = torch.arange(1, 1 + prefix)
+        r2t[b, prefix:L] = torch.arange(nxt, nxt + L - prefix)
+        nxt += L - prefix
+    return q, kb, vb, r2t, torch.tensor(lens, dtype=torch.int64)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Hq,Hkv,prefix,max_splits", [(5, 32, 8, 96, 8), (3, 8, 8, 10, 4), (2, 64, 2, 300, 16),
+                                                        (4, 40, 8, 0, 8)])
+def test_decode_attention_vs_oracle(dtype, B, Hq, Hkv, prefix, max_splits):
+    """Seeded shared-prefix batches (head size 128: the matrix-core path) against the C oracle; includes a
+    GQA group of 32 (two head tiles), MHA, ragged lengths and sequences shorter than one tile."""
+    import oracle
+
+    ops = _ops()
+    q, kb, vb, r2t, seq = _synthetic_batch(B, Hq, Hkv, 128, prefix, 1, 200, dtype, seed=B)
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(seq, 0)
+    ind = oracle.create_kv_indices(r2t, torch.arange(B), seq, ptr)
+    ns_d = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(ns_d, seq.to(DEV), Hq, Hkv, max_splits, 256)
+    ns = ns_d.cpu()
+    sm = 1.0 / math.sqrt(128)
+    want = oracle.decode_attention(q, kb, vb, ptr, ind, ns, sm)
+    g = dict(q=q, k_buffer=kb, v_buffer=vb, kv_indptr=ptr, kv_indices=ind, num_kv_splits=ns, sm_scale=sm,
+             logit_cap=0.0)
+    o = _run_decode(ops, g, dtype, max_splits)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (o - want).abs().max().item() < tol
+    cos = torch.nn.functional.cosine_similarity(o.flatten(), want.flatten(), dim=0)
+    assert cos.item() > 0.999
+
+
+def test_decode_attention_noncontiguous_pool():
+    """Pools with permuted head/token strides, as the reference CPU test builds them
+    (test/srt/cpu/test_decode.py:103-107)."""
+    import oracle
+
+    ops = _ops()
+    q, kb, vb, r2t, seq = _synthetic_batch(3, 32, 8, 128, 40, 5, 60, torch.bfloat16, seed=7)
+    B = 3
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(seq, 0)
+    ind = oracle.create_kv_indices(r2t, torch.arange(B), seq, ptr)
+    ns = torch.tensor([2, 1, 3], dtype=torch.int32)
+    sm = 1.0 / math.sqrt(128)
+    want = oracle.decode_attention(q, kb, vb, ptr, ind, ns, sm)
+    kb_d = kb.to(DEV).transpose(0, 1).contiguous().transpose(0, 1)
+    vb_d = vb.to(DEV).transpose(0, 1).contiguous().transpose(0, 1)
+    assert not kb_d.is_contiguous()
+    o = torch.zeros(B, 32, 128, dtype=torch.bfloat16, device=DEV)
+    al = torch.empty(B, 32, 4, 128, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, 32, 4, dtype=torch.float32, device=DEV)
+    ops.decode_attention_fwd(q.to(DEV), kb_d, vb_d, o, ptr.to(DEV), ind.to(DEV), al, lse, ns.to(DEV), 4, sm, 0.0)
+    assert (o.float().cpu() - want).abs().max().item() < 2e-2
+
+
+def test_decode_attention_full_size_properties():
+    """BASELINE workload size (batch 64, 1024 shared + 128 private tokens, Llama-3-8B heads).  Too large
+    for the scalar oracle in seconds, so: (1) the result must not depend on the split count (8 vs 1 vs 16);
+    (2) requests with identical slots and queries must give identical rows; (3) a sample of rows is checked
+    against the oracle."""
+    import oracle
+
+    ops = _ops()
+    B, Hq, Hkv, D = 64, 32, 8, 128
+    q, kb, vb, r2t, seq = _synthetic_batch(B, Hq, Hkv, D, 1024, 128, 128, torch.bfloat16, seed=1, ragged=False)
+    q[1] = q[0]
+    r2t[1] = r2t[0]
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(seq, 0)
+    ind = oracle.create_kv_indices(r2t, torch.arange(B), seq, ptr)
+    sm = 1.0 / math.sqrt(D)
+    g = dict(q=q, k_buffer=kb, v_buffer=vb, kv_indptr=ptr, kv_indices=ind, sm_scale=sm, logit_cap=0.0)
+    o8 = _run_decode(ops, g, torch.bfloat16, 8, torch.full((B,), 8))
+    o1 = _run_decode(ops, g, torch.bfloat16, 8, torch.full((B,), 1))
+    o16 = _run_decode(ops, g, torch.bfloat16, 16, torch.full((B,), 16))
+    assert (o8 - o1).abs().max().item() < 1e-2
+    assert (o8 - o16).abs().max().item() < 1e-2
+    assert torch.equal(o8[0], o8[1])
+    sel = [0, 17, 63]
+    ptr_s = torch.zeros(len(sel) + 1, dtype=torch.int32)
+    ptr_s[1:] = torch.cumsum(seq[sel], 0)
+    ind_s = torch.cat([r2t[b, : int(seq[b])] for b in sel])
+    want = oracle.decode_attention(q[sel], kb, vb, ptr_s, ind_s, torch.full((3,), 8), sm)
+    assert (o8[sel] - want).abs().max().item() < 2e-2
+
+
+def test_decode_attention_rejects_bad_arguments():
+    ops = _ops()
+    from sglang_security_amd import SglkError
+
+    q = torch.zeros(1, 6, 128, dtype=torch.bfloat16, device=DEV)
+    kb = torch.zeros(4, 4, 128, dtype=torch.bfloat16, device=DEV)
+    o = torch.zeros(1, 6, 128, dtype=torch.bfloat16, device=DEV)
+    al = torch.zeros(1, 6, 2, 128, device=DEV)
+    lse = torch.zeros(1, 6, 2, device=DEV)
+    ptr = torch.tensor([0, 2], dtype=torch.int32, device=DEV)
+    ind = torch.tensor([1, 2], dtype=torch.int32, device=DEV)
+    ns = torch.tensor([1], dtype=torch.int32, device=DEV)
+    with pytest.raises(SglkError):
+        ops.decode_attention_fwd(q, kb, kb, o, ptr, ind, al, lse, ns, 2, 1.0)  # 6 heads over 4 kv heads
+    with pytest.raises(SglkError):
+        ops.decode_attention_fwd(q.cpu(), kb, kb, o, ptr, ind, al, lse, ns, 2, 1.0)  # CPU tensor: no fallback

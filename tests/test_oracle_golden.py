@@ -1,0 +1,128 @@
+"""CPU: pin the C oracle (oracle/oracle.c) against the committed golden vectors, which were produced by the
+reference itself (Triton kernels under the CPU interpreter, compiled sgl-kernel CPU kernels, and the torch
+reference functions inside the reference's kernel tests) -- see oracle/gen_golden.py."""
+import json
+import os
+
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, load_golden
+
+
+@pytest.mark.parametrize("name", ["kv_indices_small", "kv_indices_ragged"])
+def test_kv_indices(name):
+    g = load_golden(name)
+    out = oracle.create_kv_indices(g["req_to_token"], g["req_pool_indices"], g["lens"], g["kv_indptr"])
+    assert torch.equal(out, g["expect"])
+    out = oracle.create_kv_indices(g["req_to_token"], g["req_pool_indices"], g["lens"], g["kv_indptr"], g["kv_start"])
+    assert torch.equal(out, g["expect_start"])
+
+
+def test_num_kv_splits():
+    for c in json.load(open(os.path.join(GOLDEN, "num_kv_splits.json"))):
+        out = oracle.get_num_kv_splits(torch.tensor(c["seq_lens"]), 1, c["num_head"], c["num_kv_head"],
+                                       c["max_kv_splits"], c["device_core_count"])
+        assert out.tolist() == c["expect"]
+
+
+@pytest.mark.parametrize("case", ["gqa128", "mha64", "mqa_cap", "mla", "odd", "shared", "gqa_q05"])
+def test_decode_attention(case):
+    g = load_golden("decode_" + case)
+    o = oracle.decode_attention(g["q"], g["k_buffer"], g["v_buffer"], g["kv_indptr"], g["kv_indices"],
+                                g["num_kv_splits"], g["sm_scale"], g["logit_cap"])
+    # Triton kernel, fp32 arithmetic on the same (bf16-valued) inputs
+    assert (o - g["expect_triton_f32"]).abs().max().item() < 2e-5
+    # compiled reference CPU kernel, bf16 output: the reference's own tolerance (test_decode.py:136-140)
+    torch.testing.assert_close(o, g["expect_cpu_bf16"].float(), atol=3e-2, rtol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["gqa128", "mha64_cap"])
+def test_extend_attention(case):
+    g = load_golden("extend_" + case)
+    o = oracle.extend_attention(g["q_extend"], g["k_extend"], g["v_extend"], g["k_buffer"], g["v_buffer"],
+                                g["qo_indptr"], g["kv_indptr"], g["kv_indices"], g["sm_scale"], g["logit_cap"])
+    assert (o - g["expect_triton_f32"]).abs().max().item() < 2e-5
+    torch.testing.assert_close(o, g["expect_cpu_bf16"].float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["merge_state_bf16", "merge_state_f16", "merge_state_f32"])
+def test_merge_state(name):
+    g = load_golden(name)
+    vo, so = oracle.merge_state(g["v_a"], g["s_a"], g["v_b"], g["s_b"])
+    torch.testing.assert_close(vo.to(g["expect_v"].dtype).float(), g["expect_v"].float(), atol=1e-3, rtol=1e-2)
+    torch.testing.assert_close(so, g["expect_s"], atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["awq_g128_bf16", "awq_g128_f16", "awq_gall_f16", "awq_g64_bf16"])
+def test_awq(name):
+    g = load_golden(name)
+    w = oracle.awq_dequantize(g["qweight"], g["scales"], g["qzeros"])
+    assert torch.equal(w.view(torch.int16), g["expect"].view(torch.int16))  # bit-exact
+    y = oracle.half_matmul(g["x"], w).float()
+    want = g["expect_matmul_f32"]
+    assert (y - want).abs().max().item() <= 1e-2 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("name", ["norm_f16", "norm_bf16", "norm_odd"])
+def test_norm(name):
+    g = load_golden(name)
+    y = oracle.rmsnorm(g["x"], g["weight"], g["eps"])
+    torch.testing.assert_close(y.float(), g["expect_rmsnorm"].float(), rtol=1e-3, atol=1e-3)
+    y2, r2 = oracle.fused_add_rmsnorm(g["x"], g["residual"], g["weight"], g["eps"])
+    torch.testing.assert_close(y2.float(), g["expect_fused_x"].float(), rtol=1e-3, atol=1e-3)
+    assert torch.equal(r2.view(torch.int16), g["expect_fused_residual"].view(torch.int16))
+    if "expect_rmsnorm_cpu" in g:
+        torch.testing.assert_close(y.float(), g["expect_rmsnorm_cpu"].float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["silu_f16", "silu_bf16"])
+def test_silu(name):
+    g = load_golden(name)
+    y = oracle.silu_and_mul(g["x"])
+    torch.testing.assert_close(y.float(), g["expect"].float(), rtol=1e-3, atol=1e-3)
+    if "expect_cpu" in g:
+        torch.testing.assert_close(y.float(), g["expect_cpu"].float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("name", ["rope_neox128", "rope_gptj128", "rope_partial"])
+def test_rope(name):
+    g = load_golden(name)
+    q = oracle.rope(g["q"], g["positions"], g["cos_sin_cache"], g["head_size"], bool(g["is_neox"]))
+    k = oracle.rope(g["k"], g["positions"], g["cos_sin_cache"], g["head_size"], bool(g["is_neox"]))
+    assert torch.equal(q.view(torch.int16), g["expect_q"].view(torch.int16))
+    assert torch.equal(k.view(torch.int16), g["expect_k"].view(torch.int16))
+
+
+def test_fp8_codec_matches_torch():
+    """The oracle's e4m3fn codec against torch's cast over every code and a dense sweep of floats."""
+    codes = torch.arange(256, dtype=torch.uint8)
+    want = codes.view(torch.float8_e4m3fn).float()
+    got = oracle.e4m3_decode(codes.view(torch.float8_e4m3fn))
+    ok = ~torch.isnan(want)
+    assert torch.equal(got[ok], want[ok]) and torch.isnan(got[~ok]).all()
+    x = torch.cat([torch.linspace(-460, 460, 20001), torch.randn(20000) * 0.01, torch.randn(20000) * 3])
+    enc = oracle.e4m3_encode(x).view(torch.uint8)
+    ref = x.clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert torch.equal(enc, ref)
+
+
+@pytest.mark.parametrize("name", ["fp8_mm_bf16", "fp8_mm_f16"])
+def test_fp8_scaled_mm(name):
+    g = load_golden(name)
+    out = oracle.fp8_scaled_mm(g["a"], g["b_nk"].t(), g["scale_a"], g["scale_b"], g["expect"].dtype, g.get("bias"))
+    torch.testing.assert_close(out.float(), g["expect"].float(), rtol=0.02, atol=1)
+
+
+def test_fp8_blockwise_mm():
+    g = load_golden("fp8_block_mm")
+    out = oracle.fp8_blockwise_mm(g["a"], g["b_nk"], g["scale_a"], g["scale_b_kn"].t().contiguous(), torch.bfloat16)
+    torch.testing.assert_close(out.float(), g["expect"].float(), rtol=0.02, atol=1)
+
+
+def test_per_token_quant_fp8():
+    g = load_golden("fp8_per_token_quant")
+    q, s = oracle.per_token_quant_fp8(g["x"])
+    torch.testing.assert_close(s.reshape(-1), g["expect_scale"], rtol=1e-6, atol=0)
+    torch.testing.assert_close(q.float(), g["expect_q"].float(), rtol=1e-3, atol=1e-3)
