@@ -1,0 +1,226 @@
+"""Decode-step driver for a Llama-family model on the sglk kernels.
+
+This is the host-side sequence the reference runs per decode step (python/sglang/srt/models/llama.py:245-267
+per layer; model_executor/model_runner.py:1139-1149 forward_decode; managers/schedule_batch.py:1464-1527
+prepare_for_decode), reduced to what the hot path needs: fixed-address buffers, every launch on the current
+stream, no allocation and no host synchronisation inside step(), so a step can be captured into a HIP graph
+(the reference's CudaGraphRunner, model_executor/cuda_graph_runner.py).
+
+Weights are synthetic (random int4 / scales in the AWQ layout of layers/quantization/awq.py:98-151).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+@dataclasses.dataclass
+class LlamaConfig:
+    hidden: int = 4096
+    layers: int = 32
+    q_heads: int = 32
+    kv_heads: int = 8
+    head_dim: int = 128
+    inter: int = 14336
+    vocab: int = 128256
+    rope_theta: float = 500000.0
+    max_pos: int = 8192
+    eps: float = 1e-5
+    group_size: int = 128
+    quant: str = "awq"  # "awq" (int4) or "bf16"
+
+    @staticmethod
+    def llama3_8b(quant="awq"):
+        return LlamaConfig(quant=quant)
+
+    @staticmethod
+    def tiny(quant="awq"):
+        return LlamaConfig(hidden=512, layers=2, q_heads=8, kv_heads=2, head_dim=128, inter=1024, vocab=1024,
+                           max_pos=2048, quant=quant)
+
+
+class _AwqLinear:
+    """AWQ weight in the reference layout plus the repacked copy the fused GEMM streams."""
+
+    def __init__(self, K, N, group, dtype, device, gen, keep_reference_layout=False):
+        self.K, self.N = K, N
+        qweight = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=device, generator=gen)
+        self.qzeros = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // group, N // 8), dtype=torch.int32, device=device,
+                                    generator=gen)
+        # U(0,1) * 0.01 scales as in the reference's kernel tests, rescaled so activations stay O(1)
+        self.scales = (torch.rand(K // group, N, device=device, generator=gen) * (2.0 / math.sqrt(K) / 4.6)).to(dtype)
+        self.packed = ops.awq_repack(qweight)
+        self.qweight = qweight if keep_reference_layout else None
+        self.ws_bytes = 0
+
+    def bytes(self):
+        return self.packed.numel() * 4 + self.qzeros.numel() * 4 + self.scales.numel() * 2
+
+
+class _DenseLinear:
+    def __init__(self, K, N, dtype, device, gen):
+        self.K, self.N = K, N
+        self.weight = (torch.randn(N, K, device=device, generator=gen) / math.sqrt(K)).to(dtype)
+
+    def bytes(self):
+        return self.weight.numel() * 2
+
+
+class LlamaDecoder:
+    def __init__(self, cfg: LlamaConfig, batch: int, pool_slots: int, max_ctx: int, dtype=torch.bfloat16,
+                 device="cuda", seed=0, max_kv_splits=8, keep_reference_layout=False):
+        self.cfg, self.B, self.dtype, self.device = cfg, batch, dtype, device
+        gen = torch.Generator(device=device).manual_seed(seed)
+        c = cfg
+        self.q_size, self.kv_size = c.q_heads * c.head_dim, c.kv_heads * c.head_dim
+
+        def lin(K, N):
+            if c.quant == "awq":
+                return _AwqLinear(K, N, c.group_size, dtype, device, gen, keep_reference_layout)
+            return _DenseLinear(K, N, dtype, device, gen)
+
+        self.embed = (torch.randn(c.vocab, c.hidden, device=device, generator=gen) * 0.5).to(dtype)
+        self.lm_head = _DenseLinear(c.hidden, c.vocab, dtype, device, gen)
+        self.final_norm = torch.ones(c.hidden, dtype=dtype, device=device)
+        self.layers = []
+        for _ in range(c.layers):
+            self.layers.append(dict(
+                ln1=(1.0 + 0.1 * torch.randn(c.hidden, device=device, generator=gen)).to(dtype),
+                ln2=(1.0 + 0.1 * torch.randn(c.hidden, device=device, generator=gen)).to(dtype),
+                qkv=lin(c.hidden, self.q_size + 2 * self.kv_size),
+                o=lin(self.q_size, c.hidden),
+                gate_up=lin(c.hidden, 2 * c.inter),
+                down=lin(c.inter, c.hidden),
+            ))
+        # rotary cache, layout of RotaryEmbedding._compute_cos_sin_cache (layers/rotary_embedding.py)
+        inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=device) / c.head_dim))
+        t = torch.arange(c.max_pos, dtype=torch.float32, device=device)
+        fr = torch.einsum("i,j->ij", t, inv)
+        self.cos_sin = torch.cat([fr.cos(), fr.sin()], dim=-1).contiguous()
+        # KV pool: per layer [slots, Hkv, D], slot 0 a dummy (mem_cache/memory_pool.py:277-296)
+        self.k_pool = [torch.zeros(pool_slots, c.kv_heads, c.head_dim, dtype=dtype, device=device) for _ in range(c.layers)]
+        self.v_pool = [torch.zeros(pool_slots, c.kv_heads, c.head_dim, dtype=dtype, device=device) for _ in range(c.layers)]
+        self.req_to_token = torch.zeros(batch + 1, max_ctx + 4, dtype=torch.int32, device=device)
+        # attention metadata at fixed addresses (TritonAttnBackend.init_cuda_graph_state, triton_backend.py:448-487)
+        self.max_kv_splits = max_kv_splits
+        self.kv_indptr = torch.zeros(batch + 1, dtype=torch.int32, device=device)
+        self.kv_indices = torch.zeros(batch * (max_ctx + 4), dtype=torch.int32, device=device)
+        self.num_kv_splits = torch.zeros(batch, dtype=torch.int32, device=device)
+        self.attn_logits = torch.empty(batch, c.q_heads, max_kv_splits, c.head_dim, dtype=torch.float32, device=device)
+        self.attn_lse = torch.empty(batch, c.q_heads, max_kv_splits, dtype=torch.float32, device=device)
+        self.cu_count = 256
+        # activations
+        B = batch
+        self.hidden = torch.empty(B, c.hidden, dtype=dtype, device=device)
+        self.residual = torch.empty(B, c.hidden, dtype=dtype, device=device)
+        self.qkv = torch.empty(B, self.q_size + 2 * self.kv_size, dtype=dtype, device=device)
+        self.attn_out = torch.empty(B, self.q_size, dtype=dtype, device=device)
+        self.gate_up = torch.empty(B, 2 * c.inter, dtype=dtype, device=device)
+        self.act = torch.empty(B, c.inter, dtype=dtype, device=device)
+        self.logits = torch.empty(B, c.vocab, dtype=dtype, device=device)
+        ws = 0
+        if c.quant == "awq":
+            for K, N in ((c.hidden, self.q_size + 2 * self.kv_size), (self.q_size, c.hidden), (c.hidden, 2 * c.inter),
+                         (c.inter, c.hidden)):
+                ws = max(ws, ops.awq_gemm_workspace_bytes(B, N, K))
+        self.workspace = torch.zeros(max(ws, 256), dtype=torch.uint8, device=device)  # ticket words start at zero
+        # batch state (ScheduleBatch fields, device resident)
+        self.input_ids = torch.zeros(B, dtype=torch.int64, device=device)
+        self.positions = torch.zeros(B, dtype=torch.int64, device=device)
+        self.seq_lens = torch.zeros(B, dtype=torch.int64, device=device)
+        self.out_cache_loc = torch.zeros(B, dtype=torch.int64, device=device)
+        self.req_pool_indices = torch.arange(B, dtype=torch.int64, device=device)
+        self.next_ids = torch.zeros(B, dtype=torch.int64, device=device)
+        self.gemm_timer = None  # optional callable(name, fn) used by bench.py to time launches with events
+
+    # ---- weights / bytes ------------------------------------------------------------------------
+    def layer_weight_bytes(self) -> int:
+        L = self.layers[0]
+        return sum(L[k].bytes() for k in ("qkv", "o", "gate_up", "down"))
+
+    # ---- batch set-up: shared prefix + private suffix (bench_in_batch_prefix shape) -------------------
+    def setup_shared_prefix_batch(self, prefix_len: int, suffix_len: int, seed: int = 0, share: bool = True):
+        """req_to_token rows share slots 1..prefix_len, then private ranges; pools filled with N(0,1)."""
+        B = self.B
+        gen = torch.Generator(device=self.device).manual_seed(seed + 1)
+        r2t = torch.zeros_like(self.req_to_token)
+        per_req = (self.k_pool[0].shape[0] - 1 - (prefix_len if share else 0)) // B
+        base0 = 1 + (prefix_len if share else 0)
+        self.private_base = torch.zeros(B, dtype=torch.int64, device=self.device)
+        width = r2t.shape[1]
+        for b in range(B):
+            base = base0 + b * per_req
+            first = prefix_len if share else 0
+            if share:
+                r2t[b, :prefix_len] = torch.arange(1, 1 + prefix_len, dtype=torch.int32, device=self.device)
+            n = min(per_req, width - first)
+            r2t[b, first:first + n] = torch.arange(base, base + n, dtype=torch.int32, device=self.device)
+        self.req_to_token.copy_(r2t)
+        for l in range(self.cfg.layers):
+            self.k_pool[l].normal_(generator=gen)
+            self.v_pool[l].normal_(generator=gen)
+        L = prefix_len + suffix_len
+        # state BEFORE the first decode step: L tokens cached, the next token goes to position L
+        self.seq_lens.fill_(L)
+        self.input_ids.copy_(torch.randint(0, self.cfg.vocab, (B,), device=self.device, generator=gen))
+        self.prefix_len = prefix_len if share else 0
+
+    # ---- one decode step ------------------------------------------------------------------------------
+    def _linear(self, name, w, x, out):
+        def run():
+            if isinstance(w, _AwqLinear):
+                ops.awq_gemm(x, w.packed, w.scales, w.qzeros, None, out, self.workspace)
+            else:
+                ops.dense_gemm_nt(x, w.weight, None, out)
+
+        if self.gemm_timer is not None:
+            self.gemm_timer(name, run)
+        else:
+            run()
+        return out
+
+    def prepare_for_decode(self):
+        """schedule_batch.py:1464-1527: seq_lens += 1; out_cache_loc = the request's next free slot;
+        req_to_token[req, seq_len - 1] = out_cache_loc.  All on device."""
+        self.positions.copy_(self.seq_lens)  # the new token's position = tokens cached so far
+        self.seq_lens.add_(1)
+        loc = self.req_to_token[self.req_pool_indices, self.positions]  # private slots are pre-assigned per request
+        self.out_cache_loc.copy_(loc)
+
+    def step(self):
+        c = self.cfg
+        self.prepare_for_decode()
+        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
+                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
+        sm_scale = 1.0 / math.sqrt(c.head_dim)
+        q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
+        o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                self.residual.copy_(self.hidden)
+                ops.rmsnorm(self.hidden, self.hidden, L["ln1"], c.eps)
+            else:
+                ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln1"], c.eps)
+            self._linear("qkv", L["qkv"], self.hidden, self.qkv)
+            ops.rope_and_store_kv(self.qkv, self.cos_sin, self.positions, self.k_pool[li], self.v_pool[li],
+                                  self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
+            self.attention(li, q_view, o_view, sm_scale)
+            self._linear("o", L["o"], self.attn_out, self.hidden)
+            ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln2"], c.eps)
+            self._linear("gate_up", L["gate_up"], self.hidden, self.gate_up)
+            ops.act_and_mul(self.act, self.gate_up, 0)
+            self._linear("down", L["down"], self.act, self.hidden)
+        ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)
+        ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
+        torch.argmax(self.logits, dim=-1, out=self.next_ids)
+        self.input_ids.copy_(self.next_ids)
+
+    def attention(self, li, q_view, o_view, sm_scale):
+        ops.decode_attention_fwd(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
+                                 self.attn_logits, self.attn_lse, self.num_kv_splits, self.max_kv_splits, sm_scale, 0.0)

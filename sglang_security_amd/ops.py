@@ -289,7 +289,8 @@ def awq_gemm(x, packed, scales, qzeros, bias=None, out=None, workspace=None):
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
     need = awq_gemm_workspace_bytes(M, N, K)
     if workspace is None:
-        workspace = torch.empty(need, dtype=torch.uint8, device=x.device)
+        # the head of the workspace holds split-K ticket counters: zero before first use, left zero by every call
+        workspace = torch.zeros(need, dtype=torch.uint8, device=x.device)
     elif workspace.numel() * workspace.element_size() < need:
         raise SglkError(f"awq_gemm: workspace too small ({need} bytes needed)")
     check(lib().sglk_awq_gemm(_ptr(x), _ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(out),

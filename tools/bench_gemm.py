@@ -1,0 +1,69 @@
+"""Micro-benchmark of the weight-streaming GEMMs on the Llama-3-8B decode shapes (M = 64).
+
+Rotates over enough distinct weight copies that no launch finds its weights in the 256 MiB Infinity Cache,
+times with events on the launch stream, prints GB/s of algorithmic bytes per shape."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sglang_security_amd import ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--m", type=int, default=64)
+ap.add_argument("--iters", type=int, default=40)
+ap.add_argument("--dense", action="store_true")
+args = ap.parse_args()
+dev = "cuda"
+M = args.m
+shapes = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]
+if args.dense:
+    shapes = [("lm_head", 4096, 128256)]
+gen = torch.Generator(device=dev).manual_seed(0)
+for name, K, N in shapes:
+    wbytes = K * N // 2 + (K // 128) * N * 2 + (K // 128) * N // 2 if not args.dense else K * N * 2
+    copies = max(2, int(600e6 // wbytes) + 1)
+    x = torch.randn(M, K, device=dev, generator=gen).to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ws = []
+    for _ in range(copies):
+        if args.dense:
+            ws.append(((torch.randn(N, K, device=dev, generator=gen) * 0.02).to(torch.bfloat16),))
+        else:
+            qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
+            qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // 128, N // 8), dtype=torch.int32, device=dev, generator=gen)
+            sc = (torch.rand(K // 128, N, device=dev, generator=gen) * 0.01).to(torch.bfloat16)
+            ws.append((ops.awq_repack(qw), sc, qz))
+            del qw
+    work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), 256), dtype=torch.uint8, device=dev)
+
+    def run(i):
+        w = ws[i % copies]
+        if args.dense:
+            ops.dense_gemm_nt(x, w[0], None, out)
+        else:
+            ops.awq_gemm(x, w[0], w[1], w[2], None, out, work)
+
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for i in range(copies):
+            run(i)
+        st.synchronize()
+        # one graph of `iters` launches: no host launch cost inside the timed region
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st):
+            for i in range(args.iters):
+                run(i)
+        gr.replay()
+        st.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        gr.replay()
+        b.record(st)
+        st.synchronize()
+    us = a.elapsed_time(b) / args.iters * 1e3
+    tot = wbytes + 2 * M * (K + N)
+    print(f"{name:8s} K={K:6d} N={N:6d} copies={copies:3d}  {us:8.2f} us  {tot / us / 1e3:8.1f} GB/s  "
+          f"({2 * M * K * N / us / 1e6:7.1f} TFLOP/s)", flush=True)
