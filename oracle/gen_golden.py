@@ -482,6 +482,36 @@ def gen_radix():
             ep += 1
             script.append(dict(op="epoch", value=ep))
     run("random_user0", script)
+    # 7. hit-rate anomaly release (radix_cache.py:385-411): a burst of hits in one window frees the subtree,
+    #    skipping locked nodes
+    slot[0] = 1
+    g, g2, g3 = toks(30), toks(12), toks(9)
+    burst = [dict(op="match", key=g + g2, user="0") for _ in range(12)]
+    run("entropy_release", [
+        dict(op="insert", key=g + g2, value=slots(42), user="0"),
+        dict(op="insert", key=g + g3, value=slots(39), user="0"),
+        dict(op="match", key=g + g2, user="0"),
+        dict(op="epoch", value=1),
+        dict(op="match", key=g + g2, user="0"),
+    ] + burst + [
+        dict(op="match", key=g + g3, user="0"),
+        dict(op="insert", key=g + g2, value=slots(42), user="0"),
+        dict(op="evict", n=1000),
+    ])
+    slot[0] = 1
+    run("entropy_release_locked", [
+        dict(op="insert", key=g + g2, value=slots(42), user="0"),
+        dict(op="insert", key=g + g3, value=slots(39), user="0"),
+        dict(op="match", key=g + g3, user="0", handle="h"),
+        dict(op="match", key=g + g2, user="0"),
+        dict(op="lock", handle="h"),
+        dict(op="epoch", value=1),
+        dict(op="match", key=g + g2, user="0"),
+    ] + burst + [
+        dict(op="unlock", handle="h"),
+        dict(op="match", key=g + g3, user="0"),
+        dict(op="evict", n=1000),
+    ])
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "radix_traces.json"), "w") as f:
         json.dump(traces, f, separators=(",", ":"))
