@@ -1,0 +1,398 @@
+// fp8 (OCP e4m3fn) activation quantisation and scaled matmuls on the gfx950 fp8 matrix instructions.
+//
+//   sglk_per_token_quant_fp8        <- sgl-kernel/csrc/gemm/per_token_quant_fp8.cu:10-106
+//   sglk_per_token_group_quant_fp8  <- sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:19-197
+//   sglk_per_tensor_quant_fp8       <- sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu:10-122
+//   sglk_fp8_scaled_mm              <- sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146
+//   sglk_fp8_blockwise_scaled_mm    <- sgl-kernel/csrc/gemm/fp8_blockwise_gemm_kernel.cu:345-423
+//
+// Quantisation is bit-exact integer-valued work (one correctly rounded f32 op per step, then the
+// hardware round-to-nearest-even f32 -> e4m3 conversion of a value already clamped to +-448).
+// The matmuls accumulate in fp32 on v_mfma_f32_16x16x32_fp8_fp8.
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+constexpr float kFp8Max = 448.0f;
+
+template <typename T>
+__device__ __forceinline__ void load8(const void* base, int64_t i, float (&v)[8]) {
+  if constexpr (sizeof(typename Raw<T>::type) == 2) {
+    const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + i);
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[2 * j] = Conv<T>::to_f32((uint16_t)(w[j] & 0xffffu));
+      v[2 * j + 1] = Conv<T>::to_f32((uint16_t)(w[j] >> 16));
+    }
+  } else {
+    const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i);
+    const float4 b = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + i + 4);
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  }
+}
+
+__device__ __forceinline__ float clamp_sym(float v, float lo, float hi) { return fmaxf(fminf(v, hi), lo); }
+
+// two floats -> two e4m3 bytes in the low half of the result
+__device__ __forceinline__ uint32_t cvt2(float a, float b) {
+  return (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffffu;
+}
+__device__ __forceinline__ uint8_t cvt1(float a) { return (uint8_t)(cvt2(a, 0.f) & 0xff); }
+
+__device__ __forceinline__ uint2 cvt8(const float (&v)[8]) {
+  int lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+  int hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], 0, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+  return make_uint2((uint32_t)lo, (uint32_t)hi);
+}
+
+__device__ __forceinline__ float block_max_256(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  return v;
+}
+
+// ---- per token: one block per row ------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void per_token_quant_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
+                                                              float* __restrict__ scales, int hidden) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const int64_t base = row * hidden;
+  float amax = 0.f;
+  if constexpr (VEC) {
+    for (int i = threadIdx.x * 8; i < hidden; i += 256 * 8) {
+      float v[8];
+      load8<T>(x, base + i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    }
+  } else {
+    for (int i = threadIdx.x; i < hidden; i += 256) amax = fmaxf(amax, fabsf(ld<T>(x, base + i)));
+  }
+  amax = block_max_256(amax, red);
+  const float scale = amax / kFp8Max;
+  if (threadIdx.x == 0) scales[row] = scale;
+  const float inv = 1.0f / scale;
+  if constexpr (VEC) {
+    for (int i = threadIdx.x * 8; i < hidden; i += 256 * 8) {
+      float v[8];
+      load8<T>(x, base + i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = clamp_sym(v[j] * inv, -kFp8Max, kFp8Max);
+      *reinterpret_cast<uint2*>(q + base + i) = cvt8(v);
+    }
+  } else {
+    for (int i = threadIdx.x; i < hidden; i += 256)
+      q[base + i] = cvt1(clamp_sym(ld<T>(x, base + i) * inv, -kFp8Max, kFp8Max));
+  }
+}
+
+// ---- per (token, group): 16 lanes per group ------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void per_group_quant_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
+                                                              float* __restrict__ scales, int64_t rows, int hidden,
+                                                              int group, float eps, float fp8_min, float fp8_max,
+                                                              int col_major) {
+  const int ng = hidden / group;
+  const int64_t total = rows * ng;
+  const int sub = threadIdx.x & 15;
+  const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool live = gid < total;
+  const int64_t g = live ? gid : total - 1;  // every lane stays in the shuffles
+  const int64_t base = g * group;            // groups tile the row-major tensor contiguously
+  float amax = eps;
+  if constexpr (VEC) {
+    for (int i = sub * 8; i < group; i += 128) {
+      float v[8];
+      load8<T>(x, base + i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    }
+  } else {
+    for (int i = sub; i < group; i += 16) amax = fmaxf(amax, fabsf(ld<T>(x, base + i)));
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 16));
+  const float ys = amax / fp8_max;
+  if (!live) return;
+  if (sub == 0) {
+    const int64_t r = g / ng, c = g % ng;
+    scales[col_major ? c * rows + r : g] = ys;
+  }
+  if constexpr (VEC) {
+    for (int i = sub * 8; i < group; i += 128) {
+      float v[8];
+      load8<T>(x, base + i, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = clamp_sym(v[j] / ys, fp8_min, fp8_max);
+      *reinterpret_cast<uint2*>(q + base + i) = cvt8(v);
+    }
+  } else {
+    for (int i = sub; i < group; i += 16) q[base + i] = cvt1(clamp_sym(ld<T>(x, base + i) / ys, fp8_min, fp8_max));
+  }
+}
+
+// ---- per tensor ----------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void per_tensor_absmax_kernel(const void* __restrict__ x, float* __restrict__ scale,
+                                                                int64_t n) {
+  __shared__ float red[4];
+  float amax = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    amax = fmaxf(amax, fabsf(ld<T>(x, i)));
+  amax = block_max_256(amax, red);
+  // non-negative floats order like their bit patterns
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(scale), __float_as_int(amax / kFp8Max));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void per_tensor_quant_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
+                                                               const float* __restrict__ scale, int64_t n) {
+  const float inv = 1.0f / scale[0];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    q[i] = cvt1(clamp_sym(ld<T>(x, i) * inv, -kFp8Max, kFp8Max));
+}
+
+// ---- scaled matmul -------------------------------------------------------------------------------------
+//
+// Block = 4 waves on one (16*MT rows) x (32 cols) output tile; the waves split K in 128-byte blocks
+// (wave w takes blocks w, w+4, ...) and their fp32 partials are summed through LDS.  Operands go
+// straight from global memory to the MFMA registers: inside a 128-byte K block lane group g = lane>>4
+// owns bytes [32g, 32g+32) of its row for BOTH operands, so any fixed assignment of those bytes to the
+// four MFMA k-slots gives the same dot product.  BLOCKWISE applies a_scale[m,kb] * b_scale[n/128,kb]
+// per K block; otherwise the epilogue applies scales_a[m] * scales_b[n] (+ bias).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MmArgs {
+  const uint8_t* a;
+  const uint8_t* b;
+  const float* sa;
+  const float* sb;
+  const void* bias;
+  void* out;
+  int M, N, K;
+  int64_t a_stride, b_stride, out_stride;
+  int64_t sa_m, sa_k, sb_n, sb_k;
+};
+
+__device__ __forceinline__ void load32(const uint8_t* row, int k, int K, long (&r)[4]) {
+  // K % 16 == 0: 16-byte chunks are all-or-nothing
+  int4v lo = {0, 0, 0, 0}, hi = {0, 0, 0, 0};
+  if (k + 16 <= K) lo = *reinterpret_cast<const int4v*>(row + k);
+  if (k + 32 <= K) hi = *reinterpret_cast<const int4v*>(row + k + 16);
+  r[0] = (long)(uint32_t)lo.x | ((long)lo.y << 32);
+  r[1] = (long)(uint32_t)lo.z | ((long)lo.w << 32);
+  r[2] = (long)(uint32_t)hi.x | ((long)hi.y << 32);
+  r[3] = (long)(uint32_t)hi.z | ((long)hi.w << 32);
+}
+
+template <typename TO, int MT, bool BLOCKWISE>
+__global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
+  __shared__ float red[4][MT * 2][64][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 16 * MT;
+  const uint8_t* arow[MT];
+  int mrow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    mrow[i] = min(m0 + 16 * i + l16, p.M - 1);
+    arow[i] = p.a + (int64_t)mrow[i] * p.a_stride;
+  }
+  const uint8_t* brow[2];
+  int ncol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    ncol[j] = min(n0 + 16 * j + l16, p.N - 1);
+    brow[j] = p.b + (int64_t)ncol[j] * p.b_stride;
+  }
+  f32x4 tot[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kblocks = (p.K + 127) / 128;
+  for (int kb = w; kb < kblocks; kb += 4) {
+    const int k = kb * 128 + 32 * g;
+    long af[MT][4], bf[2][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) load32(arow[i], k, p.K, af[i]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) load32(brow[j], k, p.K, bf[j]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        f32x4 acc = BLOCKWISE ? f32x4{0.f, 0.f, 0.f, 0.f} : tot[i][j];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i][s], bf[j][s], acc, 0, 0, 0);
+        if constexpr (BLOCKWISE) {
+          // C layout: column = lane & 15, row = 4 * (lane >> 4) + r
+          const float bs = p.sb[(int64_t)(ncol[j] / 128) * p.sb_n + (int64_t)kb * p.sb_k];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = min(m0 + 16 * i + 4 * g + r, p.M - 1);
+            const float as = p.sa[(int64_t)m * p.sa_m + (int64_t)kb * p.sa_k];
+            tot[i][j][r] += acc[r] * as * bs;
+          }
+        } else {
+          tot[i][j] = acc;
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      *reinterpret_cast<f32x4*>(&red[w][i * 2 + j][lane][0]) = tot[i][j];
+  __syncthreads();
+  // wave w finishes tiles w, w+4, ...
+  for (int t = w; t < MT * 2; t += 4) {
+    const int i = t >> 1, j = t & 1;
+    f32x4 s = *reinterpret_cast<f32x4*>(&red[0][t][lane][0]);
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) {
+      const f32x4 o = *reinterpret_cast<f32x4*>(&red[ww][t][lane][0]);
+      s += o;
+    }
+    const int n = n0 + 16 * j + l16;
+    if (n >= p.N) continue;
+    float sbn = 1.f, bn = 0.f;
+    if constexpr (!BLOCKWISE) {
+      sbn = p.sb[n];
+      if (p.bias) bn = ld<TO>(p.bias, n);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + 16 * i + 4 * g + r;
+      if (m >= p.M) continue;
+      float v = s[r];
+      if constexpr (!BLOCKWISE) v = v * p.sa[m] * sbn + bn;
+      st<TO>(p.out, (int64_t)m * p.out_stride + n, v);
+    }
+  }
+}
+
+template <typename TO, bool BLOCKWISE>
+int launch_mm(const MmArgs& p, hipStream_t s) {
+  const dim3 block(256);
+  if (p.M <= 16) {
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 1, BLOCKWISE>), dim3((p.N + 31) / 32, (p.M + 15) / 16), block, 0, s, p);
+  } else if (p.M <= 32) {
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 2, BLOCKWISE>), dim3((p.N + 31) / 32, (p.M + 31) / 32), block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 4, BLOCKWISE>), dim3((p.N + 31) / 32, (p.M + 63) / 64), block, 0, s, p);
+  }
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+}  // namespace
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" {
+
+int sglk_per_token_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int hidden, int dtype,
+                             void* stream) {
+  SGLK_CHECK(x && q && scales, "per_token_quant_fp8: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0, "per_token_quant_fp8: bad shape rows=%lld hidden=%d", (long long)rows, hidden);
+  if (rows == 0) return SGLK_OK;
+  const bool vec = hidden % 8 == 0 && aligned16(x) && ((uintptr_t)q & 7) == 0;
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    if (vec)
+      hipLaunchKernelGGL((per_token_quant_kernel<T, true>), dim3((unsigned)rows), dim3(256), 0, s, x, (uint8_t*)q, scales,
+                         hidden);
+    else
+      hipLaunchKernelGGL((per_token_quant_kernel<T, false>), dim3((unsigned)rows), dim3(256), 0, s, x, (uint8_t*)q,
+                         scales, hidden);
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_per_token_group_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int hidden, int group_size,
+                                   float eps, float fp8_min, float fp8_max, int scale_col_major, int dtype,
+                                   void* stream) {
+  SGLK_CHECK(x && q && scales, "per_token_group_quant_fp8: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0 && group_size > 0, "per_token_group_quant_fp8: bad shape");
+  SGLK_CHECK(hidden % group_size == 0, "per_token_group_quant_fp8: hidden %d not a multiple of group_size %d", hidden,
+             group_size);
+  SGLK_CHECK(fp8_max > 0.f && fp8_min < 0.f, "per_token_group_quant_fp8: bad clamp range");
+  if (rows == 0) return SGLK_OK;
+  const int64_t groups = rows * (hidden / group_size);
+  const bool vec = group_size % 8 == 0 && aligned16(x) && ((uintptr_t)q & 7) == 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((unsigned)((groups + 15) / 16));
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    if (vec)
+      hipLaunchKernelGGL((per_group_quant_kernel<T, true>), grid, dim3(256), 0, s, x, (uint8_t*)q, scales, rows, hidden,
+                         group_size, eps, fp8_min, fp8_max, scale_col_major);
+    else
+      hipLaunchKernelGGL((per_group_quant_kernel<T, false>), grid, dim3(256), 0, s, x, (uint8_t*)q, scales, rows, hidden,
+                         group_size, eps, fp8_min, fp8_max, scale_col_major);
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_per_tensor_quant_fp8(const void* x, void* q, float* scale, int64_t numel, int is_static, int dtype,
+                              void* stream) {
+  SGLK_CHECK(x && q && scale, "per_tensor_quant_fp8: null pointer");
+  SGLK_CHECK(numel >= 0, "per_tensor_quant_fp8: negative size");
+  if (numel == 0) return SGLK_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)std::min<int64_t>((numel + 255) / 256, 1024);
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    if (!is_static) hipLaunchKernelGGL((per_tensor_absmax_kernel<T>), dim3(blocks), dim3(256), 0, s, x, scale, numel);
+    hipLaunchKernelGGL((per_tensor_quant_kernel<T>), dim3(blocks), dim3(256), 0, s, x, (uint8_t*)q, scale, numel);
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* scales_a, const float* scales_b, const void* bias,
+                       void* out, int M, int N, int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
+                       int out_dtype, void* stream) {
+  SGLK_CHECK(a && b_nk && scales_a && scales_b && out, "fp8_scaled_mm: null pointer");
+  SGLK_CHECK(M >= 0 && N > 0 && K > 0, "fp8_scaled_mm: bad shape M=%d N=%d K=%d", M, N, K);
+  // fp8_gemm_kernel.cu:1086-1091: both inner dimensions must be multiples of 16 bytes
+  SGLK_CHECK(K % 16 == 0, "fp8_scaled_mm: K=%d must be a multiple of 16", K);
+  SGLK_CHECK(N % 16 == 0, "fp8_scaled_mm: N=%d must be a multiple of 16", N);
+  SGLK_CHECK(a_stride % 16 == 0 && b_stride % 16 == 0 && aligned16(a) && aligned16(b_nk),
+             "fp8_scaled_mm: operand rows must be 16-byte aligned");
+  SGLK_CHECK(a_stride >= K && b_stride >= K && out_stride >= N, "fp8_scaled_mm: stride smaller than the row");
+  if (M == 0) return SGLK_OK;
+  MmArgs p{(const uint8_t*)a, (const uint8_t*)b_nk, scales_a, scales_b, bias, out, M, N, K, a_stride, b_stride,
+           out_stride,        0,                    0,        0,        0};
+  SGLK_DISPATCH_HALF(out_dtype, TO, return (launch_mm<TO, false>(p, (hipStream_t)stream)));
+  return SGLK_OK;
+}
+
+int sglk_fp8_blockwise_scaled_mm(const void* a, const void* b_nk, const float* scales_a, const float* scales_b,
+                                 void* out, int M, int N, int K, int64_t sa_stride_m, int64_t sa_stride_k,
+                                 int64_t sb_stride_n, int64_t sb_stride_k, int out_dtype, void* stream) {
+  SGLK_CHECK(a && b_nk && scales_a && scales_b && out, "fp8_blockwise_scaled_mm: null pointer");
+  SGLK_CHECK(M >= 0 && N > 0 && K > 0, "fp8_blockwise_scaled_mm: bad shape M=%d N=%d K=%d", M, N, K);
+  // fp8_blockwise_gemm_kernel.cu:372-380: K and N multiples of 16 bytes, 128x128 weight blocks
+  SGLK_CHECK(K % 16 == 0 && N % 16 == 0, "fp8_blockwise_scaled_mm: N=%d and K=%d must be multiples of 16", N, K);
+  SGLK_CHECK(aligned16(a) && aligned16(b_nk), "fp8_blockwise_scaled_mm: operands must be 16-byte aligned");
+  if (M == 0) return SGLK_OK;
+  MmArgs p{(const uint8_t*)a, (const uint8_t*)b_nk, scales_a,    scales_b,    nullptr,     out,        M, N, K, K, K,
+           N,                 sa_stride_m,          sa_stride_k, sb_stride_n, sb_stride_k};
+  SGLK_DISPATCH_HALF(out_dtype, TO, return (launch_mm<TO, true>(p, (hipStream_t)stream)));
+  return SGLK_OK;
+}
+
+}  // extern "C"

@@ -309,3 +309,100 @@ def dense_gemm_nt(x, w, bias=None, out=None):
     check(lib().sglk_dense_gemm_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x.stride(0), w.stride(0),
                                    out.stride(0), dtype_code(x.dtype), _stream(x)), "dense_gemm_nt")
     return out
+
+
+# ---- fp8 ----------------------------------------------------------------------------------------------
+def per_token_quant_fp8(x, out_q, out_s):
+    """sgl_per_token_quant_fp8(input, output_q, output_s) (sgl-kernel/python/sgl_kernel/gemm.py:131-136)."""
+    _need_gpu(x, out_q, out_s)
+    if not (x.is_contiguous() and out_q.is_contiguous() and out_s.is_contiguous()):
+        raise SglkError("per_token_quant_fp8: tensors must be contiguous")
+    if out_q.dtype != torch.float8_e4m3fn or out_s.dtype != torch.float32:
+        raise SglkError("per_token_quant_fp8: output_q must be float8_e4m3fn and output_s float32")
+    hidden = x.shape[-1]
+    rows = x.numel() // hidden if hidden else 0
+    check(lib().sglk_per_token_quant_fp8(_ptr(x), _ptr(out_q), _ptr(out_s), rows, hidden, dtype_code(x.dtype),
+                                         _stream(x)), "per_token_quant_fp8")
+
+
+def per_token_group_quant_fp8(x, out_q, out_s, group_size, eps, fp8_min, fp8_max):
+    """sgl_per_token_group_quant_fp8 (sgl-kernel/python/sgl_kernel/gemm.py:84-95).  A column-major scale
+    tensor (stride(0) == 1 with more than one row) is written through its strides."""
+    _need_gpu(x, out_q, out_s)
+    if not (x.is_contiguous() and out_q.is_contiguous()):
+        raise SglkError("per_token_group_quant_fp8: input and output_q must be contiguous")
+    if out_q.dtype != torch.float8_e4m3fn or out_s.dtype != torch.float32:
+        raise SglkError("per_token_group_quant_fp8: output_q must be float8_e4m3fn and output_s float32")
+    hidden = x.shape[-1]
+    rows = x.numel() // hidden
+    ng = hidden // group_size
+    col_major = 0
+    if out_s.dim() == 2 and rows > 1 and ng > 1 and out_s.stride(0) == 1 and out_s.stride(1) == rows:
+        col_major = 1
+    elif not out_s.is_contiguous():
+        raise SglkError("per_token_group_quant_fp8: output_s must be row-major or exactly column-major")
+    check(lib().sglk_per_token_group_quant_fp8(_ptr(x), _ptr(out_q), _ptr(out_s), rows, hidden, group_size, eps,
+                                               fp8_min, fp8_max, col_major, dtype_code(x.dtype), _stream(x)),
+          "per_token_group_quant_fp8")
+
+
+def per_tensor_quant_fp8(x, out_q, out_s, is_static):
+    """sgl_per_tensor_quant_fp8 (sgl-kernel/python/sgl_kernel/gemm.py:119-128); for the dynamic form output_s
+    must hold 0 on entry (the kernel takes a running maximum into it)."""
+    _need_gpu(x, out_q, out_s)
+    if not (x.is_contiguous() and out_q.is_contiguous()):
+        raise SglkError("per_tensor_quant_fp8: tensors must be contiguous")
+    check(lib().sglk_per_tensor_quant_fp8(_ptr(x), _ptr(out_q), _ptr(out_s), x.numel(), 1 if is_static else 0,
+                                          dtype_code(x.dtype), _stream(x)), "per_tensor_quant_fp8")
+
+
+def _b_as_nk(mat_b, name):
+    """The reference passes B as a column-major [K, N] view (mat_b.stride(0) == 1): the same memory as a
+    row-major [N, K] matrix."""
+    if mat_b.dim() != 2 or mat_b.stride(0) != 1:
+        raise SglkError(f"{name}: mat_b must be a column-major [K, N] tensor")
+    return mat_b.t()
+
+
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
+    """fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias) (sgl-kernel/python/sgl_kernel/gemm.py:48-57)."""
+    _need_gpu(mat_a, mat_b, scales_a, scales_b)
+    if mat_a.dim() != 2 or mat_a.stride(1) != 1:
+        raise SglkError("fp8_scaled_mm: mat_a must be a row-major 2-D tensor")
+    b = _b_as_nk(mat_b, "fp8_scaled_mm")
+    M, K = mat_a.shape
+    N = b.shape[0]
+    if b.shape[1] != K:
+        raise SglkError(f"fp8_scaled_mm: inner dimensions differ ({K} vs {b.shape[1]})")
+    if scales_a.numel() != M or scales_b.numel() != N:
+        raise SglkError("fp8_scaled_mm: scales_a must have M and scales_b N elements")
+    if bias is not None and (bias.numel() != N or bias.dtype != out_dtype):
+        raise SglkError("fp8_scaled_mm: bias must have N elements of the output dtype")
+    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    check(lib().sglk_fp8_scaled_mm(_ptr(mat_a), _ptr(b), _ptr(scales_a.contiguous()), _ptr(scales_b.contiguous()),
+                                   _ptr(bias), _ptr(out), M, N, K, mat_a.stride(0), b.stride(0), out.stride(0),
+                                   dtype_code(out_dtype), _stream(mat_a)), "fp8_scaled_mm")
+    return out
+
+
+def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
+    """fp8_blockwise_scaled_mm (sgl-kernel/python/sgl_kernel/gemm.py:36-45): scales_a [M, K/128] (any strides),
+    scales_b [K/128, N/128] as the reference passes it (the transpose of the [N/128, K/128] checkpoint tensor)."""
+    _need_gpu(mat_a, mat_b, scales_a, scales_b)
+    if mat_a.dim() != 2 or not mat_a.is_contiguous():
+        raise SglkError("fp8_blockwise_scaled_mm: mat_a must be a contiguous 2-D tensor")
+    b = _b_as_nk(mat_b, "fp8_blockwise_scaled_mm")
+    if not b.is_contiguous():
+        raise SglkError("fp8_blockwise_scaled_mm: mat_b must be dense")
+    M, K = mat_a.shape
+    N = b.shape[0]
+    kb = (K + 127) // 128
+    nb = (N + 127) // 128
+    if tuple(scales_a.shape) != (M, kb) or tuple(scales_b.shape) != (kb, nb):
+        raise SglkError(f"fp8_blockwise_scaled_mm: scales_a must be [{M},{kb}] and scales_b [{kb},{nb}]")
+    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    check(lib().sglk_fp8_blockwise_scaled_mm(_ptr(mat_a), _ptr(b), _ptr(scales_a), _ptr(scales_b), _ptr(out), M, N, K,
+                                             scales_a.stride(0), scales_a.stride(1), scales_b.stride(1),
+                                             scales_b.stride(0), dtype_code(out_dtype), _stream(mat_a)),
+          "fp8_blockwise_scaled_mm")
+    return out

@@ -1,0 +1,185 @@
+"""GPU parity for the fp8 (e4m3fn) path through the C ABI: activation quantisation (bit-exact codes and scales
+against the C oracle) and the two scaled matmuls (fp32-accumulated; tolerance rtol 2e-2 as in
+sgl-kernel/tests/test_fp8_gemm.py:45 and test_fp8_blockwise_gemm.py:86 (rtol 0.02 on the relative mean error))."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+F8 = torch.float8_e4m3fn
+
+
+def _ops():
+    from sglang_security_amd import ops
+
+    return ops
+
+
+def _u8(t):
+    return t.cpu().view(torch.uint8)
+
+
+def test_hw_cast_matches_oracle_codec():
+    """Every e4m3 rounding boundary: the device conversion (scale 1 row: absmax == 448) equals the oracle codec."""
+    import oracle
+
+    ops = _ops()
+    x = torch.cat([torch.linspace(-448, 448, 8192 * 4 - 2), torch.tensor([448.0, -448.0])]).reshape(1, -1)
+    x = torch.cat([x, x * 0.001, torch.randn(1, x.shape[1]).clamp(-3.9, 3.9) * 100])
+    x[1, 0], x[2, 0] = 448.0, 448.0  # scale == 1 in every row
+    q = torch.empty(x.shape, dtype=F8, device=DEV)
+    s = torch.empty(x.shape[0], 1, dtype=torch.float32, device=DEV)
+    ops.per_token_quant_fp8(x.to(DEV), q, s)
+    assert torch.equal(s.cpu().reshape(-1), torch.ones(3))
+    assert torch.equal(_u8(q), oracle.e4m3_encode(x).view(torch.uint8))
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 128), (7, 4096), (64, 14336), (33, 1368), (5, 100), (128, 8192)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_per_token_quant_bitexact(rows, hidden, dtype):
+    import oracle
+
+    ops = _ops()
+    torch.manual_seed(rows * 31 + hidden)
+    x = (torch.randn(rows, hidden) * 3).to(dtype)
+    wq, ws = oracle.per_token_quant_fp8(x)
+    q = torch.empty(rows, hidden, dtype=F8, device=DEV)
+    s = torch.empty(rows, 1, dtype=torch.float32, device=DEV)
+    ops.per_token_quant_fp8(x.to(DEV), q, s)
+    assert torch.equal(s.cpu(), ws)
+    assert torch.equal(_u8(q), wq.view(torch.uint8))
+
+
+def test_per_token_quant_golden(golden):
+    """Fixture minted from the reference formula (sgl-kernel/tests/test_per_token_quant_fp8.py:15-27)."""
+    ops = _ops()
+    g = golden("fp8_per_token_quant")
+    x = g["x"]
+    q = torch.empty(x.shape, dtype=F8, device=DEV)
+    s = torch.empty(x.shape[0], 1, dtype=torch.float32, device=DEV)
+    ops.per_token_quant_fp8(x.to(DEV), q, s)
+    torch.testing.assert_close(s.cpu().reshape(-1), g["expect_scale"], rtol=1e-6, atol=0)
+    torch.testing.assert_close(q.cpu().float(), g["expect_q"].float(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("rows,hidden,group", [(1, 128, 128), (16, 7168, 128), (33, 4096, 64), (5, 512, 32),
+                                                (3, 96, 16), (64, 2048, 256), (7, 1536, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("col_major", [False, True])
+def test_per_token_group_quant_bitexact(rows, hidden, group, dtype, col_major):
+    import oracle
+
+    ops = _ops()
+    torch.manual_seed(rows + hidden + group)
+    x = (torch.randn(rows, hidden) * 2).to(dtype)
+    x[0, :group] = 0  # an all-zero group exercises eps
+    wq, ws = oracle.per_token_group_quant_fp8(x, group, 1e-10, -448.0, 448.0)
+    q = torch.empty(rows, hidden, dtype=F8, device=DEV)
+    ng = hidden // group
+    if col_major:
+        s = torch.empty(ng, rows, dtype=torch.float32, device=DEV).t()
+    else:
+        s = torch.empty(rows, ng, dtype=torch.float32, device=DEV)
+    ops.per_token_group_quant_fp8(x.to(DEV), q, s, group, 1e-10, -448.0, 448.0)
+    assert torch.equal(s.cpu(), ws)
+    assert torch.equal(_u8(q), wq.view(torch.uint8))
+
+
+@pytest.mark.parametrize("n", [1, 1000, 256 * 1024 + 3])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_per_tensor_quant(n, dtype):
+    """sgl-kernel/tests/test_per_tensor_quant_fp8.py: dynamic scale = absmax / 448; static uses the given scale."""
+    import oracle
+
+    ops = _ops()
+    torch.manual_seed(n)
+    x = (torch.randn(n) * 5).to(dtype)
+    scale = x.float().abs().max() / 448.0
+    want = oracle.e4m3_encode((x.float() * (1.0 / scale)).clamp(-448, 448)).view(torch.uint8)
+    q = torch.empty(n, dtype=F8, device=DEV)
+    s = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.per_tensor_quant_fp8(x.to(DEV), q, s, False)
+    assert s.cpu().item() == scale.item()
+    assert torch.equal(_u8(q), want)
+    q2 = torch.empty(n, dtype=F8, device=DEV)
+    s2 = torch.tensor([0.0625], device=DEV)
+    ops.per_tensor_quant_fp8(x.to(DEV), q2, s2, True)
+    assert torch.equal(_u8(q2), oracle.e4m3_encode((x.float() * 16.0).clamp(-448, 448)).view(torch.uint8))
+
+
+def _fp8_rand(shape, g):
+    return (torch.randn(shape, generator=g) * 0.5).clamp(-448, 448).to(F8)
+
+
+@pytest.mark.parametrize("name", ["fp8_mm_bf16", "fp8_mm_f16"])
+def test_fp8_scaled_mm_golden(golden, name):
+    ops = _ops()
+    g = golden(name)
+    bias = g.get("bias")
+    out = ops.fp8_scaled_mm(g["a"].to(DEV), g["b_nk"].to(DEV).t(), g["scale_a"].to(DEV), g["scale_b"].to(DEV),
+                            g["expect"].dtype, None if bias is None else bias.to(DEV))
+    torch.testing.assert_close(out.cpu().float(), g["expect"].float(), rtol=0.02, atol=1)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 128), (16, 2048, 4096), (17, 512, 1040), (33, 128, 512), (100, 4096, 1024),
+                                   (512, 1024, 2048), (3, 16, 16)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_fp8_scaled_mm_vs_oracle(M, N, K, out_dtype, with_bias):
+    """Shapes after sgl-kernel/tests/test_fp8_gemm.py:49-56 (M 1..8192, N, K up to 16384), incl. K not a multiple
+    of 128 and M not a multiple of 16."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    a, b_nk = _fp8_rand((M, K), g), _fp8_rand((N, K), g)
+    sa, sb = torch.rand(M, 1, generator=g) * 0.1, torch.rand(N, 1, generator=g) * 0.1
+    bias = torch.randn(N, generator=g).to(out_dtype) if with_bias else None
+    want = oracle.fp8_scaled_mm(a, b_nk.t(), sa, sb, out_dtype, bias)
+    out = ops.fp8_scaled_mm(a.to(DEV), b_nk.to(DEV).t(), sa.to(DEV), sb.to(DEV), out_dtype,
+                            None if bias is None else bias.to(DEV))
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_fp8_scaled_mm_rejects_bad_shapes():
+    ops = _ops()
+    from sglang_security_amd._lib import SglkError
+
+    a = torch.zeros(4, 24, dtype=F8, device=DEV)  # K % 16 != 0
+    b = torch.zeros(32, 24, dtype=F8, device=DEV)
+    s = torch.ones(32, device=DEV)
+    with pytest.raises(SglkError):
+        ops.fp8_scaled_mm(a, b.t(), s[:4], s, torch.bfloat16)
+    with pytest.raises(SglkError):  # row-major B
+        ops.fp8_scaled_mm(torch.zeros(4, 32, dtype=F8, device=DEV), torch.zeros(32, 32, dtype=F8, device=DEV), s[:4], s,
+                          torch.bfloat16)
+
+
+def test_fp8_blockwise_golden(golden):
+    ops = _ops()
+    g = golden("fp8_block_mm")
+    out = ops.fp8_blockwise_scaled_mm(g["a"].to(DEV), g["b_nk"].to(DEV).t(), g["scale_a"].to(DEV),
+                                      g["scale_b_kn"].to(DEV), torch.bfloat16)
+    torch.testing.assert_close(out.cpu().float(), g["expect"].float(), rtol=0.02, atol=1)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 128, 128), (16, 512, 7168), (100, 1536, 1024), (64, 2112, 512), (257, 256, 384)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("a_col_major", [False, True])
+def test_fp8_blockwise_vs_oracle(M, N, K, out_dtype, a_col_major):
+    """sgl-kernel/tests/test_fp8_blockwise_gemm.py:62-90: scale_a column-major (M-contiguous) as the reference
+    passes it, scale_b [K/128, N/128]; N need not be a multiple of 128 (2112 = 16.5 blocks)."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b_nk = _fp8_rand((M, K), g), _fp8_rand((N, K), g)
+    kb, nb = K // 128, (N + 127) // 128
+    sa = torch.rand(M, kb, generator=g) * 0.2 + 0.01
+    sb_nk = torch.rand(nb, kb, generator=g) * 0.2 + 0.01
+    want = oracle.fp8_blockwise_mm(a, b_nk, sa, sb_nk, out_dtype)
+    sa_d = sa.to(DEV)
+    if a_col_major:
+        sa_d = sa_d.t().contiguous().t()
+    out = ops.fp8_blockwise_scaled_mm(a.to(DEV), b_nk.to(DEV).t(), sa_d, sb_nk.to(DEV).t(), out_dtype)
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
