@@ -83,9 +83,7 @@ _SIGS = {
 }
 
 
-_PENDING = {n for n in _SIGS if n.startswith(("sglk_ar_", "sglk_ipc_",
-                                              "sglk_alloc_", "sglk_free_", "sglk_extend_", "sglk_decode_shared",
-                                              "sglk_decode_attention_shared"))}
+_PENDING = {n for n in _SIGS if n.startswith(("sglk_ar_", "sglk_ipc_", "sglk_alloc_", "sglk_free_"))}
 
 
 class SglkError(RuntimeError):

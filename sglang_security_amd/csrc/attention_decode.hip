@@ -17,6 +17,7 @@
 // Everything else (fp32, odd head sizes, MLA 576/512) takes the generic wave-per-(request, head,
 // split) kernel.  Partials are merged by log-sum-exp in a second kernel, as in the reference
 // (triton_ops/decode_attention.py:497-557).
+#include "attention_tile.h"
 #include "common.h"
 
 namespace sglk {
@@ -261,47 +262,24 @@ __global__ void __launch_bounds__(128) decode_stage2(const float* __restrict__ a
 // ---------------------------------------------------------------------------------------------
 // fast path: D = Dv = 128, 16-bit types, matrix cores, wave-private LDS tiles
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-struct Mfma16;
-template <>
-struct Mfma16<bf16_t> {
-  using frag = bfloat8;
-  static __device__ __forceinline__ float4v mma(short8 a, short8 b, float4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfloat8, a), __builtin_bit_cast(bfloat8, b), c, 0,
-                                                   0, 0);
-  }
-};
-template <>
-struct Mfma16<f16_t> {
-  using frag = half8;
-  static __device__ __forceinline__ float4v mma(short8 a, short8 b, float4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0,
-                                                  0);
-  }
-};
-
-typedef __attribute__((address_space(3))) short4v* lds_short4_ptr;
-
-__device__ __forceinline__ short4v lds_read_tr16(const char* p) {
-  // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered
-  // column-major (lane i of the group receives column i of the four rows).  EXEC must be full.
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(p));
-}
-
-static constexpr int kTile = 32;                 // tokens per tile
-static constexpr int kRowBytes = 256;            // 128 x 16-bit
-static constexpr int kTileBytes = kTile * kRowBytes;  // 8 KiB each for K and V
 static constexpr int kWavesPerBlock = 4;
 static constexpr int kLdsPerWave = 2 * kTileBytes;  // K tile + V tile
 
-// K tile: 16-byte chunk c of row r sits at chunk slot c ^ (r & 15): the row reads of one MFMA
-// operand (16 rows, same chunk) then fall on 16 different slots of the 256-byte bank row.
-__device__ __forceinline__ int k_off(int r, int c) { return r * kRowBytes + ((c ^ (r & 15)) << 4); }
-// V tile: 32-byte granule g of row r sits at granule slot g ^ (r & 7): the transposed reads of one
-// 32-lane half (8 rows, same granule) fall on 8 different 32-byte slots.
-__device__ __forceinline__ int v_off(int r, int byte_in_row) {
-  const int g = byte_in_row >> 5;
-  return r * kRowBytes + (((g ^ (r & 7)) << 5) | (byte_in_row & 31));
+// group g with group_indptr[g] <= b < group_indptr[g + 1]
+__device__ __forceinline__ int find_group(const int32_t* __restrict__ group_indptr, int num_groups, int b) {
+  int lo = 0, hi = num_groups - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (group_indptr[mid] <= b)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  return lo;
+}
+// split count of the per-request remainder in the shared-prefix path: about 128 tokens per split
+__device__ __forceinline__ int tail_splits(int len, int max_splits) {
+  return min(max(cdiv_i(len, 128), 1), max_splits);
 }
 
 template <typename T>
@@ -310,7 +288,8 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
     float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv,
     int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-    int64_t v_stride_h, float sm_scale, float logit_cap) {
+    int64_t v_stride_h, float sm_scale, float logit_cap, const int32_t* __restrict__ group_indptr,
+    const int32_t* __restrict__ prefix_lens, int num_groups, int split_offset, int total_splits) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -321,9 +300,18 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   const int kvh = blockIdx.y / head_tiles, ht = blockIdx.y - kvh * head_tiles;
   const int split = blockIdx.z * kWavesPerBlock + wid;
   const int group = Hq / Hkv;
-  const int start = kv_indptr[b];
-  const int len = kv_indptr[b + 1] - start;
-  const int splits = max(num_kv_splits[b], 1);
+  int start = kv_indptr[b];
+  int len = kv_indptr[b + 1] - start;
+  int splits;
+  if (group_indptr) {
+    // remainder mode: the first prefix_lens[group of b] tokens are handled elsewhere
+    const int skip = prefix_lens[find_group(group_indptr, num_groups, b)];
+    start += skip;
+    len -= skip;
+    splits = tail_splits(len, max_kv_splits);
+  } else {
+    splits = max(num_kv_splits[b], 1);
+  }
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
   const int s0 = per_split * split, s1 = min(s0 + per_split, len);
   // wave-uniform exit; no block-level synchronisation is used below
@@ -446,7 +434,7 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   lsum += __shfl_xor(lsum, 32, 64);
   if (head_ok) {
     const float inv = 1.0f / lsum;
-    const int64_t ob = ((int64_t)b * Hq + head) * max_kv_splits + split;
+    const int64_t ob = ((int64_t)b * Hq + head) * total_splits + split_offset + split;
     float* dst = attn_logits + ob * 128;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -455,6 +443,97 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     }
     if (g == 0) attn_lse[ob] = (m + log2f(lsum)) * 0.6931471805599453f;
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// shared-prefix decode: the prefix of a group is streamed once per (kv head, split, 128 columns)
+// and multiplied against every (request, head) column of the group
+// ---------------------------------------------------------------------------------------------
+static constexpr int kGroupNC = 2;
+static constexpr int kGroupCols = 64 * kGroupNC;  // columns per block
+
+template <typename T>
+__global__ void __launch_bounds__(256) decode_group_prefix_kernel(
+    const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
+    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
+    const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, float* __restrict__ part_o,
+    float* __restrict__ part_lse, int prefix_splits, int total_splits, int Hq, int Hkv, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
+    float logit_cap) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int grp = blockIdx.z / prefix_splits, split = blockIdx.z - grp * prefix_splits;
+  const int kvh = blockIdx.y;
+  const int gstart = group_indptr[grp];
+  const int gsize = group_indptr[grp + 1] - gstart;
+  const int heads = Hq / Hkv;
+  const int col0 = blockIdx.x * kGroupCols;
+  const int plen = prefix_lens[grp];
+  const int per_split = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+  const int t0 = per_split * split, t1 = min(t0 + per_split, plen);
+  if (col0 >= gsize * heads || t1 <= t0) return;  // block-uniform
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hl = lane & 15, g = lane >> 4;
+
+  BlockAttn<T, kGroupNC> st;
+  st.init();
+  int qpos[kGroupNC];
+  int req[kGroupNC], head[kGroupNC];
+#pragma unroll
+  for (int c = 0; c < kGroupNC; ++c) {
+    const int col = col0 + (wid * kGroupNC + c) * 16 + hl;
+    const bool ok = col < gsize * heads;
+    req[c] = ok ? gstart + col / heads : -1;
+    head[c] = kvh * heads + col % heads;
+    qpos[c] = 0;
+    st.load_q(c, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req[c] * q_stride_b + (int64_t)head[c] * q_stride_h
+                    : nullptr);
+  }
+  // every request of the group lists the same slots for the prefix: walk the first request's list
+  st.template run<false, true>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+                               reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
+                               v_stride_n, kv_indices + kv_indptr[gstart], t0, t1, qpos, 0, sm_scale, logit_cap);
+#pragma unroll
+  for (int c = 0; c < kGroupNC; ++c) {
+    const float tot = st.total(c);
+    if (req[c] < 0) continue;
+    const float inv = 1.0f / tot;
+    const int64_t ob = ((int64_t)req[c] * Hq + head[c]) * total_splits + split;
+    float* dst = part_o + ob * 128;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = st.oacc[c][n] * inv;
+    if (g == 0) part_lse[ob] = (st.m[c] + log2f(tot)) * 0.6931471805599453f;
+  }
+}
+
+// LSE merge of the prefix splits and the per-request remainder splits
+template <typename T>
+__global__ void __launch_bounds__(128) decode_group_merge_kernel(
+    const float* __restrict__ part_o, const float* __restrict__ part_lse, void* __restrict__ o,
+    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ group_indptr,
+    const int32_t* __restrict__ prefix_lens, int num_groups, int prefix_splits, int tail_max_splits, int Hq,
+    int64_t o_stride_b, int64_t o_stride_h) {
+  const int b = blockIdx.x, h = blockIdx.y;
+  const int plen = prefix_lens[find_group(group_indptr, num_groups, b)];
+  const int tlen = kv_indptr[b + 1] - kv_indptr[b] - plen;
+  const int per_p = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+  const int per_t = cdiv_i(cdiv_i(tlen, tail_splits(tlen, tail_max_splits)), kMinBlockKV) * kMinBlockKV;
+  const int total_splits = prefix_splits + tail_max_splits;
+  const int64_t base = ((int64_t)b * Hq + h) * total_splits;
+  const int d = threadIdx.x;
+  float e_sum = 0.f, e_max = -INFINITY, acc = 0.f;
+  for (int s = 0; s < total_splits; ++s) {
+    const bool live = s < prefix_splits ? (per_p * s < plen) : (per_t * (s - prefix_splits) < tlen);
+    if (!live) continue;
+    const float tv = part_o[(base + s) * 128 + d];
+    const float tl = part_lse[base + s];
+    const float n_max = fmaxf(tl, e_max);
+    const float old = expf(e_max - n_max), w = expf(tl - n_max);
+    acc = acc * old + w * tv;
+    e_sum = e_sum * old + w;
+    e_max = n_max;
+  }
+  st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d, acc / e_sum);
 }
 
 }  // namespace sglk
@@ -546,7 +625,8 @@ int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buf
                        hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
                                           k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse,
                                           num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h,
-                                          k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap));
+                                          k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap,
+                                          (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, max_kv_splits));
   } else {
     dim3 grid(B, Hq, max_kv_splits);
     const size_t lds = (size_t)D * sizeof(float);
@@ -574,6 +654,66 @@ int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buf
   SGLK_DISPATCH_FLOAT(dtype, T,
                       hipLaunchKernelGGL((decode_stage2<T>), dim3(B, Hq), dim3(128), 0, s, attn_logits, attn_lse, o,
                                          kv_indptr, num_kv_splits, max_kv_splits, Hq, Dv, o_stride_b, o_stride_h));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+static constexpr int kTailMaxSplits = 4;  // remainder splits per request (one block of four waves)
+
+int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits) {
+  if (B <= 0 || Hq <= 0 || Dv <= 0 || max_kv_splits <= 0) return 0;
+  return (int64_t)B * Hq * (max_kv_splits + kTailMaxSplits) * (Dv + 1) * (int64_t)sizeof(float);
+}
+
+int sglk_decode_attention_shared_prefix(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                        const int32_t* kv_indptr, const int32_t* kv_indices,
+                                        const int32_t* group_indptr, const int32_t* prefix_lens, int G, float* workspace,
+                                        int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+                                        int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                        int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+                                        float logit_cap, int dtype, void* stream) {
+  SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
+             "decode_attention_shared_prefix: null pointer");
+  SGLK_CHECK(B >= 0 && G > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
+  SGLK_CHECK(max_kv_splits > 0, "decode_attention_shared_prefix: max_kv_splits must be positive");
+  if (B == 0) return SGLK_OK;
+  auto mult8 = [](int64_t v) { return v % 8 == 0; };
+  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
+                    aligned16(k_buffer) && aligned16(v_buffer) && aligned16(workspace) && mult8(q_stride_b) &&
+                    mult8(q_stride_h) && mult8(k_stride_n) && mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h);
+  if (!fast)
+    return fail(SGLK_EUNSUP, "decode_attention_shared_prefix: only 16-bit types with head size 128 (got D=%d Dv=%d dtype=%d)",
+                D, Dv, dtype);
+  hipStream_t s = (hipStream_t)stream;
+  const int heads = Hq / Hkv;
+  const int total_splits = max_kv_splits + kTailMaxSplits;
+  float* part_o = workspace;
+  float* part_lse = workspace + (int64_t)B * Hq * total_splits * 128;
+  {
+    dim3 grid((B * heads + kGroupCols - 1) / kGroupCols, Hkv, G * max_kv_splits);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((decode_group_prefix_kernel<T>), grid, dim3(256), kBlockAttnLds, s, q, k_buffer,
+                                          v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, part_o, part_lse,
+                                          max_kv_splits, total_splits, Hq, Hkv, q_stride_b, q_stride_h, k_stride_n,
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap));
+    SGLK_LAUNCH_CHECK();
+  }
+  {
+    const int head_tiles = (heads + 15) / 16;
+    dim3 grid(B, Hkv * head_tiles, 1);
+    const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
+                                          k_buffer, v_buffer, kv_indptr, kv_indices, part_o, part_lse,
+                                          (const int32_t*)nullptr, kTailMaxSplits, Hq, Hkv, head_tiles, q_stride_b,
+                                          q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap,
+                                          group_indptr, prefix_lens, G, max_kv_splits, total_splits));
+    SGLK_LAUNCH_CHECK();
+  }
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((decode_group_merge_kernel<T>), dim3(B, Hq), dim3(128), 0, s, part_o, part_lse, o,
+                                        kv_indptr, group_indptr, prefix_lens, G, max_kv_splits, kTailMaxSplits, Hq,
+                                        o_stride_b, o_stride_h));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

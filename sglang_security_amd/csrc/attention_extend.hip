@@ -1,0 +1,233 @@
+// Extend (prefill with a cached prefix) attention.
+//
+// Per sequence b: queries are the rows qo_indptr[b] .. qo_indptr[b+1] of q_extend; they see the cached prefix
+// (pool rows kv_indices[kv_indptr[b] .. kv_indptr[b+1]) of k_buffer / v_buffer, unmasked) and then the new
+// tokens themselves (the same rows of k_extend / v_extend, under the causal mask).  One online softmax
+// runs over both ranges (triton_ops/extend_attention.py:306-438 does the same in two loops).
+//
+// Fast path (16-bit, D = Dv = 128): one block per (sequence, query head, 64*NC query rows); the four waves
+// share every 32-token K/V tile through LDS and each multiplies it against NC tiles of 16 query rows on
+// the matrix cores.  Everything else takes a wave-per-(query row, head) kernel.
+#include "attention_tile.h"
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+constexpr int kNC = 2;
+
+template <typename T, int NC>
+__global__ void __launch_bounds__(256) extend_attention_mfma128(
+    const void* __restrict__ q_extend, const void* __restrict__ k_extend, const void* __restrict__ v_extend,
+    void* __restrict__ o_extend, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
+    const int32_t* __restrict__ qo_indptr, const int32_t* __restrict__ kv_indptr,
+    const int32_t* __restrict__ kv_indices, int Hq, int Hkv, int64_t q_stride_t, int64_t q_stride_h,
+    int64_t ke_stride_t, int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
+    int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
+    float logit_cap, int causal) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = qo_indptr[b];
+  const int ext_len = qo_indptr[b + 1] - q0;
+  const int block_q0 = blockIdx.x * 64 * NC;
+  if (block_q0 >= ext_len) return;  // block-uniform
+  const int pstart = kv_indptr[b];
+  const int plen = kv_indptr[b + 1] - pstart;
+  const int kvh = h / (Hq / Hkv);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hl = lane & 15, g = lane >> 4;
+
+  BlockAttn<T, NC> st;
+  st.init();
+  int qpos[NC];
+  bool col_ok[NC];
+  int wave_qmax = 0;
+  const uint16_t* qb = reinterpret_cast<const uint16_t*>(q_extend) + (int64_t)h * q_stride_h;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int tile = c * 4 + wid;  // interleaved so that every wave gets early and late rows
+    const int row = block_q0 + tile * 16 + hl;
+    col_ok[c] = row < ext_len;
+    qpos[c] = min(row, ext_len - 1);
+    wave_qmax = max(wave_qmax, min(block_q0 + tile * 16 + 15, ext_len - 1));
+    st.load_q(c, qb + (int64_t)(q0 + qpos[c]) * q_stride_t);
+  }
+
+  if (plen > 0) {
+    st.template run<false, true>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+                                 reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
+                                 v_stride_n, kv_indices + pstart, 0, plen, qpos, wave_qmax, sm_scale, logit_cap);
+  }
+  const uint16_t* ke = reinterpret_cast<const uint16_t*>(k_extend) + (int64_t)q0 * ke_stride_t + (int64_t)kvh * ke_stride_h;
+  const uint16_t* ve = reinterpret_cast<const uint16_t*>(v_extend) + (int64_t)q0 * ve_stride_t + (int64_t)kvh * ve_stride_h;
+  if (causal) {
+    const int t_end = min(ext_len, block_q0 + 64 * NC);
+    st.template run<true, false>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, t_end, qpos, wave_qmax, sm_scale,
+                                 logit_cap);
+  } else {
+    st.template run<false, false>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, ext_len, qpos, wave_qmax, sm_scale,
+                                  logit_cap);
+  }
+
+  uint16_t* ob = reinterpret_cast<uint16_t*>(o_extend) + (int64_t)h * o_stride_h;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float inv = 1.0f / st.total(c);
+    if (!col_ok[c]) continue;
+    uint16_t* dst = ob + (int64_t)(q0 + qpos[c]) * o_stride_t;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      // lane (hl, g) holds O[row hl][16n + 4g + r], r = 0..3
+      short4v pk;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pk[r] = (short)Conv<T>::from_f32(st.oacc[c][n][r] * inv);
+      *reinterpret_cast<short4v*>(dst + 16 * n + 4 * g) = pk;
+    }
+  }
+}
+
+// one wave per (query row, head): any head size, any float type
+template <typename T, int DV_PER_LANE>
+__global__ void __launch_bounds__(64) extend_attention_generic(
+    const void* __restrict__ q_extend, const void* __restrict__ k_extend, const void* __restrict__ v_extend,
+    void* __restrict__ o_extend, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
+    const int32_t* __restrict__ qo_indptr, const int32_t* __restrict__ kv_indptr,
+    const int32_t* __restrict__ kv_indices, int Hq, int Hkv, int D, int Dv, int64_t q_stride_t, int64_t q_stride_h,
+    int64_t ke_stride_t, int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
+    int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
+    float logit_cap, int causal) {
+  extern __shared__ float qs[];  // D floats
+  const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x;
+  const int q0 = qo_indptr[b];
+  const int ext_len = qo_indptr[b + 1] - q0;
+  if (qi >= ext_len) return;
+  const int pstart = kv_indptr[b];
+  const int plen = kv_indptr[b + 1] - pstart;
+  const int kvh = h / (Hq / Hkv);
+  const int lane = threadIdx.x;
+  for (int d = lane; d < D; d += 64) qs[d] = ld<T>(q_extend, (int64_t)(q0 + qi) * q_stride_t + (int64_t)h * q_stride_h + d);
+  __syncthreads();
+  const int vis = causal ? qi + 1 : ext_len;  // visible new tokens
+  const int total = plen + vis;
+  float m = -INFINITY, l = 0.f;
+  float acc[DV_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < DV_PER_LANE; ++i) acc[i] = 0.f;
+  for (int t0 = 0; t0 < total; t0 += 64) {
+    const int tok = t0 + lane;
+    const bool valid = tok < total;
+    // where this lane's token lives
+    const bool in_prefix = tok < plen;
+    const void* kp = in_prefix ? k_buffer : k_extend;
+    const void* vp = in_prefix ? v_buffer : v_extend;
+    int64_t kb = 0, vb = 0;
+    if (valid) {
+      if (in_prefix) {
+        const int64_t loc = kv_indices[pstart + tok];
+        kb = loc * k_stride_n + (int64_t)kvh * k_stride_h;
+        vb = loc * v_stride_n + (int64_t)kvh * v_stride_h;
+      } else {
+        const int64_t r = q0 + (tok - plen);
+        kb = r * ke_stride_t + (int64_t)kvh * ke_stride_h;
+        vb = r * ve_stride_t + (int64_t)kvh * ve_stride_h;
+      }
+    }
+    float s = -INFINITY;
+    if (valid) {
+      s = 0.f;
+      for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(kp, kb + d);
+      s *= sm_scale;
+      if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
+    }
+    const float m_new = fmaxf(m, wave_max(s));
+    const float alpha = expf(m - m_new);
+    const float p = valid ? expf(s - m_new) : 0.f;
+    l = l * alpha + wave_sum(p);
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < DV_PER_LANE; ++i) acc[i] *= alpha;
+    const int cnt = min(64, total - t0);
+    for (int j = 0; j < cnt; ++j) {
+      const float pj = __shfl(p, j, 64);
+      const int64_t vj = __shfl((long long)vb, j, 64);
+      const void* vsrc = (t0 + j) < plen ? v_buffer : v_extend;
+#pragma unroll
+      for (int i = 0; i < DV_PER_LANE; ++i) {
+        const int d = lane + 64 * i;
+        if (d < Dv) acc[i] += pj * ld<T>(vsrc, vj + d);
+      }
+    }
+    (void)vp;
+  }
+#pragma unroll
+  for (int i = 0; i < DV_PER_LANE; ++i) {
+    const int d = lane + 64 * i;
+    if (d < Dv) st<T>(o_extend, (int64_t)(q0 + qi) * o_stride_t + (int64_t)h * o_stride_h + d, acc[i] / l);
+  }
+}
+
+}  // namespace
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" int sglk_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+                                     const void* k_buffer, const void* v_buffer, const int32_t* qo_indptr,
+                                     const int32_t* kv_indptr, const int32_t* kv_indices, int B, int Hq, int Hkv, int D,
+                                     int Dv, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                     int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
+                                     int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                     int64_t v_stride_h, int max_extend_len, float sm_scale, float logit_cap, int causal,
+                                     int dtype, void* stream) {
+  SGLK_CHECK(q_extend && k_extend && v_extend && o_extend && qo_indptr && kv_indptr, "extend_attention: null pointer");
+  SGLK_CHECK(B >= 0 && Hq > 0 && Hkv > 0 && D > 0 && Dv > 0, "extend_attention: bad shape");
+  SGLK_CHECK(Hq % Hkv == 0, "extend_attention: Hq %d not a multiple of Hkv %d", Hq, Hkv);
+  SGLK_CHECK(Dv <= 1024 && D <= 4096, "extend_attention: head size too large");
+  SGLK_CHECK(max_extend_len >= 0, "extend_attention: negative max_extend_len");
+  if (B == 0 || max_extend_len == 0) return SGLK_OK;
+  // a batch without any cached prefix may pass no pool at all
+  if (!k_buffer) k_buffer = k_extend;
+  if (!v_buffer) v_buffer = v_extend;
+  hipStream_t s = (hipStream_t)stream;
+  auto mult8 = [](int64_t v) { return v % 8 == 0; };
+  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
+                    aligned16(k_extend) && aligned16(v_extend) && aligned16(k_buffer) && aligned16(v_buffer) &&
+                    ((uintptr_t)o_extend % 8 == 0) && mult8(q_stride_t) && mult8(q_stride_h) && mult8(ke_stride_t) &&
+                    mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && mult8(k_stride_n) &&
+                    mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h) && o_stride_t % 4 == 0 &&
+                    o_stride_h % 4 == 0;
+  if (fast) {
+    dim3 grid((max_extend_len + 64 * kNC - 1) / (64 * kNC), Hq, B);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((extend_attention_mfma128<T, kNC>), grid, dim3(256), kBlockAttnLds, s,
+                                          q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                                          kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h, ke_stride_t,
+                                          ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal));
+  } else {
+    dim3 grid(max_extend_len, Hq, B);
+    const size_t lds = (size_t)D * sizeof(float);
+    const int per_lane = (Dv + 63) / 64;
+#define SGLK_GEN(N)                                                                                                   \
+  hipLaunchKernelGGL((extend_attention_generic<T, N>), grid, dim3(64), lds, s, q_extend, k_extend, v_extend, o_extend, \
+                     k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, D, Dv, q_stride_t, q_stride_h,     \
+                     ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,           \
+                     k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal)
+    SGLK_DISPATCH_FLOAT(dtype, T, {
+      if (per_lane <= 1) {
+        SGLK_GEN(1);
+      } else if (per_lane <= 2) {
+        SGLK_GEN(2);
+      } else if (per_lane <= 4) {
+        SGLK_GEN(4);
+      } else if (per_lane <= 8) {
+        SGLK_GEN(8);
+      } else {
+        SGLK_GEN(16);
+      }
+    });
+#undef SGLK_GEN
+  }
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}

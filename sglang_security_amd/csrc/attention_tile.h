@@ -1,0 +1,197 @@
+// Matrix-core attention building blocks for head size 128 and 16-bit types (gfx950).
+//
+// Tiles of 32 KV tokens live in LDS as 32 rows x 256 bytes, XOR-swizzled so that both the row reads
+// of the K operand (ds_read_b128) and the transposed reads of the V operand (ds_read_b64_tr_b16)
+// spread over all banks.  Scores are produced transposed, S^T = K . Q^T, so that one 16-column
+// operand tile holds 16 independent query rows ("columns") and the score accumulators are, as they
+// stand, the P^T operand of O^T += V^T . P^T.
+#pragma once
+#include "common.h"
+
+namespace sglk {
+
+template <typename T>
+struct Mfma16;
+template <>
+struct Mfma16<bf16_t> {
+  static __device__ __forceinline__ float4v mma(short8 a, short8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfloat8, a), __builtin_bit_cast(bfloat8, b), c, 0,
+                                                   0, 0);
+  }
+};
+template <>
+struct Mfma16<f16_t> {
+  static __device__ __forceinline__ float4v mma(short8 a, short8 b, float4v c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0,
+                                                  0);
+  }
+};
+
+typedef __attribute__((address_space(3))) short4v* lds_short4_ptr;
+
+__device__ __forceinline__ short4v lds_read_tr16(const char* p) {
+  // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered
+  // column-major (lane i of the group receives column i of the four rows).  EXEC must be full.
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4_ptr)(p));
+}
+
+static constexpr int kTile = 32;                      // tokens per tile
+static constexpr int kRowBytes = 256;                 // 128 x 16-bit
+static constexpr int kTileBytes = kTile * kRowBytes;  // 8 KiB each for K and V
+
+// K tile: 16-byte chunk c of row r sits at chunk slot c ^ (r & 15): the row reads of one MFMA
+// operand (16 rows, same chunk) then fall on 16 different slots of the 256-byte bank row.
+__device__ __forceinline__ int k_off(int r, int c) { return r * kRowBytes + ((c ^ (r & 15)) << 4); }
+// V tile: 32-byte granule g of row r sits at granule slot g ^ (r & 7): the transposed reads of one
+// 32-lane half (8 rows, same granule) fall on 8 different 32-byte slots.
+__device__ __forceinline__ int v_off(int r, int byte_in_row) {
+  const int g = byte_in_row >> 5;
+  return r * kRowBytes + (((g ^ (r & 7)) << 5) | (byte_in_row & 31));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Block-cooperative streaming attention: the 4 waves of a 256-thread block share each K/V tile
+// (double-buffered in LDS, one barrier per tile) and every wave multiplies it against its own NC
+// column tiles of 16 query rows.  State is carried across run() calls, so a caller can stream a
+// gathered range (pool slots through an index list) and then a contiguous range under a causal
+// mask into the same accumulators.
+// ---------------------------------------------------------------------------------------------------
+static constexpr int kBlockAttnLds = 2 * 2 * kTileBytes;  // two stages of (K tile + V tile)
+
+template <typename T, int NC>
+struct BlockAttn {
+  float m[NC];      // running maximum per column (log2 domain), replicated over the four lane groups
+  float lsum[NC];   // this lane's share of the running sum
+  float4v oacc[NC][8];
+  short8 qf[NC][4];
+
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      m[c] = -INFINITY;
+      lsum[c] = 0.f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) oacc[c][n] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+
+  // Q^T operand of column tile c: this lane's column is the 128-element row at qrow (nullptr: zeros);
+  // lane (hl, g) keeps elements 32*ks + 8*g .. +8 for ks = 0..3.
+  __device__ __forceinline__ void load_q(int c, const uint16_t* qrow) {
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (qrow)
+        qf[c][ks] = *reinterpret_cast<const short8*>(qrow + 32 * ks + 8 * g);
+      else
+        qf[c][ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  // Stream tokens [t_begin, t_end) (block-uniform, non-empty).  GATHER: token t lives in pool row idx[t],
+  // else in row t of kbase/vbase.  CAUSAL: column tile c of this lane sees token t only if t <= qpos[c];
+  // wave_qmax is the largest qpos of the wave (tiles wholly above it are skipped by the wave).
+  template <bool CAUSAL, bool GATHER>
+  __device__ __forceinline__ void run(char* lds, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                      int64_t v_stride_n, const int32_t* idx, int t_begin, int t_end,
+                                      const int (&qpos)[NC], int wave_qmax, float sm_scale, float logit_cap) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int hl = lane & 15, g = lane >> 4;
+    const int frow = tid >> 4, chunk = tid & 15;  // this thread parks rows frow and frow + 16
+    const float LOG2E = 1.4426950408889634f;
+    const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+
+    int4v kreg[2], vreg[2];
+    auto fetch = [&](int t0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int tok = t0 + frow + 16 * i;
+        tok = tok < t_end ? tok : t_begin;  // rows past the end re-read a valid row; their scores are masked
+        const int64_t row = GATHER ? (int64_t)idx[tok] : (int64_t)tok;
+        kreg[i] = *reinterpret_cast<const int4v*>(kbase + row * k_stride_n + chunk * 8);
+        vreg[i] = *reinterpret_cast<const int4v*>(vbase + row * v_stride_n + chunk * 8);
+      }
+    };
+
+    __syncthreads();  // a previous run() may still be reading the stages
+    fetch(t_begin);
+    int stage = 0;
+    for (int t0 = t_begin; t0 < t_end; t0 += kTile, stage ^= 1) {
+      char* kl = lds + stage * 2 * kTileBytes;
+      char* vl = kl + kTileBytes;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int r = frow + 16 * i;
+        *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[i];
+        *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[i];
+      }
+      __syncthreads();
+      if (t0 + kTile < t_end) fetch(t0 + kTile);  // the next tile flies while this one is multiplied
+      if (CAUSAL && t0 > wave_qmax) continue;     // wave-uniform: nothing visible to this wave
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        float4v sacc[2];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
+            sacc[hh] = Mfma16<T>::mma(kf, qf[c][ks], sacc[hh]);
+          }
+        }
+        float sv[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float s = sacc[hh][r] * qk_scale;
+            if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
+            const int tok = t0 + 16 * hh + 4 * g + r;
+            bool ok = tok < t_end;
+            if (CAUSAL) ok = ok && tok <= qpos[c];
+            s = ok ? s : -INFINITY;
+            sv[hh * 4 + r] = s;
+            tmax = fmaxf(tmax, s);
+          }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m[c], tmax);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // nothing visible yet: keep everything at zero
+        const float alpha = exp2f(m[c] - m_use);
+        m[c] = m_new;
+        float psum = 0.f;
+        short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = exp2f(sv[j] - m_use);
+          psum += p;
+          pf[j] = (short)Conv<T>::from_f32(p);
+        }
+        lsum[c] = lsum[c] * alpha + psum;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) oacc[c][n] *= alpha;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          const int byte_in_row = 32 * n + 8 * (hl & 3);
+          const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
+          const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
+          const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          oacc[c][n] = Mfma16<T>::mma(vf, pf, oacc[c][n]);
+        }
+      }
+    }
+  }
+
+  // total of the running sum over the four lane groups
+  __device__ __forceinline__ float total(int c) const {
+    float s = lsum[c];
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+  }
+};
+
+}  // namespace sglk
