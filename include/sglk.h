@@ -239,22 +239,41 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm(const void* a, const void* b_nk, const
 
 /* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.
  * Replaces the ROCm op set of sgl-kernel/csrc/torch_extension_rocm.cc:25-55
- * (python/sgl_kernel/allreduce.py:5-50; device code custom_all_reduce_hip.cuh:155-575). */
+ * (python/sgl_kernel/allreduce.py:5-50; device code custom_all_reduce_hip.cuh:155-575).
+ * The set-up calls below (init, register, IPC, allocation) are host-side and may allocate or
+ * synchronise; sglk_ar_all_reduce itself only launches. */
 SGLK_API int64_t sglk_ar_meta_size(void);
-/* meta_ptrs[w]: every rank's signal buffer as mapped into THIS process (uncached device memory,
- * sglk_ar_meta_size() + staging bytes); returns an opaque handle (0 on failure). */
-SGLK_API int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi);
+/* meta_ptrs[w]: every rank's signal block as mapped into THIS process: zero-initialised uncached
+ * device memory of sglk_ar_meta_size() + staging_bytes bytes (the staging area of the two-stage
+ * algorithm follows the signals).  Returns an opaque handle (0 on failure).  At most 8 ranks.
+ * (init_custom_ar, sgl-kernel/csrc/allreduce/custom_all_reduce.hip:13-49) */
+SGLK_API int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi,
+                              int64_t staging_bytes);
 SGLK_API int sglk_ar_dispose(int64_t fa);
-/* data_ptrs[w]: every rank's registered input buffer for `local` (peer mappings). */
+/* data_ptrs[w]: every rank's registered input buffer for `local` (peer mappings);
+ * data_ptrs[rank] == local.  (register_buffer, custom_all_reduce.hip:119-144) */
 SGLK_API int sglk_ar_register_buffer(int64_t fa, void* local, void* const* data_ptrs);
+/* out = sum over ranks of their registered `inp` (fp32 accumulation in rank order, one rounding:
+ * every rank gets bit-identical results).  numel * element size must be a multiple of 16.
+ * algo: 0 = choose as the reference does (custom_all_reduce_hip.cuh:543-553), 1 = one-stage,
+ * 2 = two-stage.  (all_reduce_reg, custom_all_reduce.hip:89-95) */
 SGLK_API int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, int dtype,
-                                void* stream);
-/* IPC plumbing (hipIpcGetMemHandle / hipIpcOpenMemHandle / uncached allocation) */
+                                int algo, void* stream);
+/* Same for an unregistered input: it is first copied into the registered reg_buffer.
+ * (all_reduce_unreg, custom_all_reduce.hip:97-117) */
+SGLK_API int sglk_ar_all_reduce_unreg(int64_t fa, const void* inp, void* reg_buffer, void* out,
+                                      int64_t numel, int dtype, int algo, void* stream);
+/* Number of thread blocks whose barrier wait gave up (a peer never arrived); synchronises.
+ * No counterpart in the reference, whose barrier spins forever. */
+SGLK_API int sglk_ar_stuck(int64_t fa);
+/* IPC plumbing (hipIpcGetMemHandle / hipIpcOpenMemHandle / uncached allocation):
+ * allocate_meta_buffer, get_meta_buffer_ipc_handle (custom_all_reduce.hip:146-170).
+ * The handle names the allocation that holds dev_ptr; *offset_out is dev_ptr's offset in it. */
 SGLK_API int sglk_ipc_handle_bytes(void);
-SGLK_API int sglk_ipc_get_handle(void* dev_ptr, void* handle_out);
+SGLK_API int sglk_ipc_get_handle(void* dev_ptr, void* handle_out, int64_t* offset_out);
 SGLK_API void* sglk_ipc_open_handle(const void* handle);
 SGLK_API int sglk_ipc_close(void* mapped);
-SGLK_API void* sglk_alloc_uncached(int64_t bytes);
+SGLK_API void* sglk_alloc_uncached(int64_t bytes); /* zero-filled */
 SGLK_API int sglk_free_uncached(void* p);
 
 /* ------------------------------------------------------------------ R1-R4: radix tree (host) -- */

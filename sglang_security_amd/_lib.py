@@ -53,12 +53,14 @@ _SIGS = {
     "sglk_fp8_scaled_mm": (i32, [p, p, p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_fp8_blockwise_scaled_mm": (i32, [p, p, p, p, p, i32, i32, i32, i64, i64, i64, i64, i32, p]),
     "sglk_ar_meta_size": (i64, []),
-    "sglk_ar_init": (i64, [p, i32, i32, i32]),
+    "sglk_ar_init": (i64, [p, i32, i32, i32, i64]),
     "sglk_ar_dispose": (i32, [i64]),
     "sglk_ar_register_buffer": (i32, [i64, p, p]),
-    "sglk_ar_all_reduce": (i32, [i64, p, p, i64, i32, p]),
+    "sglk_ar_all_reduce": (i32, [i64, p, p, i64, i32, i32, p]),
+    "sglk_ar_all_reduce_unreg": (i32, [i64, p, p, p, i64, i32, i32, p]),
+    "sglk_ar_stuck": (i32, [i64]),
     "sglk_ipc_handle_bytes": (i32, []),
-    "sglk_ipc_get_handle": (i32, [p, p]),
+    "sglk_ipc_get_handle": (i32, [p, p, p]),
     "sglk_ipc_open_handle": (p, [p]),
     "sglk_ipc_close": (i32, [p]),
     "sglk_alloc_uncached": (p, [i64]),
@@ -83,7 +85,7 @@ _SIGS = {
 }
 
 
-_PENDING = {n for n in _SIGS if n.startswith(("sglk_ar_", "sglk_ipc_", "sglk_alloc_", "sglk_free_"))}
+_PENDING = set()
 
 
 class SglkError(RuntimeError):

@@ -1,0 +1,328 @@
+// Peer-to-peer all-reduce over xGMI on IPC-mapped buffers (one process per GPU).
+//
+// Replaces the ROCm op set of sgl-kernel/csrc/torch_extension_rocm.cc:25-55 (device code
+// custom_all_reduce_hip.cuh:155-575).  Every rank maps every other rank's signal block and registered
+// input buffers into its own address space; a reduction is then one kernel per rank:
+//
+//   one-stage  : barrier, every rank sums all ranks' inputs (fp32, rank order 0..W-1, one rounding)
+//                into its own output, barrier (inputs may be overwritten afterwards).
+//   two-stage  : barrier, rank r reduces slice r of all inputs into its own staging area (behind its
+//                signal block), barrier with release/acquire, every rank gathers all slices from the
+//                peers' staging areas.
+//
+// Because every element is summed in the same order by whichever rank owns it, all ranks end with
+// bit-identical results.
+//
+// Barriers: per (block, peer) 32-bit tickets in uncached memory.  Barrier number n of block b writes n
+// into slot [n & 1][b][my rank] of every peer and waits for n in its own slots; two slot sets keep a
+// fast rank's next barrier from overwriting a ticket a slow rank has not read yet.  A wait gives up
+// after a bounded number of polls and raises the block's `stuck` word instead of hanging the GPU.
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "common.h"
+
+namespace sglk {
+namespace {
+
+constexpr int kMaxRanks = 8;
+constexpr int kMaxBlocks = 64;
+constexpr int kThreads = 512;
+constexpr uint32_t kMaxPolls = 1u << 24;
+
+struct Signal {
+  alignas(128) uint32_t ticket[kMaxBlocks];                // barriers this block has passed (owner only)
+  alignas(128) uint32_t slot[2][kMaxBlocks][kMaxRanks];    // written by peers
+  alignas(128) uint32_t stuck[kMaxBlocks];                 // non-zero: a wait timed out
+};
+
+struct Peers {
+  Signal* sig[kMaxRanks];
+};
+struct Inputs {
+  const void* ptr[kMaxRanks];
+};
+
+template <bool RELEASE_ACQUIRE>
+__device__ __forceinline__ void barrier_all(const Peers& peers, Signal* self, int rank, int world) {
+  if (RELEASE_ACQUIRE) __syncthreads();  // all of the block's prior stores are issued
+  const uint32_t n = self->ticket[blockIdx.x] + 1;
+  if ((int)threadIdx.x < world) {
+    uint32_t* remote = &peers.sig[threadIdx.x]->slot[n & 1][blockIdx.x][rank];
+    if (RELEASE_ACQUIRE)
+      __hip_atomic_store(remote, n, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    else
+      __hip_atomic_store(remote, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* mine = &self->slot[n & 1][blockIdx.x][threadIdx.x];
+    uint32_t polls = 0;
+    while (true) {
+      const uint32_t v = RELEASE_ACQUIRE ? __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
+                                         : __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // tickets only grow; a peer that is already one barrier ahead wrote the other slot set
+      if (v == n) break;
+      if (++polls > kMaxPolls) {
+        self->stuck[blockIdx.x] = n;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) self->ticket[blockIdx.x] = n;
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void add_vec(float (&acc)[8], const uint4& v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  if constexpr (sizeof(typename Raw<T>::type) == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[2 * j] += Conv<T>::to_f32((uint16_t)(w[j] & 0xffffu));
+      acc[2 * j + 1] += Conv<T>::to_f32((uint16_t)(w[j] >> 16));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += __uint_as_float(w[j]);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 pack_vec(const float (&acc)[8]) {
+  uint32_t w[4];
+  if constexpr (sizeof(typename Raw<T>::type) == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      w[j] = (uint32_t)Conv<T>::from_f32(acc[2 * j]) | ((uint32_t)Conv<T>::from_f32(acc[2 * j + 1]) << 16);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = __float_as_uint(acc[j]);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// sum of 16-byte vector `i` over all ranks, rank order, fp32
+template <typename T>
+__device__ __forceinline__ uint4 reduce_vec(const Inputs& in, int world, int64_t i) {
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < world; ++r) add_vec<T>(acc, reinterpret_cast<const uint4*>(in.ptr[r])[i]);
+  return pack_vec<T>(acc);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) allreduce_one_stage(Inputs in, Peers peers, Signal* self, void* out, int rank,
+                                                                int world, int64_t nvec) {
+  barrier_all<true>(peers, self, rank, world);
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
+    reinterpret_cast<uint4*>(out)[i] = reduce_vec<T>(in, world, i);
+  barrier_all<false>(peers, self, rank, world);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(kThreads) allreduce_two_stage(Inputs in, Peers peers, Signal* self, void* out, int rank,
+                                                                int world, int64_t nvec) {
+  const int64_t part = nvec / world;  // the last rank also takes the remainder
+  const int64_t lo = part * rank, hi = rank == world - 1 ? nvec : lo + part;
+  uint4* stage = reinterpret_cast<uint4*>(self + 1);
+  barrier_all<true>(peers, self, rank, world);
+  for (int64_t i = lo + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kThreads)
+    stage[i - lo] = reduce_vec<T>(in, world, i);
+  barrier_all<true>(peers, self, rank, world);
+  for (int r = 0; r < world; ++r) {
+    // start with the own slice and walk the ring so that the links are used evenly
+    const int src = (rank + r) % world;
+    const int64_t slo = part * src, shi = src == world - 1 ? nvec : slo + part;
+    const uint4* from = reinterpret_cast<const uint4*>(peers.sig[src] + 1);
+    for (int64_t i = slo + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < shi; i += (int64_t)gridDim.x * kThreads)
+      reinterpret_cast<uint4*>(out)[i] = from[i - slo];
+  }
+}
+
+struct Comm {
+  int rank = 0, world = 1, full_xgmi = 1;
+  int64_t staging_bytes = 0;
+  Peers peers{};
+  Signal* self = nullptr;
+  std::map<const void*, Inputs> buffers;
+  std::mutex mu;
+};
+
+}  // namespace
+}  // namespace sglk
+
+using namespace sglk;
+
+extern "C" {
+
+int64_t sglk_ar_meta_size(void) { return (int64_t)sizeof(Signal); }
+
+int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi, int64_t staging_bytes) {
+  if (!meta_ptrs || world < 1 || world > kMaxRanks || rank < 0 || rank >= world || staging_bytes < 0) {
+    fail(SGLK_EINVAL, "ar_init: bad arguments (world=%d rank=%d; at most %d ranks)", world, rank, kMaxRanks);
+    return 0;
+  }
+  for (int r = 0; r < world; ++r)
+    if (!meta_ptrs[r]) {
+      fail(SGLK_EINVAL, "ar_init: null signal block for rank %d", r);
+      return 0;
+    }
+  Comm* c = new Comm();
+  c->rank = rank;
+  c->world = world;
+  c->full_xgmi = full_xgmi;
+  c->staging_bytes = staging_bytes;
+  for (int r = 0; r < world; ++r) c->peers.sig[r] = reinterpret_cast<Signal*>(meta_ptrs[r]);
+  c->self = c->peers.sig[rank];
+  return (int64_t) reinterpret_cast<intptr_t>(c);
+}
+
+int sglk_ar_dispose(int64_t fa) {
+  delete reinterpret_cast<Comm*>((intptr_t)fa);
+  return SGLK_OK;
+}
+
+int sglk_ar_register_buffer(int64_t fa, void* local, void* const* data_ptrs) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c && local && data_ptrs, "ar_register_buffer: null argument");
+  Inputs in{};
+  for (int r = 0; r < c->world; ++r) {
+    SGLK_CHECK(data_ptrs[r], "ar_register_buffer: null mapping for rank %d", r);
+    in.ptr[r] = data_ptrs[r];
+  }
+  SGLK_CHECK(data_ptrs[c->rank] == local, "ar_register_buffer: data_ptrs[rank] must be the local buffer");
+  std::lock_guard<std::mutex> g(c->mu);
+  c->buffers[local] = in;
+  return SGLK_OK;
+}
+
+int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, int dtype, int algo, void* stream) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c && inp && out, "ar_all_reduce: null argument");
+  SGLK_CHECK(numel >= 0, "ar_all_reduce: negative size");
+  SGLK_CHECK(dtype == SGLK_F32 || dtype == SGLK_F16 || dtype == SGLK_BF16, "ar_all_reduce: unsupported dtype %d", dtype);
+  if (numel == 0) return SGLK_OK;
+  const int64_t bytes = numel * elem_size(dtype);
+  // custom_all_reduce_hip.cuh:480-484: the payload must be a whole number of 16-byte packs
+  SGLK_CHECK(bytes % 16 == 0, "ar_all_reduce: byte size %lld is not a multiple of 16", (long long)bytes);
+  SGLK_CHECK(aligned16(inp) && aligned16(out), "ar_all_reduce: buffers must be 16-byte aligned");
+  Inputs in;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    auto it = c->buffers.find(inp);
+    SGLK_CHECK(it != c->buffers.end(), "ar_all_reduce: input %p is not a registered buffer", inp);
+    in = it->second;
+  }
+  const int64_t nvec = bytes / 16;
+  if (algo == 0) {
+    // custom_all_reduce_hip.cuh:543-553
+    if (c->world <= 2)
+      algo = 1;
+    else if (c->full_xgmi && ((c->world <= 4 && bytes < 512 * 1024) || bytes < 256 * 1024))
+      algo = 1;
+    else
+      algo = 2;
+  }
+  SGLK_CHECK(algo == 1 || algo == 2, "ar_all_reduce: algo must be 0 (auto), 1 or 2");
+  if (algo == 2) {
+    const int64_t need = (nvec / c->world + nvec % c->world) * 16;
+    SGLK_CHECK(need <= c->staging_bytes, "ar_all_reduce: two-stage needs %lld staging bytes, %lld were given at init",
+               (long long)need, (long long)c->staging_bytes);
+  }
+  const int64_t work = algo == 2 ? (nvec + c->world - 1) / c->world : nvec;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, (work + kThreads - 1) / kThreads));
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_FLOAT(dtype, T, {
+    if (algo == 1)
+      hipLaunchKernelGGL((allreduce_one_stage<T>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,
+                         c->rank, c->world, nvec);
+    else
+      hipLaunchKernelGGL((allreduce_two_stage<T>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,
+                         c->rank, c->world, nvec);
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_ar_all_reduce_unreg(int64_t fa, const void* inp, void* reg_buffer, void* out, int64_t numel, int dtype, int algo,
+                             void* stream) {
+  SGLK_CHECK(inp && reg_buffer, "ar_all_reduce_unreg: null argument");
+  SGLK_CHECK(numel >= 0, "ar_all_reduce_unreg: negative size");
+  SGLK_HIP(hipMemcpyAsync(reg_buffer, inp, (size_t)numel * elem_size(dtype), hipMemcpyDeviceToDevice,
+                          (hipStream_t)stream));
+  return sglk_ar_all_reduce(fa, reg_buffer, out, numel, dtype, algo, stream);
+}
+
+int sglk_ar_stuck(int64_t fa) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  if (!c) return fail(SGLK_EINVAL, "ar_stuck: null handle");
+  uint32_t host[kMaxBlocks];
+  SGLK_HIP(hipMemcpy(host, c->self->stuck, sizeof(host), hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int i = 0; i < kMaxBlocks; ++i) n += host[i] != 0;
+  return n;
+}
+
+// ---- IPC plumbing --------------------------------------------------------------------------------------
+int sglk_ipc_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
+
+int sglk_ipc_get_handle(void* dev_ptr, void* handle_out, int64_t* offset_out) {
+  SGLK_CHECK(dev_ptr && handle_out, "ipc_get_handle: null argument");
+  void* base = nullptr;
+  size_t size = 0;
+  SGLK_HIP(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)dev_ptr));
+  hipIpcMemHandle_t h;
+  SGLK_HIP(hipIpcGetMemHandle(&h, base));
+  std::memcpy(handle_out, &h, sizeof(h));
+  if (offset_out) *offset_out = (int64_t)((char*)dev_ptr - (char*)base);
+  return SGLK_OK;
+}
+
+void* sglk_ipc_open_handle(const void* handle) {
+  if (!handle) {
+    fail(SGLK_EINVAL, "ipc_open_handle: null handle");
+    return nullptr;
+  }
+  hipIpcMemHandle_t h;
+  std::memcpy(&h, handle, sizeof(h));
+  void* p = nullptr;
+  hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) {
+    fail(SGLK_EHIP, "hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+
+int sglk_ipc_close(void* mapped) {
+  SGLK_CHECK(mapped, "ipc_close: null pointer");
+  SGLK_HIP(hipIpcCloseMemHandle(mapped));
+  return SGLK_OK;
+}
+
+void* sglk_alloc_uncached(int64_t bytes) {
+  if (bytes <= 0) {
+    fail(SGLK_EINVAL, "alloc_uncached: bad size");
+    return nullptr;
+  }
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    fail(SGLK_EHIP, "hipExtMallocWithFlags(uncached) failed: %s", hipGetErrorString(e));
+    return nullptr;
+  }
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e != hipSuccess) {
+    fail(SGLK_EHIP, "hipMemset failed: %s", hipGetErrorString(e));
+    (void)hipFree(p);
+    return nullptr;
+  }
+  return p;
+}
+
+int sglk_free_uncached(void* p) {
+  if (p) SGLK_HIP(hipFree(p));
+  return SGLK_OK;
+}
+
+}  // extern "C"
