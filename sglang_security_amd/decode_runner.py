@@ -221,6 +221,23 @@ class LlamaDecoder:
         torch.argmax(self.logits, dim=-1, out=self.next_ids)
         self.input_ids.copy_(self.next_ids)
 
+    def enable_shared_prefix(self, on: bool = True) -> bool:
+        """Route decode attention through the shared-prefix kernel: the batch is one group whose first
+        prefix_len slots are the radix-tree hit every request shares (what RadixCache.match_prefix returned)."""
+        self.shared = bool(on) and getattr(self, "prefix_len", 0) > 0 and self.cfg.head_dim == 128
+        if self.shared:
+            c = self.cfg
+            self.group_indptr = torch.tensor([0, self.B], dtype=torch.int32, device=self.device)
+            self.group_prefix = torch.tensor([self.prefix_len], dtype=torch.int32, device=self.device)
+            nbytes = ops.decode_shared_workspace_bytes(self.B, c.q_heads, c.head_dim, self.max_kv_splits)
+            self.shared_ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+        return self.shared
+
     def attention(self, li, q_view, o_view, sm_scale):
+        if getattr(self, "shared", False):
+            ops.decode_attention_shared_prefix(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr,
+                                               self.kv_indices, self.group_indptr, self.group_prefix, self.shared_ws,
+                                               self.max_kv_splits, sm_scale, 0.0)
+            return
         ops.decode_attention_fwd(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
                                  self.attn_logits, self.attn_lse, self.num_kv_splits, self.max_kv_splits, sm_scale, 0.0)
