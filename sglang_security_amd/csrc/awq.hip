@@ -18,6 +18,7 @@
 //     acc[m,n]  = sum_k x[m,k] * (OFF + q[k,n])                       (matrix cores, fp32)
 //     out[m,n] += s[gq,n] * acc[m,n] - s[gq,n] * (OFF + z[gq,n]) * X[kb,m],   X[kb,m] = sum_k x[m,k]
 // i.e. out = x @ ((q - z) * s) with the product (q - z) * s never rounded to half precision.
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -428,28 +429,373 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) awq_gemm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide kernel: 8 waves = 4 k-groups x 2 column chunks of 64, one block per CU (two waves per SIMD).
+//
+// The inner loop of the kernel above spends ~15 instructions per MFMA on 16 columns per wave; issue slots,
+// not HBM, bound it.  Here a wave owns 64 columns (4 strips) of one 128-k group per stage, so every A
+// fragment read from LDS feeds 4 strips and the per-stage bookkeeping is spread over 64 MFMAs.  The four
+// k-waves of a column chunk work on four consecutive groups (a stage is 512 k) and add their tiles up
+// through LDS at the end, so a block needs no split-K partner for K <= 4096.
+//
+//   x   : stage = 4 tiles of 64 rows x 128 k (64 KiB) by LDS-DMA, two stages;
+//   sz  : per wave and stage one 256-byte LDS-DMA piece (scale pairs + zero words), three stages;
+//   w   : 4 x 16 bytes per lane straight into registers, two stages ahead (three register sets);
+//   X   : block sums of x per (group, row), computed once per stage from the landed tile by all threads.
+// Per-wave issue order inside a stage is x(i+1), sz(i+2), w(i+2): waiting for x(i+1) leaves the five younger
+// operations outstanding.
+// ---------------------------------------------------------------------------------------------
+struct Wide {
+  static constexpr int kStageK = 512;
+  static constexpr int kXStage = 4 * 64 * 256;          // 64 KiB
+  static constexpr int kSzOff = 2 * kXStage;            // [3][8 waves][256 B]
+  static constexpr int kXsumOff = kSzOff + 3 * 8 * 256;  // float [2][4][64]
+  static constexpr int kFlagOff = kXsumOff + 2 * 4 * 64 * 4;
+  static constexpr int kLds = kFlagOff + 16;
+  static constexpr int kTileFloats = 64 * 128;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
+    const uint16_t* __restrict__ x, const int32_t* __restrict__ packed, const uint16_t* __restrict__ scales,
+    const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+    float* __restrict__ partial, int* __restrict__ tickets, int M, int N, int K, int stages_per_split, int splits,
+    int64_t x_stride, int64_t out_stride, int abl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* xsumS = reinterpret_cast<float*>(smem + Wide::kXsumOff);
+  int* flag = reinterpret_cast<int*>(smem + Wide::kFlagOff);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kw = wid & 3, nw = wid >> 2;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.z * kGemmBM;
+  const int total_stages = K / Wide::kStageK;
+  const int st0 = blockIdx.y * stages_per_split;
+  const int nst = min(stages_per_split, total_stages - st0);
+  const int n0 = blockIdx.x * 128 + nw * 64;
+  const int64_t nstrips = N / 16;
+  const int qcols = N / 8;
+  // timing experiments (abl & 16): thread 0 drops 100 MHz clock stamps behind the ticket words in use
+  const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  auto stamp = [&](int k) {
+    if ((abl & 16) && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
+  };
+  // abl & 32: six stamps inside stage 3 (wave 0 lane 0) instead
+  auto stamp_in = [&](int stage, int k) {
+    if ((abl & 32) && stage == 3 && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
+  };
+  stamp(0);
+
+  // ---- x DMA: wave w fills pieces 8w .. 8w+7 of a stage; piece p = (tile p >> 4, rows 4 * (p & 15) + g)
+  uint32_t xoff[8];  // element offset of this lane's 16-byte source chunk inside stage 0
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int p = 8 * wid + j;
+    const int row = 4 * (p & 15) + g;
+    xoff[j] = (uint32_t)(min(m0 + row, M - 1) * x_stride + 128 * (p >> 4) + 8 * (i16 ^ (row & 15)));
+  }
+  auto issue_x = [&](int stage, int buf) {
+    const uint16_t* src = x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK;
+    char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16(src + xoff[j], dst + j * 1024);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- sz DMA: lanes [0, 32) scale pairs of the wave's 64 columns, [32, 40) zero words, the rest repeat
+  const bool sz_is_zero = lane >= 32 && lane < 40;
+  const int sz_col = lane < 32 ? 2 * lane : 0;
+  auto issue_sz = [&](int stage, int slot) {
+    const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
+    const void* src = sz_is_zero ? (const void*)(qzeros + (int64_t)gq * qcols + (n0 >> 3) + (lane - 32))
+                                 : (const void*)(scales + (int64_t)gq * N + n0 + sz_col);
+    glds4(src, smem + Wide::kSzOff + (slot * 8 + wid) * 256);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- weights: strip t of group gq is 1 KiB at ((gq * nstrips) + n0/16 + t) * 1024; 16 bytes per lane.
+  // Issued as raw instructions so that the compiler neither counts them nor waits for them: the counted
+  // vmcnt at each stage boundary (bound to the registers through its operands) is the only wait.
+  const uint32_t wvoff = (uint32_t)((((int64_t)kw * nstrips + (n0 >> 4)) * 64 + lane) * 16);
+  auto load_w = [&](int stage, int4v(&w)[4]) {
+    const char* src = reinterpret_cast<const char*>(packed) + (int64_t)(st0 + min(stage, nst - 1)) * 4 * nstrips * 1024;
+    asm volatile(
+        "global_load_dwordx4 %0, %4, %5\n\t"
+        "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+        "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+        "global_load_dwordx4 %3, %4, %5 offset:3072"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
+        : "v"(wvoff), "s"(src)
+        : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // x(next) has landed once only sz and w issued after it (five operations) are outstanding; the weights named
+  // here were issued before it, so they have landed too
+  auto stage_wait = [&](int4v(&w)[4]) {
+    asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
+  };
+
+  // One accumulator set: R[t][q] holds the running sum of strip t in units of the current group's scale,
+  //   R = sum_{g' <= g} (s_g' / s_g) * (x . (OFF + q_g') - (OFF + z_g') * X_g'),
+  // so the matrix cores add straight into it; moving to the next group multiplies R by s_g / s_{g+1}.
+  // Needs every scale finite and non-zero (the launcher's precondition).
+  float4v R[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R[t][q] = float4v{0.f, 0.f, 0.f, 0.f};
+  float s_cur[4] = {1.f, 1.f, 1.f, 1.f};
+  int zsh[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) zsh[t] = 4 * kAwqOrd[(n0 + 16 * t + i16) & 7];
+  int aoff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) aoff[ks] = kw * 16384 + x_off(i16, 4 * ks + g);
+  uint32_t or_const = AwqMagic<T>::kOr;
+  uint32_t nib_mask = 0x000F000Fu;
+  asm volatile("" : "+v"(or_const));
+  asm volatile("" : "+s"(nib_mask));
+
+  // block sums of the landed x stage: thread (row = tid >> 3, tile = (tid & 7) >> 1, half = tid & 1)
+  auto xsum_pass = [&](int buf) {
+    const int row = tid >> 3, tile = (tid & 7) >> 1, half = tid & 1;
+    const char* tp = smem + buf * Wide::kXStage + tile * 16384;
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int4v v = *reinterpret_cast<const int4v*>(tp + x_off(row, 8 * half + j));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) part = AwqMagic<T>::pair_sum((uint32_t)v[e], part);
+    }
+    part += __shfl_xor(part, 1, 64);
+    if (half == 0) xsumS[(buf * 4 + tile) * 64 + row] = part;
+  };
+
+  int4v wreg[3][4];
+  // prologue: sz(0), w(0), x(0), sz(1), w(1); then X(0)
+  issue_sz(0, 0);
+  load_w(0, wreg[0]);
+  issue_x(0, 0);
+  issue_sz(1, 1);
+  load_w(1, wreg[1]);
+  stage_wait(wreg[0]);  // sz(0), w(0), x(0) landed; sz(1) and w(1) fly on
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  xsum_pass(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  stamp(1);
+  const int npad = (nst + 2) / 3 * 3;  // register set = unroll index; padded stages only keep the pipeline counts
+  for (int i0 = 0; i0 < npad; i0 += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int i = i0 + u;
+      const int buf = i & 1;
+      stamp_in(i, 0);
+      issue_x((abl & 2) ? 0 : i + 1, buf ^ 1);
+      issue_sz(i + 2, (u + 2) % 3);
+      load_w((abl & 8) ? 0 : i + 2, wreg[(u + 2) % 3]);
+      stamp_in(i, 1);
+      if (i < nst && !(abl & 4)) {  // block-uniform
+        const char* xt = smem + buf * Wide::kXStage;
+        // this stage's per-column scale and zero (landed two stages ago); rescale R to the new unit
+        float nzo[4];  // -(OFF + z)
+        {
+          const char* szp = smem + Wide::kSzOff + (u * 8 + wid) * 256;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int c = 16 * t + i16;
+            const float sg = Conv<T>::to_f32(*reinterpret_cast<const uint16_t*>(szp + 2 * c));
+            const uint32_t zw = *reinterpret_cast<const uint32_t*>(szp + 128 + 4 * (c >> 3));
+            nzo[t] = -(AwqMagic<T>::kOff + (float)((zw >> zsh[t]) & 0xF));
+            const float ratio = s_cur[t] * __builtin_amdgcn_rcpf(sg);
+            s_cur[t] = sg;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[t][q] *= ratio;
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          int4v af[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const int4v*>(xt + q * 4096 + aoff[ks]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const uint32_t w = (uint32_t)wreg[u][t][ks];
+            int4v bf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[e] = (int)(((w >> (4 * e)) & nib_mask) | or_const);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
+          }
+        }
+        // zero-point term with this group's block sums
+        {
+          const float* xp = xsumS + (buf * 4 + kw) * 64;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 16 * q + 4 * g);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              R[t][q] = __builtin_elementwise_fma(xs4, float4v{nzo[t], nzo[t], nzo[t], nzo[t]}, R[t][q]);
+          }
+        }
+      }
+      stamp_in(i, 2);
+      if (i + 1 >= nst) goto stages_done;  // block-uniform: the look-ahead loads are drained below
+      stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
+      stamp_in(i, 3);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stamp_in(i, 4);
+      if (!(abl & 1)) xsum_pass(buf ^ 1);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      stamp_in(i, 5);
+    }
+  }
+stages_done:
+  // drain the look-ahead loads (the DMA targets this block's LDS) before the stages are reused
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  stamp(2);
+  // ---- add the four k-waves of each column chunk up through LDS: wave (kw, nw) finishes strip t = kw
+  float* red = reinterpret_cast<float*>(smem);  // [8 waves][16 regs x 4][64 lanes] = 128 KiB: the x stages
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[((wid * 16 + t * 4 + q) * 4 + r) * 64 + lane] = R[t][q][r] * s_cur[t];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  float4v fin[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) a += red[(((nw * 4 + k2) * 16 + kw * 4 + q) * 4 + r) * 64 + lane];
+      fin[q][r] = a;
+    }
+  // lane (i16, g) of wave (kw, nw) now holds rows 16q + 4g + r of column n0 + 16*kw + i16
+  const int n = n0 + 16 * kw + i16;
+  stamp(3);
+  if (splits == 1) {
+    const float bv = bias ? Conv<T>::to_f32(bias[n]) : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * q + 4 * g + r;
+        if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(fin[q][r] + bv);
+      }
+    stamp(4);
+    return;
+  }
+  // split-K: slab[tile][split] holds the block's 64 x 128 fp32 tile as [strip = nw*4+kw][q][r][lane].
+  // Slabs are written and read with agent-scope (write-through / cache-bypassing) accesses, so that no
+  // whole-cache write-back or invalidate is needed around the ticket.
+  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+  float* slab = partial + ((int64_t)tile * splits + blockIdx.y) * Wide::kTileFloats;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      __hip_atomic_store(&slab[(((nw * 4 + kw) * 4 + q) * 4 + r) * 64 + lane], fin[q][r], __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0) {
+    const int ticket = __hip_atomic_fetch_add(&tickets[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == splits - 1;
+    if (last) __hip_atomic_store(&tickets[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero for the next launch
+    *flag = last;
+  }
+  __syncthreads();
+  stamp(4);
+  if (*flag == 0) return;
+  const float* tslab = partial + (int64_t)tile * splits * Wide::kTileFloats;
+  // thread -> 16 consecutive floats (one register row quarter): element e0 = 16 * tid
+  {
+    const int e0 = 16 * tid;
+    float a[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.f;
+    // four slabs' worth of loads in flight at a time (each one is a trip to memory); the sum runs in slab order
+    for (int s0 = 0; s0 < splits; s0 += 4) {
+      unsigned long long v[4][8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s2 = min(s0 + j, splits - 1);
+        const unsigned long long* src =
+            reinterpret_cast<const unsigned long long*>(tslab + (int64_t)s2 * Wide::kTileFloats + e0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float keep = (s0 + j < splits) ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          a[2 * e] += keep * __uint_as_float((uint32_t)v[j][e]);
+          a[2 * e + 1] += keep * __uint_as_float((uint32_t)(v[j][e] >> 32));
+        }
+      }
+    }
+    // element e0 + e: lane = (e0 + e) & 63, reg = e0 >> 6 -> (strip, q, r)
+    const int l0 = e0 & 63, reg = e0 >> 6;
+    const int r = reg & 3, q = (reg >> 2) & 3, strip = reg >> 4;
+    const int m = m0 + 16 * q + 4 * (l0 >> 4) + r;
+    const int nn = blockIdx.x * 128 + 16 * strip;  // l0 & 15 == 0: the 16 floats are the strip's 16 columns
+    if (m < M) {
+      short8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float b0 = bias ? Conv<T>::to_f32(bias[nn + e]) : 0.f;
+        const float b1 = bias ? Conv<T>::to_f32(bias[nn + 8 + e]) : 0.f;
+        o0[e] = (short)Conv<T>::from_f32(a[e] + b0);
+        o1[e] = (short)Conv<T>::from_f32(a[8 + e] + b1);
+      }
+      *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + nn) = o0;
+      *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + nn + 8) = o1;
+    }
+  }
+  stamp(5);
+}
+
 struct GemmPlan {
-  int nw, tn, splits, kb_per_split, mblocks, tiles;
+  int nw, tn, wr, splits, kb_per_split, mblocks, tiles;
   int64_t slab_floats;
 };
 
 static GemmPlan plan_awq_gemm(int M, int N, int K) {
-  static const int env_cfg = getenv("SGLK_AWQ_CFG") ? atoi(getenv("SGLK_AWQ_CFG")) : 0;  // 82, 42, 41
+  // SGLK_AWQ_CFG = 100 * waves + 10 * strips per wave + weight ring depth (tuning aid)
+  static const int env_cfg = getenv("SGLK_AWQ_CFG") ? atoi(getenv("SGLK_AWQ_CFG")) : 0;
   static const int env_blocks = getenv("SGLK_AWQ_MIN_BLOCKS") ? atoi(getenv("SGLK_AWQ_MIN_BLOCKS")) : 224;
+  static const int env_minkb = getenv("SGLK_AWQ_MIN_KB") ? atoi(getenv("SGLK_AWQ_MIN_KB")) : 4;
   GemmPlan p;
   p.mblocks = (M + kGemmBM - 1) / kGemmBM;
   const int kblocks = K / 128;
   int cfg = env_cfg;
-  if (cfg == 82 && N % 256) cfg = 0;
-  if (cfg == 42 && N % 128) cfg = 0;
-  if (cfg == 0) cfg = (N % 128 == 0 && N >= 8192) ? 42 : 41;
-  p.nw = cfg / 10;
-  p.tn = cfg % 10;
+  if (cfg && N % (16 * (cfg / 100) * ((cfg / 10) % 10))) cfg = 0;
+  if (cfg == 0) cfg = (N % 128 == 0 && N >= 8192) ? 426 : 416;
+  p.nw = cfg / 100;
+  p.tn = (cfg / 10) % 10;
+  p.wr = cfg % 10;
   const int nblocks = N / (16 * p.nw * p.tn);
   p.tiles = nblocks * p.mblocks;
-  // enough blocks to cover the 256 CUs, but keep >= 4 k-blocks (512 k) per split
+  // enough blocks to cover the 256 CUs, but keep >= env_minkb k-blocks per split
   int splits = 1;
-  while (p.tiles * splits < env_blocks && kblocks / (splits * 2) >= 4) splits *= 2;
+  while (p.tiles * splits < env_blocks && kblocks / (splits * 2) >= env_minkb) splits *= 2;
   p.kb_per_split = (kblocks + splits - 1) / splits;
   p.splits = (kblocks + p.kb_per_split - 1) / p.kb_per_split;
   p.slab_floats = (int64_t)p.nw * p.tn * 16 * 64;
@@ -457,6 +803,42 @@ static GemmPlan plan_awq_gemm(int M, int N, int K) {
 }
 
 static constexpr int kMaxTiles = 4096;  // ticket words at the head of the workspace
+
+struct WidePlan {
+  bool ok;
+  int tiles, splits, stages_per_split, mblocks;
+};
+
+// The wide kernel needs K in whole 512-k stages, N in whole 128-column tiles and 128-k scale groups.
+static WidePlan plan_awq_wide(int M, int N, int K, int group_size) {
+  static const int env_wide = getenv("SGLK_AWQ_WIDE") ? atoi(getenv("SGLK_AWQ_WIDE")) : 1;
+  static const int env_sps = getenv("SGLK_AWQ_WIDE_SPS") ? atoi(getenv("SGLK_AWQ_WIDE_SPS")) : 0;
+  WidePlan p{};
+  p.ok = env_wide && group_size == 128 && K % Wide::kStageK == 0 && N % 128 == 0;
+  if (!p.ok) return p;
+  p.mblocks = (M + kGemmBM - 1) / kGemmBM;
+  p.tiles = (N / 128) * p.mblocks;
+  const int total = K / Wide::kStageK;
+  // one block per CU: rounds of 256 blocks, each costing its stages plus about two stages of fill and drain,
+  // plus the last split's reduction over all slabs
+  int best_sps = total;
+  float best = 1e30f;
+  for (int sps = 1; sps <= total; ++sps) {
+    const int splits = (total + sps - 1) / sps;
+    const int rounds = (p.tiles * splits + 255) / 256;
+    const float cost = rounds * (sps + 2.0f) + (splits > 1 ? 0.25f * splits : 0.f);
+    if (cost < best) {
+      best = cost;
+      best_sps = sps;
+    }
+  }
+  if (env_sps > 0 && env_sps <= total) best_sps = env_sps;
+  p.stages_per_split = best_sps;
+  p.splits = (total + best_sps - 1) / best_sps;
+  // a block that would run a single stage is all fill and drain: the narrow kernel is faster there
+  if (best_sps < 2 && env_wide < 2) p.ok = false;
+  return p;
+}
 
 }  // namespace sglk
 
@@ -493,9 +875,11 @@ int sglk_awq_repack(const int32_t* qweight, int32_t* packed, int rows, int qcols
 int64_t sglk_awq_gemm_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0 || K % 128) return 0;
   const GemmPlan p = plan_awq_gemm(M, N, K);
-  int64_t bytes = (int64_t)kMaxTiles * 4;
-  if (p.splits > 1) bytes += (int64_t)p.tiles * p.splits * p.slab_floats * 4;
-  return bytes;
+  int64_t bytes = 0;
+  if (p.splits > 1) bytes = (int64_t)p.tiles * p.splits * p.slab_floats * 4;
+  const WidePlan wp = plan_awq_wide(M, N, K, 128);
+  if (wp.ok && wp.splits > 1) bytes = std::max<int64_t>(bytes, (int64_t)wp.tiles * wp.splits * Wide::kTileFloats * 4);
+  return bytes + (int64_t)kMaxTiles * 4;
 }
 
 int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, const void* bias,
@@ -511,10 +895,28 @@ int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, cons
   SGLK_CHECK(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0, "awq_gemm: out rows must be 8-byte aligned");
   SGLK_CHECK(aligned16(workspace), "awq_gemm: workspace must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const GemmPlan p = plan_awq_gemm(M, N, K);
-  SGLK_CHECK(p.tiles <= kMaxTiles, "awq_gemm: too many output tiles (%d)", p.tiles);
   int* tickets = reinterpret_cast<int*>(workspace);
   float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (int64_t)kMaxTiles * 4);
+  const WidePlan wp = plan_awq_wide(M, N, K, group_size);
+  static const int env_abl = getenv("SGLK_AWQ_ABL") ? atoi(getenv("SGLK_AWQ_ABL")) : 0;  // timing experiments only
+  if (wp.ok && wp.tiles <= kMaxTiles && aligned16(out) && out_stride % 8 == 0) {
+    dim3 wgrid(N / 128, wp.splits, wp.mblocks);
+    SGLK_DISPATCH_HALF(dtype, T, {
+      static bool attr_set = false;
+      if (!attr_set) {
+        SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_wide_kernel<T>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((awq_gemm_wide_kernel<T>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x, packed,
+                         (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial, tickets, M, N,
+                         K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl);
+    });
+    SGLK_LAUNCH_CHECK();
+    return SGLK_OK;
+  }
+  const GemmPlan p = plan_awq_gemm(M, N, K);
+  SGLK_CHECK(p.tiles <= kMaxTiles, "awq_gemm: too many output tiles (%d)", p.tiles);
   dim3 grid(N / (16 * p.nw * p.tn), p.splits, p.mblocks);
 #define SGLK_AWQ_LAUNCH(NW, TN, WR)                                                                               \
   {                                                                                                               \
@@ -529,13 +931,15 @@ int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, cons
                        packed, (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial,   \
                        tickets, M, N, K, group_size, p.kb_per_split, p.splits, x_stride, out_stride);             \
   }
+  const int code = p.nw * 100 + p.tn * 10 + p.wr;
   SGLK_DISPATCH_HALF(dtype, T, {
-    if (p.nw == 8) {
-      SGLK_AWQ_LAUNCH(8, 2, 6)
-    } else if (p.tn == 2) {
-      SGLK_AWQ_LAUNCH(4, 2, 6)
-    } else {
-      SGLK_AWQ_LAUNCH(4, 1, 6)
+    switch (code) {
+      case 426: SGLK_AWQ_LAUNCH(4, 2, 6) break;
+      case 416: SGLK_AWQ_LAUNCH(4, 1, 6) break;
+      case 414: SGLK_AWQ_LAUNCH(4, 1, 4) break;
+      case 816: SGLK_AWQ_LAUNCH(8, 1, 6) break;
+      case 814: SGLK_AWQ_LAUNCH(8, 1, 4) break;
+      default: return fail(SGLK_EINVAL, "awq_gemm: no kernel for configuration %d", code);
     }
   });
 #undef SGLK_AWQ_LAUNCH

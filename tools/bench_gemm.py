@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=64)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--dense", action="store_true")
+ap.add_argument("--stamps", action="store_true", help="per-phase clock stamps of the wide AWQ kernel (run with SGLK_AWQ_ABL=16)")
 args = ap.parse_args()
 dev = "cuda"
 M = args.m
@@ -46,6 +47,32 @@ for name, K, N in shapes:
         else:
             ops.awq_gemm(x, w[0], w[1], w[2], None, out, work)
 
+    if args.stamps:
+        for i in range(3):
+            run(i)
+        torch.cuda.synchronize()
+        work.zero_()
+        run(3)
+        torch.cuda.synchronize()
+        t = work.view(torch.int32)[2048:4096].view(256, 8).cpu().double()
+        t = t[t[:, 0] != 0]
+        if t.shape[0] == 0:
+            print(f"{name}: no stamps", flush=True)
+            continue
+        t0 = t[:, 0].min()
+        names = ["start", "prologue", "loop", "reduce", "stored", "split-reduce"]
+        if int(os.environ.get("SGLK_AWQ_ABL", "0")) & 32:
+            names = ["stage3", "issued", "computed", "landed", "barrier1", "xsum+barrier2"]
+            t0 = None
+        msg = [f"{name}: blocks={t.shape[0]}"]
+        for k in range(6):
+            col = t[:, k]
+            ok = col != 0
+            if ok.any():
+                d = (col[ok] - (t0 if t0 is not None else t[ok][:, 0])) / 100.0
+                msg.append(f"{names[k]} {d.mean():.2f}/{d.max():.2f}us")
+        print("  ".join(msg), flush=True)
+        continue
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         for i in range(copies):
