@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   // One accumulator set: R[t][q] holds the running sum of strip t in units of the current group's scale,
   //   R = sum_{g' <= g} (s_g' / s_g) * (x . (OFF + q_g') - (OFF + z_g') * X_g'),
   // so the matrix cores add straight into it; moving to the next group multiplies R by s_g / s_{g+1}.
-  // Needs every scale finite and non-zero (the launcher's precondition).
+  // A column whose scale is zero keeps its previous unit (see below); non-finite scales propagate.
   float4v R[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -602,17 +602,28 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       if (i < nst && !(abl & 4)) {  // block-uniform
         const char* xt = smem + buf * Wide::kXStage;
         // this stage's per-column scale and zero (landed two stages ago); rescale R to the new unit
-        float nzo[4];  // -(OFF + z)
+        float nzo[4];        // -(OFF + z)
+        uint32_t msk[4], orc[4];  // per-strip dequantisation constants (zeroed for a column whose scale is zero)
         {
           const char* szp = smem + Wide::kSzOff + (u * 8 + wid) * 256;
+          float sg[4];
+          // A zero (or denormal) scale cannot become the unit of R: that column keeps its unit and this group
+          // contributes nothing to it (its B operand and zero-point term are zeroed).
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const int c = 16 * t + i16;
-            const float sg = Conv<T>::to_f32(*reinterpret_cast<const uint16_t*>(szp + 2 * c));
+            const float s_in = Conv<T>::to_f32(*reinterpret_cast<const uint16_t*>(szp + 2 * c));
             const uint32_t zw = *reinterpret_cast<const uint32_t*>(szp + 128 + 4 * (c >> 3));
-            nzo[t] = -(AwqMagic<T>::kOff + (float)((zw >> zsh[t]) & 0xF));
-            const float ratio = s_cur[t] * __builtin_amdgcn_rcpf(sg);
-            s_cur[t] = sg;
+            const bool ok = fabsf(s_in) >= 1.17549435e-38f;
+            sg[t] = ok ? s_in : s_cur[t];
+            nzo[t] = ok ? -(AwqMagic<T>::kOff + (float)((zw >> zsh[t]) & 0xF)) : 0.f;
+            msk[t] = ok ? nib_mask : 0u;
+            orc[t] = ok ? or_const : 0u;
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float ratio = s_cur[t] * __builtin_amdgcn_rcpf(sg[t]);
+            s_cur[t] = sg[t];
 #pragma unroll
             for (int q = 0; q < 4; ++q) R[t][q] *= ratio;
           }
@@ -627,7 +638,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
             const uint32_t w = (uint32_t)wreg[u][t][ks];
             int4v bf;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bf[e] = (int)(((w >> (4 * e)) & nib_mask) | or_const);
+            for (int e = 0; e < 4; ++e) bf[e] = (int)(((w >> (4 * e)) & msk[t]) | orc[t]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
           }
@@ -811,7 +822,9 @@ struct WidePlan {
 
 // The wide kernel needs K in whole 512-k stages, N in whole 128-column tiles and 128-k scale groups.
 static WidePlan plan_awq_wide(int M, int N, int K, int group_size) {
-  static const int env_wide = getenv("SGLK_AWQ_WIDE") ? atoi(getenv("SGLK_AWQ_WIDE")) : 1;
+  // 0: never, 1: where it is expected to be faster, 2: wherever the shape allows (read per call: a test hook)
+  const char* env_wide_s = getenv("SGLK_AWQ_WIDE");
+  const int env_wide = env_wide_s ? atoi(env_wide_s) : 1;
   static const int env_sps = getenv("SGLK_AWQ_WIDE_SPS") ? atoi(getenv("SGLK_AWQ_WIDE_SPS")) : 0;
   WidePlan p{};
   p.ok = env_wide && group_size == 128 && K % Wide::kStageK == 0 && N % 128 == 0;

@@ -240,3 +240,65 @@ def test_merge_state_golden(golden, name, rtol):
     ops.merge_state(va, sa, vb, sb, vo, so)
     torch.testing.assert_close(vo.cpu().float(), g["expect_v"].float(), atol=1e-3, rtol=rtol)
     torch.testing.assert_close(so.cpu(), g["expect_s"], atol=1e-3, rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------- AWQ, wide kernel
+@pytest.fixture
+def force_wide(monkeypatch):
+    """SGLK_AWQ_WIDE=2 routes every eligible shape (K % 512 == 0, N % 128 == 0, group 128) through the 8-wave kernel,
+    whatever the planner would pick."""
+    monkeypatch.setenv("SGLK_AWQ_WIDE", "2")
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 512, 128), (64, 2048, 256), (7, 4096, 384), (33, 1536, 128), (64, 7168, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_awq_gemm_wide_vs_oracle(force_wide, M, K, N, dtype):
+    """One stage, several stages, split-K with and without a ragged last split, ragged M."""
+    import oracle
+
+    ops = _ops()
+    x, qw, sc, qz = _awq_case(M, K, N, 128, dtype, seed=M + K + N)
+    want = oracle.awq_gemm(x, qw, sc, qz).float()
+    packed = ops.awq_repack(qw.to(DEV))
+    got = ops.awq_gemm(x.to(DEV), packed, sc.to(DEV), qz.to(DEV)).float().cpu()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 1e-2 * max(scale, 1.0)
+    # twice in a row on the same workspace: the ticket words must have been left at zero
+    work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), 256), dtype=torch.uint8, device=DEV)
+    a = ops.awq_gemm(x.to(DEV), packed, sc.to(DEV), qz.to(DEV), None, None, work)
+    b = ops.awq_gemm(x.to(DEV), packed, sc.to(DEV), qz.to(DEV), None, None, work)
+    assert torch.equal(a, b) and torch.equal(a.float().cpu(), got)
+
+
+def test_awq_gemm_wide_zero_scales(force_wide):
+    """Columns whose scale is exactly zero in some groups (first, middle, last, all): they contribute nothing
+    there and the rest of the sum is unaffected."""
+    import oracle
+
+    ops = _ops()
+    M, K, N = 64, 2048, 256
+    x, qw, sc, qz = _awq_case(M, K, N, 128, torch.bfloat16, seed=5)
+    sc = sc.clone()
+    sc[0, 3] = 0          # first group
+    sc[7, 17] = 0         # a middle group
+    sc[15, 100] = 0       # last group
+    sc[:, 200] = 0        # every group: the whole column is zero
+    sc[4:9, 64:80] = 0    # a whole strip, consecutive groups
+    want = oracle.awq_gemm(x, qw, sc, qz).float()
+    got = ops.awq_gemm(x.to(DEV), ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV)).float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got[:, 200] == 0).all()
+    assert (got - want).abs().max().item() <= 1e-2 * max(want.abs().max().item(), 1.0)
+
+
+def test_awq_gemm_full_size_shapes():
+    """The workload's own projections (Llama-3-8B, batch 64) against the oracle: the planner's choice of kernel."""
+    import oracle
+
+    ops = _ops()
+    for (K, N) in [(4096, 28672), (14336, 4096)]:
+        x, qw, sc, qz = _awq_case(64, K, N, 128, torch.bfloat16, seed=K)
+        want = oracle.awq_gemm(x, qw, sc, qz).float()
+        got = ops.awq_gemm(x.to(DEV), ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV)).float().cpu()
+        assert (got - want).abs().max().item() <= 1e-2 * max(want.abs().max().item(), 1.0)
+
