@@ -184,14 +184,23 @@ SGLK_API int sglk_awq_dequantize(const int32_t* qweight, const void* scales, con
                                  void* stream);
 
 /* One-time re-layout of an AWQ weight for the fused GEMM (done in process_weights_after_loading).
- * packed: rows*qcols int32 (same byte count as qweight). */
+ * packed: int32 [K/128][N/16][64 lanes][4], the same byte count as qweight; K % 128 == 0, N % 16 == 0. */
 SGLK_API int sglk_awq_repack(const int32_t* qweight, int32_t* packed, int rows, int qcols,
                              void* stream);
+
+/* awq_dequantize from the re-laid-out copy: the same values as sglk_awq_dequantize on the original tensor
+ * (for the prefill path once the reference-layout qweight has been dropped).  K % 128 == 0, N % 16 == 0. */
+SGLK_API int sglk_awq_dequantize_packed(const int32_t* packed, const void* scales, const int32_t* qzeros,
+                                        void* out, int K, int N, int group_size, int dtype, void* stream);
 
 /* out[M,N] = x[M,K] @ dequant(W) (+bias) with the int4 weights dequantised in registers and fed to
  * the matrix cores; W in the sglk_awq_repack layout.  Fuses AWQLinearMethod.apply,
  * python/sglang/srt/layers/quantization/awq.py:197-215 (awq_dequantize + torch.matmul).
- * workspace: fp32 split-K partials, sglk_awq_gemm_workspace_bytes() bytes (may be 0 -> NULL). */
+ * Computes x @ ((q - z) * s) with (q - z) * s never rounded to half precision (fp32 accumulation).
+ * K % 128 == 0, N % 64 == 0, group_size a multiple of 128; any M (rows are processed 64 at a time).
+ * workspace: sglk_awq_gemm_workspace_bytes() bytes, always required.  Its first 16 KiB are split-K ticket
+ * counters: they must be zero before the first call and every call leaves them zero, so one zero-filled
+ * buffer serves any number of consecutive calls on a stream (calls that overlap on two streams need two). */
 SGLK_API int64_t sglk_awq_gemm_workspace_bytes(int M, int N, int K);
 SGLK_API int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales,
                            const int32_t* qzeros, const void* bias, void* out, float* workspace,

@@ -43,6 +43,7 @@ _SIGS = {
     "sglk_rope": (i32, [p, p, p, p, i64, i32, i32, i32, i32, i64, i64, i32, i32, p]),
     "sglk_rope_and_store_kv": (i32, [p, p, p, p, p, p, i32, i64, i32, i32, i32, i32, i64, i64, i32, i32, p]),
     "sglk_awq_dequantize": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
+    "sglk_awq_dequantize_packed": (i32, [p, p, p, p, i32, i32, i32, i32, p]),
     "sglk_awq_repack": (i32, [p, p, i32, i32, p]),
     "sglk_awq_gemm_workspace_bytes": (i64, [i32, i32, i32]),
     "sglk_awq_gemm": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p]),

@@ -1,0 +1,188 @@
+"""Attention backend on the HIP kernels: mirror of TritonAttnBackend
+(python/sglang/srt/layers/attention/triton_backend.py:151-836) for the paths RadixAttention takes with a radix
+cache: decode over paged KV, extend over a cached prefix, metadata at fixed addresses for graph replay.
+
+It reads the same fields of the objects the reference passes around:
+  model_runner : .device, .req_to_token_pool.req_to_token, .token_to_kv_pool, .model_config.num_attention_heads,
+                 .model_config.get_num_kv_heads(tp), .model_config.head_dim (v_head_dim optional), .tp_size,
+                 .server_args.triton_attention_num_kv_splits
+  forward_batch: .forward_mode.is_decode_or_idle() / is_extend(), .batch_size, .req_pool_indices, .seq_lens,
+                 .seq_lens_sum, .out_cache_loc, .extend_prefix_lens, .extend_seq_lens, .token_to_kv_pool
+  layer        : .layer_id, .tp_q_head_num, .tp_k_head_num, .qk_head_dim, .v_head_dim, .scaling, .logit_cap
+
+One extension: when `forward_batch.prefix_groups = (group_indptr, prefix_lens)` is set (the radix-tree hit the
+scheduler found: requests of a group share their first prefix_lens slots), decode takes the shared-prefix
+kernel, which reads that part of the KV pool once per group.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from .. import ops
+from .._lib import SglkError, lib
+
+
+@dataclass
+class ForwardMetadata:
+    """triton_backend.py:134-148."""
+    attn_logits: Optional[torch.Tensor]
+    attn_lse: Optional[torch.Tensor]
+    max_extend_len: Optional[int]
+    num_kv_splits: Optional[torch.Tensor]
+    kv_indptr: torch.Tensor
+    kv_indices: torch.Tensor
+    qo_indptr: Optional[torch.Tensor]
+    custom_mask: Optional[torch.Tensor] = None
+    mask_indptr: Optional[torch.Tensor] = None
+    prefix_groups: Optional[tuple] = None
+    shared_workspace: Optional[torch.Tensor] = None
+
+
+class SglkAttnBackend:
+    def __init__(self, model_runner, skip_prefill: bool = False, kv_indptr_buf: Optional[torch.Tensor] = None):
+        self.device = model_runner.device
+        self.req_to_token = model_runner.req_to_token_pool.req_to_token
+        max_bs = self.req_to_token.shape[0]
+        self.kv_indptr = kv_indptr_buf if kv_indptr_buf is not None else torch.zeros(
+            (max_bs + 1,), dtype=torch.int32, device=self.device)
+        self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        cfg = model_runner.model_config
+        tp = getattr(model_runner, "tp_size", 1)
+        self.num_head = cfg.num_attention_heads // tp
+        self.num_kv_head = cfg.get_num_kv_heads(tp)
+        self.head_dim = cfg.head_dim
+        self.v_head_dim = getattr(cfg, "v_head_dim", None) or cfg.head_dim
+        self.max_kv_splits = getattr(model_runner.server_args, "triton_attention_num_kv_splits", 8)
+        self.static_kv_splits = False
+        self.device_core_count = int(lib().sglk_device_cu_count())
+        self.max_context_len = self.req_to_token.shape[1]
+        self.forward_metadata: Optional[ForwardMetadata] = None
+
+    # ---- metadata ------------------------------------------------------------------------------------------
+    def get_num_kv_splits(self, num_kv_splits: torch.Tensor, seq_lens: torch.Tensor):
+        """triton_backend.py:235-269."""
+        if self.static_kv_splits or self.device_core_count <= 0:
+            num_kv_splits.fill_(self.max_kv_splits)
+            return
+        ops.get_num_kv_splits(num_kv_splits, seq_lens, self.num_head, self.num_kv_head, self.max_kv_splits,
+                              self.device_core_count)
+
+    def _decode_buffers(self, bs: int):
+        attn_logits = torch.empty((bs, self.num_head, self.max_kv_splits, self.v_head_dim), dtype=torch.float32,
+                                  device=self.device)
+        attn_lse = torch.empty((bs, self.num_head, self.max_kv_splits), dtype=torch.float32, device=self.device)
+        num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+        return attn_logits, attn_lse, num_kv_splits
+
+    def _shared_workspace(self, bs: int):
+        n = ops.decode_shared_workspace_bytes(bs, self.num_head, self.v_head_dim, self.max_kv_splits)
+        return torch.empty(n // 4, dtype=torch.float32, device=self.device)
+
+    def init_forward_metadata(self, forward_batch):
+        """triton_backend.py:271-446 (no speculative decoding, no sliding window, no custom mask)."""
+        bs = forward_batch.batch_size
+        kv_indptr = self.kv_indptr
+        if forward_batch.forward_mode.is_decode_or_idle():
+            ops.kv_indptr_cumsum(forward_batch.seq_lens, kv_indptr)
+            kv_indptr = kv_indptr[: bs + 1]
+            kv_indices = torch.empty(forward_batch.seq_lens_sum, dtype=torch.int32, device=self.device)
+            ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
+                                  None, kv_indices)
+            attn_logits, attn_lse, num_kv_splits = self._decode_buffers(bs)
+            self.get_num_kv_splits(num_kv_splits, forward_batch.seq_lens)
+            groups = getattr(forward_batch, "prefix_groups", None)
+            self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
+                                                    None, prefix_groups=groups,
+                                                    shared_workspace=self._shared_workspace(bs) if groups else None)
+            return
+        # extend: the prefix part comes from the pool through kv_indices, the new part is contiguous
+        ops.kv_indptr_cumsum(forward_batch.extend_prefix_lens, kv_indptr)
+        kv_indptr = kv_indptr[: bs + 1]
+        total_prefix = int(forward_batch.extend_prefix_lens.sum().item())
+        kv_indices = torch.empty(max(total_prefix, 1), dtype=torch.int32, device=self.device)
+        ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.extend_prefix_lens,
+                              kv_indptr, None, kv_indices)
+        qo_indptr = self.qo_indptr
+        ops.kv_indptr_cumsum(forward_batch.extend_seq_lens, qo_indptr)
+        qo_indptr = qo_indptr[: bs + 1]
+        max_extend_len = int(forward_batch.extend_seq_lens.max().item())
+        self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+
+    # ---- graph capture: metadata lives at fixed addresses, refreshed by one launch per replay -----------------
+    def init_cuda_graph_state(self, max_bs: int, kv_indices_buf: Optional[torch.Tensor] = None):
+        """triton_backend.py:448-492."""
+        self.cuda_graph_attn_logits, self.cuda_graph_attn_lse, self.cuda_graph_num_kv_splits = self._decode_buffers(max_bs)
+        self.cuda_graph_num_kv_splits.fill_(self.max_kv_splits)
+        self.cuda_graph_kv_indices = kv_indices_buf if kv_indices_buf is not None else torch.zeros(
+            (max_bs * self.max_context_len,), dtype=torch.int32, device=self.device)
+        self.cuda_graph_shared_workspace = self._shared_workspace(max_bs)
+
+    def init_forward_metadata_capture_cuda_graph(self, bs: int, num_tokens: int, req_pool_indices: torch.Tensor,
+                                                 seq_lens: torch.Tensor, encoder_lens=None, forward_mode=None,
+                                                 spec_info=None, prefix_groups=None):
+        """triton_backend.py:494-625 (decode only)."""
+        if forward_mode is not None and not forward_mode.is_decode_or_idle():
+            raise SglkError("graph capture is implemented for decode batches")
+        ops.decode_metadata(self.req_to_token, req_pool_indices, seq_lens, self.kv_indptr, self.cuda_graph_kv_indices,
+                            self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head, self.max_kv_splits,
+                            self.device_core_count)
+        self.forward_metadata = ForwardMetadata(self.cuda_graph_attn_logits, self.cuda_graph_attn_lse, None,
+                                                self.cuda_graph_num_kv_splits, self.kv_indptr, self.cuda_graph_kv_indices,
+                                                None, prefix_groups=prefix_groups,
+                                                shared_workspace=self.cuda_graph_shared_workspace)
+
+    def init_forward_metadata_replay_cuda_graph(self, bs: int, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
+                                                seq_lens_sum: int, encoder_lens=None, forward_mode=None, spec_info=None,
+                                                seq_lens_cpu=None):
+        """triton_backend.py:627-730: rewrite kv_indptr / kv_indices / num_kv_splits in place (one launch)."""
+        ops.decode_metadata(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
+                            self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head,
+                            self.max_kv_splits, self.device_core_count)
+
+    def get_cuda_graph_seq_len_fill_value(self):
+        return 1
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
+        if forward_batch.forward_mode.is_decode_or_idle():
+            return self.forward_decode(q, k, v, layer, forward_batch, save_kv_cache)
+        return self.forward_extend(q, k, v, layer, forward_batch, save_kv_cache)
+
+    def forward_extend(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
+        """triton_backend.py:735-788."""
+        md = self.forward_metadata
+        o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim)) if layer.qk_head_dim != layer.v_head_dim \
+            else torch.empty_like(q)
+        if save_kv_cache:
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        ops.extend_attention_fwd(
+            q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k.contiguous().view(-1, layer.tp_k_head_num, layer.qk_head_dim),
+            v.contiguous().view(-1, layer.tp_k_head_num, layer.v_head_dim), o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
+            forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id), md.qo_indptr, md.kv_indptr, md.kv_indices,
+            md.custom_mask, True, md.mask_indptr, md.max_extend_len, layer.scaling, layer.logit_cap)
+        return o
+
+    def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
+        """triton_backend.py:790-835."""
+        md = self.forward_metadata
+        q = q.reshape(-1, layer.tp_q_head_num * layer.qk_head_dim)
+        o = q.new_empty((q.shape[0], layer.tp_q_head_num * layer.v_head_dim)) if layer.qk_head_dim != layer.v_head_dim \
+            else torch.empty_like(q)
+        if save_kv_cache:
+            forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        kb = forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id)
+        vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
+        q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
+        o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
+        if md.prefix_groups is not None and layer.qk_head_dim == 128 and layer.v_head_dim == 128 and q.dtype != torch.float32:
+            gi, pl = md.prefix_groups
+            ops.decode_attention_shared_prefix(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, gi, pl, md.shared_workspace,
+                                               self.max_kv_splits, layer.scaling, layer.logit_cap)
+        else:
+            ops.decode_attention_fwd(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse,
+                                     md.num_kv_splits, self.max_kv_splits, layer.scaling, layer.logit_cap)
+        return o

@@ -83,6 +83,36 @@ __global__ void __launch_bounds__(256) awq_repack_kernel(const int32_t* __restri
   }
 }
 
+// dequantise from the re-laid-out copy (the prefill path when the reference-layout tensor has been dropped):
+// one thread per packed word = 8 weights k0 .. k0+7 of one column
+template <typename T>
+__global__ void __launch_bounds__(256) awq_dequant_packed_kernel(const int32_t* __restrict__ packed,
+                                                                 const uint16_t* __restrict__ scales,
+                                                                 const int32_t* __restrict__ qzeros,
+                                                                 uint16_t* __restrict__ out, int K, int N,
+                                                                 int group_size) {
+  const int qcols = N / 8, nstrips = N / 16;
+  const int64_t total = (int64_t)K * qcols;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int d = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    const int64_t tile = idx >> 8;
+    const int nb = (int)(tile % nstrips), kb = (int)(tile / nstrips);
+    const int n = 16 * nb + (lane & 15);
+    const int k0 = 128 * kb + 32 * d + 8 * (lane >> 4);
+    const int gq = k0 / group_size;
+    const uint32_t w = (uint32_t)packed[idx];
+    const uint32_t z = ((uint32_t)qzeros[(int64_t)gq * qcols + (n >> 3)] >> (4 * kAwqOrd[n & 7])) & 0xF;
+    const float s = Conv<T>::to_f32(scales[(int64_t)gq * N + n]);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int pos = (e & 1) ? (e >> 1) + 4 : (e >> 1);
+      const float diff = (float)((int)((w >> (4 * pos)) & 0xF) - (int)z);
+      out[(int64_t)(k0 + e) * N + n] = Conv<T>::from_f32(diff * s);
+    }
+  }
+}
+
 template <typename T>
 struct AwqMagic;
 template <>
@@ -870,6 +900,20 @@ int sglk_awq_dequantize(const int32_t* qweight, const void* scales, const int32_
                      hipLaunchKernelGGL((awq_dequant_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                                         qweight, (const uint16_t*)scales, qzeros, (uint16_t*)out, rows, qcols,
                                         group_size));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_awq_dequantize_packed(const int32_t* packed, const void* scales, const int32_t* qzeros, void* out, int K, int N,
+                               int group_size, int dtype, void* stream) {
+  SGLK_CHECK(packed && scales && qzeros && out, "awq_dequantize_packed: null pointer");
+  SGLK_CHECK(K > 0 && N > 0 && K % 128 == 0 && N % 16 == 0, "awq_dequantize_packed: K %% 128 and N %% 16 must be 0");
+  SGLK_CHECK(group_size > 0 && K % group_size == 0 && group_size % 8 == 0, "awq_dequantize_packed: bad group size");
+  int blocks = (int)(((int64_t)K * (N / 8) + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((awq_dequant_packed_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                        packed, (const uint16_t*)scales, qzeros, (uint16_t*)out, K, N, group_size));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -1,0 +1,140 @@
+"""KV pools: host-side mirror of python/sglang/srt/mem_cache/memory_pool.py for the decode path.
+
+  ReqToTokenPool            (:55-96)    request -> token-slot table, int32 [size, max_context_len]
+  TokenToKVPoolAllocator    (:150-214)  free list of slot indices; slot 0 is a dummy for padded tokens
+  MHATokenToKVPool          (:240-412)  per layer K [size + 1, Hkv, D] and V [size + 1, Hkv, Dv]; set_kv_buffer
+                                        scatters new rows with the HIP kernel (sglk_set_kv_buffer)
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+
+
+class ReqToTokenPool:
+    def __init__(self, size: int, max_context_len: int, device: str, enable_memory_saver: bool = False):
+        self.size = size
+        self.max_context_len = max_context_len
+        self.device = device
+        self.req_to_token = torch.zeros((size, max_context_len), dtype=torch.int32, device=device)
+        self.free_slots = list(range(size))
+
+    def write(self, indices, values):
+        self.req_to_token[indices] = values
+
+    def available_size(self) -> int:
+        return len(self.free_slots)
+
+    def alloc(self, need_size: int) -> Optional[List[int]]:
+        if need_size > len(self.free_slots):
+            return None
+        select = self.free_slots[:need_size]
+        self.free_slots = self.free_slots[need_size:]
+        return select
+
+    def free(self, free_index):
+        if isinstance(free_index, int):
+            self.free_slots.append(free_index)
+        else:
+            self.free_slots.extend(free_index)
+
+    def clear(self):
+        self.free_slots = list(range(self.size))
+
+
+class TokenToKVPoolAllocator:
+    def __init__(self, size: int, dtype: torch.dtype, device: str, kvcache: "MHATokenToKVPool"):
+        self.size = size
+        self.dtype = dtype
+        self.device = device
+        self.page_size = 1
+        self._kvcache = kvcache
+        self.free_group: List[torch.Tensor] = []
+        self.is_not_in_free_group = True
+        self.clear()
+
+    def available_size(self) -> int:
+        return len(self.free_slots)
+
+    def get_kvcache(self):
+        return self._kvcache
+
+    def alloc(self, need_size: int) -> Optional[torch.Tensor]:
+        if need_size > len(self.free_slots):
+            return None
+        select = self.free_slots[:need_size]
+        self.free_slots = self.free_slots[need_size:]
+        return select
+
+    def free(self, free_index: torch.Tensor):
+        if free_index.numel() == 0:
+            return
+        if self.is_not_in_free_group:
+            self.free_slots = torch.cat((self.free_slots, free_index.to(self.free_slots.dtype)))
+        else:
+            self.free_group.append(free_index)
+
+    def free_group_begin(self):
+        self.is_not_in_free_group = False
+        self.free_group = []
+
+    def free_group_end(self):
+        self.is_not_in_free_group = True
+        if self.free_group:
+            self.free(torch.cat(self.free_group))
+
+    def clear(self):
+        # slot 0 is reserved for writes of padded tokens (memory_pool.py:207-211)
+        self.free_slots = torch.arange(1, self.size + 1, dtype=torch.int64, device=self.device)
+        self.is_not_in_free_group = True
+        self.free_group = []
+
+
+class MHATokenToKVPool:
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, head_num: int, head_dim: int, layer_num: int,
+                 device: str, enable_memory_saver: bool = False, start_layer: Optional[int] = None,
+                 end_layer: Optional[int] = None, v_head_dim: Optional[int] = None):
+        self.size = size
+        self.page_size = page_size
+        self.dtype = dtype
+        self.store_dtype = dtype
+        self.head_num = head_num
+        self.head_dim = head_dim
+        self.v_head_dim = v_head_dim or head_dim
+        self.layer_num = layer_num
+        self.device = device
+        self.start_layer = start_layer or 0
+        self.end_layer = end_layer if end_layer is not None else layer_num - 1
+        # [size + page_size, head_num, head_dim] per layer; the padded slot 0 absorbs dummy writes
+        self.k_buffer = [torch.zeros((size + page_size, head_num, head_dim), dtype=dtype, device=device)
+                         for _ in range(layer_num)]
+        self.v_buffer = [torch.zeros((size + page_size, head_num, self.v_head_dim), dtype=dtype, device=device)
+                         for _ in range(layer_num)]
+
+    def get_kv_size_bytes(self):
+        k = sum(t.numel() * t.element_size() for t in self.k_buffer)
+        v = sum(t.numel() * t.element_size() for t in self.v_buffer)
+        return k, v
+
+    def get_key_buffer(self, layer_id: int):
+        return self.k_buffer[layer_id - self.start_layer]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.v_buffer[layer_id - self.start_layer]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor,
+                      k_scale: Optional[float] = None, v_scale: Optional[float] = None):
+        """memory_pool.py:378-412 (the scale arguments belong to the fp8 KV cache, which this pool does not hold)."""
+        if k_scale is not None or v_scale is not None:
+            raise NotImplementedError("scaled (fp8) KV cache")
+        layer_id = layer.layer_id if hasattr(layer, "layer_id") else int(layer)
+        if cache_k.dtype != self.dtype:
+            cache_k = cache_k.to(self.dtype)
+            cache_v = cache_v.to(self.dtype)
+        ops.set_kv_buffer(self.get_key_buffer(layer_id), self.get_value_buffer(layer_id), loc, cache_k, cache_v)

@@ -273,6 +273,17 @@ def awq_repack(qweight):
     return packed
 
 
+def awq_dequantize_packed(packed, scales, qzeros):
+    """awq_dequantize from the re-laid-out copy: [K, N] in the scale dtype."""
+    _need_gpu(packed, scales, qzeros)
+    K, N = packed.shape[0], packed.shape[1] * 8
+    group = K // scales.shape[0]
+    out = torch.empty((K, N), dtype=scales.dtype, device=packed.device)
+    check(lib().sglk_awq_dequantize_packed(_ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(out), K, N, group,
+                                           dtype_code(scales.dtype), _stream(packed)), "awq_dequantize_packed")
+    return out
+
+
 def awq_gemm_workspace_bytes(M, N, K) -> int:
     return int(lib().sglk_awq_gemm_workspace_bytes(M, N, K))
 

@@ -1,0 +1,155 @@
+"""Drop-in operator surface: the functions of the reference's `sgl_kernel` package that lie on the
+RadixAttention + quantized-matmul decode path, with the reference's names, argument order, defaults and error
+behaviour, executed by libsglk (HIP, gfx950).
+
+    import sglang_security_amd.sgl_kernel as sgl_kernel        # or: sglang_security_amd.sgl_kernel.install()
+
+Each function cites the reference wrapper it replaces (sgl-kernel/python/sgl_kernel/*.py).  Arguments that only
+make sense on NVIDIA hardware (enable_pdl) are accepted and ignored.  There is no CPU fallback: CPU tensors
+raise SglkError.
+"""
+from __future__ import annotations
+
+import sys
+from typing import List, Optional, Tuple
+
+import torch
+
+from .. import ops as _ops
+from .._lib import SglkError  # noqa: F401
+
+__all__ = [
+    "rmsnorm", "fused_add_rmsnorm", "gemma_rmsnorm", "gemma_fused_add_rmsnorm", "silu_and_mul", "gelu_tanh_and_mul",
+    "gelu_and_mul", "apply_rope_with_cos_sin_cache_inplace", "awq_dequantize", "fp8_scaled_mm",
+    "fp8_blockwise_scaled_mm", "sgl_per_token_quant_fp8", "sgl_per_token_group_quant_fp8", "sgl_per_tensor_quant_fp8",
+    "merge_state", "merge_state_v2", "install",
+]
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    return t.reshape(-1, t.shape[-1])
+
+
+# ---- elementwise.py ---------------------------------------------------------------------------------------
+def rmsnorm(input: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out: Optional[torch.Tensor] = None,
+            enable_pdl: Optional[bool] = None) -> torch.Tensor:
+    """elementwise.py:9-45."""
+    if out is None:
+        out = torch.empty_like(input)
+    _ops.rmsnorm(_rows(out), _rows(input), weight, eps, gemma=False)
+    return out
+
+
+def fused_add_rmsnorm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
+                      enable_pdl: Optional[bool] = None) -> None:
+    """elementwise.py:48-82: residual += input; input = rmsnorm(residual) * weight, both in place."""
+    _ops.fused_add_rmsnorm(_rows(input), _rows(residual), weight, eps, gemma=False)
+
+
+def gemma_rmsnorm(input: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out: Optional[torch.Tensor] = None,
+                  enable_pdl: Optional[bool] = None) -> torch.Tensor:
+    """elementwise.py:85-121: scale is (1 + weight)."""
+    if out is None:
+        out = torch.empty_like(input)
+    _ops.rmsnorm(_rows(out), _rows(input), weight, eps, gemma=True)
+    return out
+
+
+def gemma_fused_add_rmsnorm(input: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6,
+                            enable_pdl: Optional[bool] = None) -> None:
+    """elementwise.py:124-158."""
+    _ops.fused_add_rmsnorm(_rows(input), _rows(residual), weight, eps, gemma=True)
+
+
+def _gated(input: torch.Tensor, out: Optional[torch.Tensor], act: int) -> torch.Tensor:
+    # elementwise.py:161-183: same checks, same messages
+    if input.shape[-1] * input.dtype.itemsize % 16 != 0:
+        raise ValueError("The pointers must be multiple of 16 bytes.")
+    if out is not None:
+        assert input.ndim == out.ndim, f"{input.ndim} != {out.ndim}"
+        assert input.shape[:-1] == out.shape[:-1], f"{input.shape[:-1]} != {out.shape[:-1]}"
+        assert input.shape[-1] == 2 * out.shape[-1], f"{input.shape[-1]} != {2 * out.shape[-1]}"
+    else:
+        out = torch.empty(input.shape[:-1] + (input.shape[-1] // 2,), device=input.device, dtype=input.dtype)
+    _ops.act_and_mul(_rows(out), _rows(input), act)
+    return out
+
+
+def silu_and_mul(input: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """elementwise.py:171-183."""
+    return _gated(input, out, 0)
+
+
+def gelu_tanh_and_mul(input: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """elementwise.py:186-198."""
+    return _gated(input, out, 1)
+
+
+def gelu_and_mul(input: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """elementwise.py:201-213."""
+    return _gated(input, out, 2)
+
+
+def apply_rope_with_cos_sin_cache_inplace(positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor,
+                                          head_size: int, cos_sin_cache: torch.Tensor, is_neox: bool = True) -> None:
+    """elementwise.py:216-268: query [nnz, Hq*head_size], key [nnz, Hk*head_size], rotated in place."""
+    if cos_sin_cache.dtype != torch.float32:
+        raise ValueError("cos_sin_cache should be float32")
+    _ops.rope(query.view(query.shape[0], -1, head_size), key.view(key.shape[0], -1, head_size), cos_sin_cache,
+              positions.long(), head_size, interleave=not is_neox)
+
+
+# ---- gemm.py ------------------------------------------------------------------------------------------------
+def awq_dequantize(qweight: torch.Tensor, scales: torch.Tensor, qzeros: torch.Tensor) -> torch.Tensor:
+    """gemm.py:7-10."""
+    return _ops.awq_dequantize(qweight, scales, qzeros)
+
+
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
+    """gemm.py:34-42."""
+    return _ops.fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias)
+
+
+def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
+    """gemm.py:24-31."""
+    return _ops.fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype)
+
+
+def sgl_per_token_group_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor, group_size: int,
+                                  eps: float, fp8_min: float, fp8_max: float) -> None:
+    """gemm.py:85-96."""
+    _ops.per_token_group_quant_fp8(input, output_q, output_s, group_size, eps, fp8_min, fp8_max)
+
+
+def sgl_per_tensor_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor,
+                             is_static: bool) -> None:
+    """gemm.py:113-121."""
+    _ops.per_tensor_quant_fp8(input, output_q, output_s, is_static)
+
+
+def sgl_per_token_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor) -> None:
+    """gemm.py:124-129."""
+    _ops.per_token_quant_fp8(input, output_q, output_s)
+
+
+# ---- attention.py ---------------------------------------------------------------------------------------------
+def merge_state_v2(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b: torch.Tensor,
+                   v_merged: Optional[torch.Tensor] = None,
+                   s_merged: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """attention.py:31-51."""
+    s_a = s_a.to(torch.float32)
+    s_b = s_b.to(torch.float32)
+    if v_merged is None:
+        v_merged = torch.empty_like(v_a)
+    if s_merged is None:
+        s_merged = torch.empty_like(s_a)
+    _ops.merge_state(v_a, s_a, v_b, s_b, v_merged, s_merged)
+    return v_merged, s_merged
+
+
+merge_state = merge_state_v2  # attention.py:12-28: same contract, older kernel
+
+
+def install(name: str = "sgl_kernel") -> None:
+    """Make `import sgl_kernel` resolve to this module (the hook a deployment uses to swap the kernels in)."""
+    sys.modules[name] = sys.modules[__name__]

@@ -1,0 +1,235 @@
+"""GPU: the host-side mirrors of the reference interfaces (sgl_kernel op surface, attention backend, KV pools, AWQ
+linear method) drive the HIP kernels and agree with the C oracle."""
+import math
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class _Mode:
+    def __init__(self, decode):
+        self._d = decode
+
+    def is_decode_or_idle(self):
+        return self._d
+
+    def is_extend(self):
+        return not self._d
+
+
+def _runner(Hq, Hkv, D, max_bs=8, max_ctx=512, layers=2, pool=2048, dtype=torch.bfloat16):
+    from sglang_security_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
+
+    r2t = ReqToTokenPool(max_bs, max_ctx, DEV)
+    kv = MHATokenToKVPool(pool, 1, dtype, Hkv, D, layers, DEV)
+    alloc = TokenToKVPoolAllocator(pool, dtype, DEV, kv)
+    cfg = types.SimpleNamespace(num_attention_heads=Hq, head_dim=D, get_num_kv_heads=lambda tp: Hkv)
+    mr = types.SimpleNamespace(device=DEV, req_to_token_pool=r2t, token_to_kv_pool=kv, model_config=cfg, tp_size=1,
+                               server_args=types.SimpleNamespace(triton_attention_num_kv_splits=8))
+    return mr, r2t, kv, alloc
+
+
+def _layer(i, Hq, Hkv, D):
+    return types.SimpleNamespace(layer_id=i, tp_q_head_num=Hq, tp_k_head_num=Hkv, tp_v_head_num=Hkv, qk_head_dim=D,
+                                 v_head_dim=D, scaling=1.0 / math.sqrt(D), logit_cap=0.0)
+
+
+def test_pools_and_set_kv_buffer():
+    mr, r2t, kv, alloc = _runner(8, 2, 128)
+    assert alloc.available_size() == 2048
+    a = alloc.alloc(10)
+    b = alloc.alloc(5)
+    assert a.tolist() == list(range(1, 11)) and b.tolist() == list(range(11, 16))  # slot 0 is never handed out
+    assert alloc.alloc(5000) is None
+    alloc.free(a)
+    assert alloc.available_size() == 2048 - 5
+    alloc.free_group_begin()
+    alloc.free(b[:2])
+    alloc.free(b[2:])
+    assert alloc.available_size() == 2048 - 5
+    alloc.free_group_end()
+    assert alloc.available_size() == 2048
+    rows = r2t.alloc(3)
+    assert rows == [0, 1, 2] and r2t.available_size() == 5
+    r2t.free(rows)
+    k = torch.randn(7, 2, 128, device=DEV).to(torch.bfloat16)
+    v = torch.randn(7, 2, 128, device=DEV).to(torch.bfloat16)
+    loc = torch.tensor([5, 9, 1, 77, 300, 2047, 2048], device=DEV)
+    kv.set_kv_buffer(_layer(1, 8, 2, 128), loc, k, v)
+    assert torch.equal(kv.get_key_buffer(1)[loc], k) and torch.equal(kv.get_value_buffer(1)[loc], v)
+    assert kv.get_key_buffer(0).abs().sum() == 0 and kv.get_key_buffer(1)[0].abs().sum() == 0
+
+
+@pytest.mark.parametrize("graph_state", [False, True])
+def test_backend_decode_matches_oracle(graph_state):
+    """Radix-style batch (shared 100-token prefix + private tails) through init_forward_metadata / forward_decode,
+    per-request and shared-prefix paths, eager and fixed-address (graph) metadata."""
+    import oracle
+    from sglang_security_amd.attention import SglkAttnBackend
+    from sglang_security_amd.mem_cache.radix_cache import build_prefix_groups
+
+    Hq, Hkv, D, B = 16, 4, 128, 5
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    g = torch.Generator().manual_seed(0)
+    prefix = alloc.alloc(100)
+    lens, slots_new = [], []
+    for b in range(B):
+        tail = alloc.alloc(3 + 7 * b)
+        L = 100 + tail.numel()
+        r2t.req_to_token[b, :100] = prefix.int()
+        r2t.req_to_token[b, 100:L] = tail.int()
+        lens.append(L)
+        slots_new.append(int(tail[-1]))
+    for layer_buf in (kv.k_buffer[0], kv.v_buffer[0]):
+        layer_buf.copy_(torch.randn(layer_buf.shape, generator=g).to(torch.bfloat16))
+    seq_lens = torch.tensor(lens, device=DEV)
+    q = torch.randn(B, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    k_new = torch.randn(B, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    v_new = torch.randn(B, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    fb = types.SimpleNamespace(forward_mode=_Mode(True), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                               seq_lens=seq_lens, seq_lens_sum=sum(lens), out_cache_loc=torch.tensor(slots_new, device=DEV),
+                               token_to_kv_pool=kv)
+    be = SglkAttnBackend(mr)
+    layer = _layer(0, Hq, Hkv, D)
+    if graph_state:
+        be.init_cuda_graph_state(8)
+        be.init_forward_metadata_capture_cuda_graph(B, B, fb.req_pool_indices, seq_lens)
+        be.init_forward_metadata_replay_cuda_graph(B, fb.req_pool_indices, seq_lens, sum(lens))
+    else:
+        be.init_forward_metadata(fb)
+    o = be.forward(q, k_new, v_new, layer, fb)
+    # oracle over the pool AFTER the write of the new token
+    kb, vb = kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu()
+    assert torch.equal(kb[slots_new], k_new.cpu().view(B, Hkv, D))
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    ind = torch.cat([r2t.req_to_token[b, : lens[b]].cpu() for b in range(B)])
+    want = oracle.decode_attention(q.cpu().view(B, Hq, D), kb, vb, ptr, ind, torch.ones(B, dtype=torch.int32), layer.scaling)
+    assert (o.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
+    # the same batch with the radix-tree groups handed over
+    order, gi, pl = build_prefix_groups([prefix] * B, lens, device=DEV)
+    assert order.tolist() == list(range(B)) and gi.tolist() == [0, B] and pl.tolist() == [100]
+    fb.prefix_groups = (gi, pl)
+    if graph_state:
+        be.init_forward_metadata_capture_cuda_graph(B, B, fb.req_pool_indices, seq_lens, prefix_groups=(gi, pl))
+    else:
+        be.init_forward_metadata(fb)
+    o2 = be.forward(q, k_new, v_new, layer, fb, save_kv_cache=False)
+    assert (o2.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
+
+
+def test_backend_extend_matches_oracle():
+    import oracle
+    from sglang_security_amd.attention import SglkAttnBackend
+
+    Hq, Hkv, D, B = 8, 2, 128, 3
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    g = torch.Generator().manual_seed(1)
+    pre = [40, 0, 17]
+    ext = [33, 70, 5]
+    for buf in (kv.k_buffer[1], kv.v_buffer[1]):
+        buf.copy_(torch.randn(buf.shape, generator=g).to(torch.bfloat16))
+    locs = []
+    for b in range(B):
+        p = alloc.alloc(pre[b])
+        e = alloc.alloc(ext[b])
+        r2t.req_to_token[b, : pre[b]] = p.int()
+        r2t.req_to_token[b, pre[b]: pre[b] + ext[b]] = e.int()
+        locs.append(e)
+    T = sum(ext)
+    q = torch.randn(T, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    k = torch.randn(T, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(T, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    fb = types.SimpleNamespace(forward_mode=_Mode(False), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                               seq_lens=torch.tensor([p + e for p, e in zip(pre, ext)], device=DEV),
+                               extend_prefix_lens=torch.tensor(pre, device=DEV), extend_seq_lens=torch.tensor(ext, device=DEV),
+                               out_cache_loc=torch.cat(locs), token_to_kv_pool=kv)
+    be = SglkAttnBackend(mr)
+    layer = _layer(1, Hq, Hkv, D)
+    kb0, vb0 = kv.k_buffer[1].cpu().clone(), kv.v_buffer[1].cpu().clone()
+    be.init_forward_metadata(fb)
+    o = be.forward(q, k, v, layer, fb)
+    assert torch.equal(kv.k_buffer[1][fb.out_cache_loc].cpu(), k.cpu().view(T, Hkv, D))  # new tokens were cached
+    qo = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32)
+    kp = torch.tensor([0] + list(torch.tensor(pre).cumsum(0)), dtype=torch.int32)
+    ki = torch.cat([r2t.req_to_token[b, : pre[b]].cpu() for b in range(B)])
+    want = oracle.extend_attention(q.cpu().view(T, Hq, D), k.cpu().view(T, Hkv, D), v.cpu().view(T, Hkv, D), kb0, vb0, qo,
+                                   kp, ki, layer.scaling, 0.0, True)
+    assert (o.float().cpu().view(T, Hq, D) - want).abs().max().item() < 2e-2
+
+
+def test_awq_linear_method():
+    import oracle
+    from sglang_security_amd.quantization import AWQConfig, AWQLinearMethod
+
+    cfg = AWQConfig.from_config({"w_bit": 4, "q_group_size": 128, "zero_point": True})
+    K, N = 1024, 768
+    g = torch.Generator().manual_seed(2)
+    qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, generator=g)
+    qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // 128, N // 8), dtype=torch.int32, generator=g)
+    sc = (torch.rand(K // 128, N, generator=g) * 0.01 + 0.001).to(torch.float16)
+    bias = torch.randn(N, generator=g).to(torch.float16)
+    for keep in (True, False):
+        method = AWQLinearMethod(cfg, keep_reference_layout=keep)
+        layer = torch.nn.Module()
+        method.create_weights(layer, K, [N // 2, N // 2], K, N, torch.float16, device=DEV)
+        assert layer.qweight.shape == (K, N // 8) and layer.qzeros.shape == (K // 128, N // 8) and layer.scales.shape == (K // 128, N)
+        layer.qweight.data.copy_(qw)
+        layer.qzeros.data.copy_(qz)
+        layer.scales.data.copy_(sc)
+        method.process_weights_after_loading(layer)
+        assert (layer.qweight is None) == (not keep)
+        for M in (1, 48, 300):  # decode sizes take the fused kernel, 300 rows the dequantise + matmul path
+            x = torch.randn(2, M, K, generator=g).to(torch.float16)[0:1]
+            out = method.apply(layer, x.to(DEV), bias.to(DEV))
+            assert out.shape == (1, M, N)
+            want = oracle.awq_gemm(x[0], qw, sc, qz, bias).float()
+            tol = 1e-2 * max(1.0, want.abs().max().item())
+            assert (out[0].float().cpu() - want).abs().max().item() <= tol
+    # the re-laid-out copy dequantises to the same bits as the reference layout
+    from sglang_security_amd import ops
+
+    w_ref = ops.awq_dequantize(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    w_pk = ops.awq_dequantize_packed(ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV))
+    assert torch.equal(w_ref.view(torch.int16), w_pk.view(torch.int16))
+    with pytest.raises(ValueError):
+        AWQConfig(weight_bits=8)
+
+
+def test_sgl_kernel_surface():
+    """A call of each mirrored op with the reference's argument order, against the oracle."""
+    import oracle
+    import sglang_security_amd.sgl_kernel as sk
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(9, 1024, generator=g).to(torch.float16)
+    w = torch.randn(1024, generator=g).to(torch.float16)
+    out = sk.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
+    assert torch.equal(out.cpu().view(torch.int16), oracle.rmsnorm(x, w, 1e-6).view(torch.int16))
+    res = torch.randn(9, 1024, generator=g).to(torch.float16)
+    xd, rd = x.to(DEV).clone(), res.to(DEV).clone()
+    sk.fused_add_rmsnorm(xd, rd, w.to(DEV), 1e-6)
+    wx, wr = oracle.fused_add_rmsnorm(x, res, w, 1e-6)
+    assert torch.equal(xd.cpu().view(torch.int16), wx.view(torch.int16)) and torch.equal(rd.cpu().view(torch.int16), wr.view(torch.int16))
+    a = torch.randn(2, 5, 512, generator=g).to(torch.bfloat16)
+    y = sk.silu_and_mul(a.to(DEV))
+    assert y.shape == (2, 5, 256)
+    assert torch.equal(y.cpu().view(torch.int16).reshape(10, 256), oracle.silu_and_mul(a.reshape(10, 512)).view(torch.int16))
+    with pytest.raises(ValueError):
+        sk.silu_and_mul(torch.zeros(2, 6, dtype=torch.float16, device=DEV))
+    with pytest.raises(ValueError):
+        sk.apply_rope_with_cos_sin_cache_inplace(torch.zeros(1, device=DEV), xd, xd, 128, torch.zeros(4, 128, dtype=torch.float16, device=DEV))
+    va, vb = torch.randn(4, 3, 64, generator=g), torch.randn(4, 3, 64, generator=g)
+    sa, sb = torch.randn(4, 3, generator=g), torch.randn(4, 3, generator=g)
+    vm, sm = sk.merge_state_v2(va.to(DEV), sa.to(DEV), vb.to(DEV), sb.to(DEV))
+    wv, ws = oracle.merge_state(va, sa, vb, sb)
+    torch.testing.assert_close(vm.cpu(), wv, atol=1e-5, rtol=1e-5)
+    torch.testing.assert_close(sm.cpu(), ws, atol=1e-5, rtol=1e-5)
+    sk.install("sgl_kernel_under_test")
+    import importlib
+
+    assert importlib.import_module("sgl_kernel_under_test").rmsnorm is sk.rmsnorm
