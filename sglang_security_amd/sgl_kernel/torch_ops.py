@@ -1,0 +1,79 @@
+"""`torch.ops.sgl_kernel.*` registrations for the hot-path ops, with the reference's schemas
+(sgl-kernel/csrc/common_extension.cc:48-121; the reference registers them from C++ with TORCH_LIBRARY_FRAGMENT,
+here torch.library does the same from Python and the implementations call libsglk through its C ABI).
+
+    from sglang_security_amd.sgl_kernel.torch_ops import register_torch_ops
+    register_torch_ops()        # idempotent; "CUDA" dispatch key = HIP device on ROCm
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops as _ops
+
+_SCHEMAS = {
+    "awq_dequantize": "(Tensor qweight, Tensor scales, Tensor qzeros) -> Tensor",
+    "fp8_scaled_mm": "(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype, Tensor? bias) -> Tensor",
+    "fp8_blockwise_scaled_mm": "(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype) -> Tensor",
+    "sgl_per_token_quant_fp8": "(Tensor input, Tensor output_q, Tensor output_s) -> ()",
+    "sgl_per_token_group_quant_fp8": "(Tensor input, Tensor output_q, Tensor output_s, int group_size, float eps, float fp8_min, float fp8_max) -> ()",
+    "sgl_per_tensor_quant_fp8": "(Tensor input, Tensor output_q, Tensor output_s, bool is_static) -> ()",
+    "merge_state_v2": "(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged, Tensor! s_merged) -> ()",
+    "merge_state": "(Tensor v_a, Tensor s_a, Tensor v_b, Tensor s_b, Tensor! v_merged, Tensor! s_merged) -> ()",
+    "rmsnorm": "(Tensor! output, Tensor input, Tensor weight, float eps, bool enable_pdl) -> ()",
+    "fused_add_rmsnorm": "(Tensor! input, Tensor! residual, Tensor weight, float eps, bool enable_pdl) -> ()",
+    "gemma_rmsnorm": "(Tensor! output, Tensor input, Tensor weight, float eps, bool enable_pdl) -> ()",
+    "gemma_fused_add_rmsnorm": "(Tensor! input, Tensor! residual, Tensor weight, float eps, bool enable_pdl) -> ()",
+    "silu_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
+    "gelu_tanh_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
+    "gelu_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
+    "apply_rope_pos_ids_cos_sin_cache": "(Tensor q, Tensor k, Tensor! q_rope, Tensor! k_rope, Tensor cos_sin_cache, Tensor pos_ids, bool interleave, int cuda_stream) -> ()",
+    # the fast path the reference does not have: fused dequantise + GEMM on the re-laid-out weight
+    "awq_gemm": "(Tensor x, Tensor packed, Tensor scales, Tensor qzeros, Tensor? bias, Tensor workspace) -> Tensor",
+}
+
+_lib = None
+
+
+def _rows(t):
+    return t.reshape(-1, t.shape[-1])
+
+
+def _rope(q, k, q_rope, k_rope, cos_sin_cache, pos_ids, interleave, cuda_stream):
+    if q_rope.data_ptr() != q.data_ptr():
+        q_rope.copy_(q)
+    if k_rope.data_ptr() != k.data_ptr():
+        k_rope.copy_(k)
+    _ops.rope(q_rope, k_rope, cos_sin_cache, pos_ids.long(), q.shape[-1], interleave)
+
+
+_IMPLS = {
+    "awq_dequantize": lambda qweight, scales, qzeros: _ops.awq_dequantize(qweight, scales, qzeros),
+    "fp8_scaled_mm": lambda a, b, sa, sb, dt, bias: _ops.fp8_scaled_mm(a, b, sa, sb, dt, bias),
+    "fp8_blockwise_scaled_mm": lambda a, b, sa, sb, dt: _ops.fp8_blockwise_scaled_mm(a, b, sa, sb, dt),
+    "sgl_per_token_quant_fp8": lambda x, q, s: _ops.per_token_quant_fp8(x, q, s),
+    "sgl_per_token_group_quant_fp8": lambda x, q, s, g, eps, lo, hi: _ops.per_token_group_quant_fp8(x, q, s, g, eps, lo, hi),
+    "sgl_per_tensor_quant_fp8": lambda x, q, s, st: _ops.per_tensor_quant_fp8(x, q, s, st),
+    "merge_state_v2": lambda va, sa, vb, sb, vm, sm: _ops.merge_state(va, sa, vb, sb, vm, sm),
+    "merge_state": lambda va, sa, vb, sb, vm, sm: _ops.merge_state(va, sa, vb, sb, vm, sm),
+    "rmsnorm": lambda out, x, w, eps, pdl: _ops.rmsnorm(_rows(out), _rows(x), w, eps, False),
+    "fused_add_rmsnorm": lambda x, r, w, eps, pdl: _ops.fused_add_rmsnorm(_rows(x), _rows(r), w, eps, False),
+    "gemma_rmsnorm": lambda out, x, w, eps, pdl: _ops.rmsnorm(_rows(out), _rows(x), w, eps, True),
+    "gemma_fused_add_rmsnorm": lambda x, r, w, eps, pdl: _ops.fused_add_rmsnorm(_rows(x), _rows(r), w, eps, True),
+    "silu_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 0),
+    "gelu_tanh_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 1),
+    "gelu_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 2),
+    "apply_rope_pos_ids_cos_sin_cache": _rope,
+    "awq_gemm": lambda x, packed, scales, qzeros, bias, ws: _ops.awq_gemm(x, packed, scales, qzeros, bias, None, ws),
+}
+
+
+def register_torch_ops() -> None:
+    global _lib
+    if _lib is not None:
+        return
+    lib = torch.library.Library("sgl_kernel", "FRAGMENT")
+    for name, schema in _SCHEMAS.items():
+        lib.define(name + schema)
+        lib.impl(name, _IMPLS[name], "CUDA")
+    _lib = lib  # keep the registrations alive

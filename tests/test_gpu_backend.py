@@ -233,3 +233,33 @@ def test_sgl_kernel_surface():
     import importlib
 
     assert importlib.import_module("sgl_kernel_under_test").rmsnorm is sk.rmsnorm
+
+
+def test_torch_ops_registration():
+    """torch.ops.sgl_kernel.* with the reference's schemas (common_extension.cc:48-121) dispatch to the HIP kernels."""
+    import oracle
+    from sglang_security_amd.sgl_kernel.torch_ops import register_torch_ops
+
+    register_torch_ops()
+    register_torch_ops()  # idempotent
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(5, 512, generator=g).to(torch.bfloat16)
+    w = torch.randn(512, generator=g).to(torch.bfloat16)
+    out = torch.empty_like(x, device=DEV)
+    torch.ops.sgl_kernel.rmsnorm.default(out, x.to(DEV), w.to(DEV), 1e-5, False)
+    assert torch.equal(out.cpu().view(torch.int16), oracle.rmsnorm(x, w, 1e-5).view(torch.int16))
+    a = torch.randn(5, 256, generator=g).to(torch.bfloat16)
+    o2 = torch.empty(5, 128, dtype=torch.bfloat16, device=DEV)
+    torch.ops.sgl_kernel.silu_and_mul.default(o2, a.to(DEV), 0)
+    assert torch.equal(o2.cpu().view(torch.int16), oracle.silu_and_mul(a).view(torch.int16))
+    qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (256, 16), dtype=torch.int32, generator=g)
+    qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (2, 16), dtype=torch.int32, generator=g)
+    sc = torch.rand(2, 128, generator=g).to(torch.float16)
+    wd = torch.ops.sgl_kernel.awq_dequantize.default(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    assert torch.equal(wd.cpu().view(torch.int16), oracle.awq_dequantize(qw, sc, qz).view(torch.int16))
+    a8 = (torch.randn(8, 64, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(32, 64, generator=g) * 0.5).to(torch.float8_e4m3fn)
+    sa, sb = torch.rand(8, 1, generator=g), torch.rand(32, 1, generator=g)
+    mm = torch.ops.sgl_kernel.fp8_scaled_mm.default(a8.to(DEV), b8.to(DEV).t(), sa.to(DEV), sb.to(DEV), torch.bfloat16, None)
+    want = oracle.fp8_scaled_mm(a8, b8.t(), sa, sb, torch.bfloat16)
+    torch.testing.assert_close(mm.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)

@@ -119,3 +119,43 @@ def test_large_random_consistency():
         else:
             tree.evict(rng.randrange(1, 200))
         assert tree.evictable_size() == tree.total_size()
+
+
+def test_privacy_hook_end_to_end():
+    """SafeKV flow on the native tree: nodes start private and unchecked; the judge thread promotes the ones the
+    detector calls public; children of a decided-private node inherit without a detector call; another user then
+    shares only the public part."""
+    from sglang_security_amd.private_service.private_client import PrivateJudgeClient
+
+    seen = []
+
+    def detector(text):
+        seen.append(text)
+        return "secret" in text
+
+    judge = PrivateJudgeClient(detector, num_workers=2)
+    tree = RadixCache(None, Alloc(), 1, judge, get_epoch_fn=lambda: 0)
+    pub = list(range(100, 1124))          # exactly one 1024-token chunk
+    priv = list(range(5000, 5040))
+    tree.insert(pub, torch.arange(1, 1025), "system prompt line\nUser: hi", user_id="0")
+    assert judge.drain()
+    d = tree.dump()
+    assert len(d) == 1 and d[0]["private"] is False and d[0]["need_check"] is False
+    tree.insert(pub + priv, torch.arange(1, 1065), "my secret is 42\nUser: continue", user_id="0")
+    assert judge.drain()
+    d = tree.dump()
+    assert [n["private"] for n in d] == [False, True] and [n["need_check"] for n in d] == [False, False]
+    # a third level under the decided-private node inherits at once: no detector call
+    calls = len(seen)
+    tree.insert(pub + priv + [7, 8, 9], torch.arange(1, 1068), "anything\nUser: x", user_id="0")
+    assert judge.drain()
+    assert len(seen) == calls and tree.dump()[2]["need_check"] is False and tree.dump()[2]["private"] is True
+    # another user shares the public chunk only
+    v, node = tree.match_prefix(pub + priv, user_id="someone-else")
+    assert v.tolist() == list(range(1, 1025))
+    v, node = tree.match_prefix(pub + priv, user_id="0")
+    assert len(v) == 1064
+    # the placeholder rule: lines that look like chat-template residue are public without asking the detector
+    assert PrivateJudgeClient.judged_text("a\nAssistant: b\nc") == "hello, you are an simple assistant"
+    assert PrivateJudgeClient.judged_text("only one line") == "only one line"
+    judge.close()
