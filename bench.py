@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="2-layer toy model (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-prefix-hit", action="store_true", help="skip the prefix-hit speedup measurements")
     return ap.parse_args()
 
 
@@ -127,6 +128,111 @@ def cpu_baseline(cfg, batch, prefix, suffix):
             "sample": sample}
 
 
+def measure_decode(dec, args, dev, world, share_prefix, attn):
+    """Set the batch up, capture one decode step into a graph, time K replays.  Returns (elapsed, graph_used, mode)."""
+    from sglang_security_amd.benchlib import dist_helpers, timed_steps
+
+    dec.setup_shared_prefix_batch(args.prefix, args.suffix, share=share_prefix)
+    mode = "per_request"
+    dec.enable_shared_prefix(False)
+    if share_prefix and attn in ("auto", "shared_prefix") and dec.enable_shared_prefix(True):
+        mode = "shared_prefix"
+    torch.cuda.synchronize()
+    stream = torch.cuda.Stream(dev)
+    barrier, mx = dist_helpers(world, dev)
+    with torch.cuda.stream(stream):
+        n_eager = min(2, args.warmup)
+        for _ in range(n_eager):
+            dec.step()
+        stream.synchronize()
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                dec.step()
+        run = graph.replay if graph is not None else dec.step
+        elapsed = timed_steps(run, args.steps, args.warmup - n_eager, torch.cuda.synchronize, barrier, mx)
+    return elapsed, graph is not None, mode, stream
+
+
+def gemm_roofline(dec, cfg, B, stream):
+    """The dominant kernel (fused AWQ GEMM), timed per launch with events on the launch stream."""
+    evs = []
+
+    def timer(name, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        fn()
+        b.record(stream)
+        evs.append((name, a, b))
+
+    with torch.cuda.stream(stream):
+        dec.gemm_timer = timer
+        for _ in range(2):
+            dec.step()
+        stream.synchronize()
+        dec.gemm_timer = None
+    per = {}
+    for name, a, b in evs:
+        per.setdefault(name, []).append(a.elapsed_time(b) * 1e3)
+    avg_us = sum(sum(v) for v in per.values()) / sum(len(v) for v in per.values())
+    # algorithmic bytes per launch: one layer's int4 weights + scales + zeros + bf16 in/out activations of its
+    # four projections, / 4 launches
+    shapes = ((cfg.hidden, dec.q_size + 2 * dec.kv_size), (dec.q_size, cfg.hidden), (cfg.hidden, 2 * cfg.inter),
+              (cfg.inter, cfg.hidden))
+    act = 2 * B * sum(k + n for k, n in shapes)
+    bytes_per_launch = (dec.layer_weight_bytes() + act) / 4.0
+    ach = bytes_per_launch / (avg_us * 1e-6) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("awq_gemm_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "awq_gemm_wide_kernel / awq_gemm_kernel (fused int4 dequant + MFMA GEMM, M=64)",
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+            "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
+            "per_projection_us": {k: round(sum(v) / len(v), 2) for k, v in per.items()}}
+
+
+def extend_ttft(cfg, B, prefix, suffix, dev):
+    """Prefix-hit speedup of the extend (prefill) attention of one layer: all prefix + suffix tokens new, against
+    only the suffix new over a cached prefix."""
+    from sglang_security_amd import ops
+
+    Hq, Hkv, D = cfg.q_heads, cfg.kv_heads, cfg.head_dim
+    g = torch.Generator(device=dev).manual_seed(0)
+    dt = torch.bfloat16
+    kb = torch.randn(1 + prefix, Hkv, D, device=dev, generator=g).to(dt)
+    vb = torch.randn(1 + prefix, Hkv, D, device=dev, generator=g).to(dt)
+
+    def run(ext, pre):
+        T = B * ext
+        q = torch.randn(T, Hq, D, device=dev, generator=g).to(dt)
+        k = torch.randn(T, Hkv, D, device=dev, generator=g).to(dt)
+        v = torch.randn(T, Hkv, D, device=dev, generator=g).to(dt)
+        o = torch.empty_like(q)
+        qo = (torch.arange(B + 1, device=dev) * ext).int()
+        kp = (torch.arange(B + 1, device=dev) * pre).int()
+        ki = (torch.arange(pre, device=dev, dtype=torch.int32) + 1).repeat(B) if pre else torch.zeros(1, dtype=torch.int32, device=dev)
+        f = lambda: ops.extend_attention_fwd(q, k, v, o, kb, vb, qo, kp, ki, None, True, None, ext, 1.0 / math.sqrt(D))
+        for _ in range(2):
+            f()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            f()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / 5
+
+    miss = run(prefix + suffix, 0)
+    hit = run(suffix, prefix)
+    return {"extend_attention_ms_no_hit": round(miss, 3), "extend_attention_ms_hit": round(hit, 3),
+            "extend_attention_speedup": round(miss / hit, 2)}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,102 +247,33 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)
 
-    from sglang_security_amd import ops
+    from sglang_security_amd.benchlib import aggregate
     from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
 
     cfg = LlamaConfig.tiny(args.quant) if args.tiny else LlamaConfig.llama3_8b(args.quant)
     B = args.batch
     total_steps = args.steps + args.warmup + 8
     per_req = args.suffix + total_steps + 2
-    slots = 1 + args.prefix + B * per_req
+    want_hit = not args.no_prefix_hit and world == 1
+    # pool sized for the variant without sharing too (every request holds its own copy of the prefix)
+    slots = 1 + (B * (args.prefix + per_req) if want_hit else args.prefix + B * per_req)
     max_ctx = args.prefix + per_req
     dec = LlamaDecoder(cfg, B, slots, max_ctx, device=dev)
     dec.cu_count = torch.cuda.get_device_properties(dev).multi_processor_count
-    dec.setup_shared_prefix_batch(args.prefix, args.suffix)
-    attn_mode = "per_request"
-    if args.attn in ("auto", "shared_prefix") and hasattr(dec, "enable_shared_prefix"):
-        if dec.enable_shared_prefix():
-            attn_mode = "shared_prefix"
-    torch.cuda.synchronize()
 
-    # ---- warm-up (eager), then capture one step into a graph ------------------------------------------
-    stream = torch.cuda.Stream(dev)
-    with torch.cuda.stream(stream):
-        n_eager = min(2, args.warmup)
-        for _ in range(n_eager):
-            dec.step()
-        stream.synchronize()
-        graph = None
-        if not args.no_graph:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=stream):
-                dec.step()
-        run = graph.replay if graph is not None else dec.step
-        for _ in range(args.warmup - n_eager):
-            run()
-        stream.synchronize()
+    elapsed, graphed, attn_mode, stream = measure_decode(dec, args, dev, world, True, args.attn)
+    agg = aggregate(B, args.steps, world, elapsed)
+    roof = gemm_roofline(dec, cfg, B, stream) if cfg.quant == "awq" else None
 
-        def barrier():
-            if world > 1:
-                import torch.distributed as dist
-
-                dist.barrier()
-
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            import torch.distributed as dist
-
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-
-        # ---- dominant kernel: the fused AWQ GEMM, timed per launch with events on the launch stream -------
-        roof = None
-        if cfg.quant == "awq":
-            evs = []
-
-            def timer(name, fn):
-                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a.record(stream)
-                fn()
-                b.record(stream)
-                evs.append((name, a, b))
-
-            dec.gemm_timer = timer
-            for _ in range(2):
-                dec.step()
-            stream.synchronize()
-            dec.gemm_timer = None
-            ms = [a.elapsed_time(b) for _, a, b in evs]
-            avg_s = sum(ms) / len(ms) * 1e-3
-            # algorithmic bytes per launch: one layer's int4 weights + scales + zeros + bf16 in/out
-            # activations of its four projections, / 4 launches
-            act = 2 * B * sum(k + n for k, n in ((cfg.hidden, dec.q_size + 2 * dec.kv_size), (dec.q_size, cfg.hidden),
-                                                 (cfg.hidden, 2 * cfg.inter), (cfg.inter, cfg.hidden)))
-            bytes_per_launch = (dec.layer_weight_bytes() + act) / 4.0
-            ach = bytes_per_launch / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": "awq_gemm_kernel (+xsum, split-K reduce)", "achieved": round(ach, 1),
-                    "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "bytes_per_launch": int(bytes_per_launch)}
-
-    tokens = B * args.steps * world
-    value = tokens / elapsed
     out = {
         "metric": "decode tokens/s (whole job), Llama-3-8B AWQ int4, batch 64/GPU, 1024-token shared prefix",
-        "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 activations x int4 weights (fp32 accumulate)", "data": "synthetic",
-        "config": {"workload": f"Llama-3-8B {cfg.quant} decode, batch {B}/GPU, prefix {args.prefix} shared + "
-                               f"{args.suffix} private tokens, seq_len {args.prefix + args.suffix}+step, greedy",
-                   "attention": attn_mode, "graph": graph is not None, "parallelism": f"replicas x{world}",
-                   "layers": cfg.layers},
+        "value": round(agg["value"], 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(agg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Llama-3-8B {cfg.quant} (int4 weights, G=128; bf16 activations and KV) decode, batch {B}/GPU, "
+                               f"prefix {args.prefix} shared + {args.suffix} private tokens, seq_len "
+                               f"{args.prefix + args.suffix}+step, greedy, random-init weights",
+                   "attention": attn_mode, "graph": graphed, "parallelism": f"replicas x{world}", "layers": cfg.layers},
     }
     # fraction of the HBM roofline for the whole step (unique bytes: weights + lm_head + KV with the prefix once)
     if not args.tiny:
@@ -247,6 +284,16 @@ def main():
         out["step_hbm_frac_of_8TBps"] = round(uniq / (elapsed / args.steps) / 8e12, 4)
     if roof:
         out["roofline"] = roof
+    if want_hit and not args.tiny:
+        # the same batch with the prefix NOT shared in the pool (every request walks its own 1152 slots)
+        e2, _, _, _ = measure_decode(dec, args, dev, world, False, "per_request")
+        hit = {"decode_ms_no_hit": round(e2 / args.steps * 1e3, 4), "decode_ms_hit": round(elapsed / args.steps * 1e3, 4),
+               "decode_speedup": round(e2 / elapsed, 3)}
+        try:
+            hit.update(extend_ttft(cfg, B, args.prefix, args.suffix, dev))
+        except Exception as e:  # the headline number must survive a failure here
+            hit["extend_error"] = str(e)[:200]
+        out["prefix_hit"] = hit
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, B, args.prefix, args.suffix)
