@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=64)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--dense", action="store_true")
+ap.add_argument("--eager", action="store_true", help="plain launches, no graph (counter collection)")
 ap.add_argument("--stamps", action="store_true", help="per-phase clock stamps of the wide AWQ kernel (run with SGLK_AWQ_ABL=16)")
 args = ap.parse_args()
 dev = "cuda"
@@ -72,6 +73,12 @@ for name, K, N in shapes:
                 d = (col[ok] - (t0 if t0 is not None else t[ok][:, 0])) / 100.0
                 msg.append(f"{names[k]} {d.mean():.2f}/{d.max():.2f}us")
         print("  ".join(msg), flush=True)
+        continue
+    if args.eager:
+        for i in range(args.iters):
+            run(i)
+        torch.cuda.synchronize()
+        print(f"{name}: {args.iters} eager launches", flush=True)
         continue
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):

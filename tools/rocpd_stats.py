@@ -24,3 +24,16 @@ def main(path):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+
+
+def pmc(path, pattern="awq_gemm"):
+    """Average counter value per (kernel, grid) for kernels whose name contains `pattern`, from a --pmc run."""
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, grid_size, counter_name, count(*), avg(value), min(value), max(value) "
+                      "from counters_collection where kernel_name like ? group by kernel_name, grid_size, counter_name",
+                      (f"%{pattern}%",)).fetchall()
+    out = []
+    for n, g, c, cnt, a, mn, mx in rows:
+        short = re.sub(r"\(.*", "", re.sub(r"\s+", " ", n))
+        out.append(dict(kernel=short, grid=g, counter=c, launches=cnt, avg=a, min=mn, max=mx))
+    return out
