@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="2-layer toy model (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-fusion", action="store_true", help="plain op sequence per layer (no partial / block-sum hand-over)")
     ap.add_argument("--no-prefix-hit", action="store_true", help="skip the prefix-hit speedup measurements")
     return ap.parse_args()
 
@@ -263,6 +264,7 @@ def main():
     max_ctx = args.prefix + per_req
     dec = LlamaDecoder(cfg, B, slots, max_ctx, device=dev)
     dec.cu_count = torch.cuda.get_device_properties(dev).multi_processor_count
+    fused = (not args.no_fusion) and dec.enable_fusion(True)
 
     elapsed, graphed, attn_mode, stream = measure_decode(dec, args, dev, world, True, args.attn)
     agg = aggregate(B, args.steps, world, elapsed)
@@ -276,7 +278,7 @@ def main():
         "config": {"workload": f"Llama-3-8B {cfg.quant} (int4 weights, G=128; bf16 activations and KV) decode, batch {B}/GPU, "
                                f"prefix {args.prefix} shared + {args.suffix} private tokens, seq_len "
                                f"{args.prefix + args.suffix}+step, greedy, random-init weights",
-                   "attention": attn_mode, "graph": graphed, "parallelism": f"replicas x{world}", "layers": cfg.layers},
+                   "attention": attn_mode, "layer_fusion": bool(fused), "graph": graphed, "parallelism": f"replicas x{world}", "layers": cfg.layers},
     }
     # fraction of the HBM roofline for the whole step (unique bytes: weights + lm_head + KV with the prefix once)
     if not args.tiny:

@@ -207,6 +207,63 @@ SGLK_API int sglk_awq_gemm(const void* x, const int32_t* packed, const void* sca
                            int M, int N, int K, int group_size, int64_t x_stride, int64_t out_stride,
                            int dtype, void* stream);
 
+/* ---- fusion forms of the decode layer --------------------------------------------------------------
+ * None of these has a counterpart in the reference, which runs norm / GEMM / rope / activation as separate
+ * ops; they are for callers that own the whole decoder layer (the graph-captured decode step).  Two ideas:
+ *  (1) block sums: the fused AWQ GEMM needs X[g][m] = sum of x[m, 128g .. 128g+127]; the kernel that produces
+ *      x can write them (xsum [K/128][xs_stride] fp32, xs_stride >= M) and the GEMM then skips its own pass;
+ *  (2) split-K partials: the GEMM stores fp32 partial[split][M][N] (row-major, split stride M*N) and the
+ *      consumer adds the splits up, rounds once to the activation type (the value the GEMM would have
+ *      stored) and carries on -- no last-block reduction inside the GEMM. */
+/* sglk_awq_gemm with the block sums of x supplied (xsum may be NULL: computed in the kernel). */
+SGLK_API int sglk_awq_gemm_xs(const void* x, const int32_t* packed, const void* scales,
+                              const int32_t* qzeros, const void* bias, void* out, float* workspace, int M,
+                              int N, int K, int group_size, int64_t x_stride, int64_t out_stride, int dtype,
+                              const float* xsum, int64_t xs_stride, void* stream);
+/* Number of splits sglk_awq_gemm_partial writes for this shape; 0: shape not covered by the partial form
+ * (needs K % 512 == 0, N % 128 == 0, group size 128). */
+SGLK_API int sglk_awq_gemm_partial_splits(int M, int N, int K, int group_size);
+SGLK_API int sglk_awq_gemm_partial(const void* x, const int32_t* packed, const void* scales,
+                                   const int32_t* qzeros, const float* xsum, int64_t xs_stride,
+                                   float* partial, int M, int N, int K, int group_size, int64_t x_stride,
+                                   int dtype, void* stream);
+/* fused_add_rmsnorm (residual may be NULL: plain rmsnorm in place) whose input row may be given as split-K
+ * partials (+bias) instead of x, and which may write the block sums of its output.  16-bit types,
+ * hidden % 128 == 0, hidden <= 8192. */
+SGLK_API int sglk_fused_add_rmsnorm_ex(void* x, void* residual, const void* weight, int64_t rows, int hidden,
+                                       float eps, int gemma, int dtype, const float* partials, int splits,
+                                       int64_t part_stride, const void* bias, float* xsum_out,
+                                       int64_t xs_stride, void* stream);
+/* sglk_act_and_mul that also writes the block sums of its output rows (d % 128 == 0). */
+SGLK_API int sglk_act_and_mul_xs(void* out, const void* x, int64_t rows, int d, int act, int dtype,
+                                 float* xsum_out, int64_t xs_stride, void* stream);
+/* sglk_rope_and_store_kv on a qkv row first assembled from split-K partials (written to qkv). */
+SGLK_API int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits,
+                                            int64_t part_stride, const void* bias,
+                                            const float* cos_sin_cache, const int64_t* positions,
+                                            void* k_buffer, void* v_buffer, const void* loc, int loc_is64,
+                                            int64_t tokens, int q_heads, int kv_heads, int head_size,
+                                            int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                                            int interleave, int dtype, void* stream);
+/* Decode attention that also writes the block sums of its output rows (Dv == 128: one head per block;
+ * xsum_out [Hq][xs_stride], xs_stride >= B). */
+SGLK_API int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                      const int32_t* kv_indptr, const int32_t* kv_indices,
+                                      float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                                      int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
+                                      int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n,
+                                      int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                      int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+                                      float logit_cap, int dtype, float* xsum_out, int64_t xs_stride,
+                                      void* stream);
+SGLK_API int sglk_decode_attention_shared_prefix_xs(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, const int32_t* group_indptr, const int32_t* prefix_lens, int G,
+    float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+    int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, float* xsum_out,
+    int64_t xs_stride, void* stream);
+
 /* Skinny dense GEMM out[M,N] = x[M,K] @ W[N,K]^T (+bias), bf16/fp16, for the unquantised lm_head and
  * the bf16 configuration (UnquantizedLinearMethod.apply, python/sglang/srt/layers/linear.py:170-186;
  * CPU twin weight_packed_linear, sgl-kernel/csrc/cpu/gemm.cpp). */

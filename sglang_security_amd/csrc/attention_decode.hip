@@ -235,7 +235,9 @@ __global__ void __launch_bounds__(128) decode_stage2(const float* __restrict__ a
                                                      const float* __restrict__ attn_lse, void* __restrict__ o,
                                                      const int32_t* __restrict__ kv_indptr,
                                                      const int32_t* __restrict__ num_kv_splits, int max_kv_splits,
-                                                     int Hq, int Dv, int64_t o_stride_b, int64_t o_stride_h) {
+                                                     int Hq, int Dv, int64_t o_stride_b, int64_t o_stride_h,
+                                                     float* __restrict__ xsum_out, int64_t xs_stride) {
+  __shared__ float xs_red[2];
   const int b = blockIdx.x, h = blockIdx.y;
   const int len = kv_indptr[b + 1] - kv_indptr[b];
   const int splits = max(num_kv_splits[b], 1);
@@ -256,6 +258,12 @@ __global__ void __launch_bounds__(128) decode_stage2(const float* __restrict__ a
       }
     }
     st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d, acc / e_sum);
+    if (xsum_out) {  // Dv == 128: one head is one 128-element block of the following projection's input row
+      const float r = wave_sum(Conv<T>::to_f32(Conv<T>::from_f32(acc / e_sum)));
+      if ((threadIdx.x & 63) == 0) xs_red[threadIdx.x >> 6] = r;
+      __syncthreads();
+      if (threadIdx.x == 0) xsum_out[(int64_t)h * xs_stride + b] = xs_red[0] + xs_red[1];
+    }
   }
 }
 
@@ -512,7 +520,8 @@ __global__ void __launch_bounds__(128) decode_group_merge_kernel(
     const float* __restrict__ part_o, const float* __restrict__ part_lse, void* __restrict__ o,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ group_indptr,
     const int32_t* __restrict__ prefix_lens, int num_groups, int prefix_splits, int tail_max_splits, int Hq,
-    int64_t o_stride_b, int64_t o_stride_h) {
+    int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out, int64_t xs_stride) {
+  __shared__ float xs_red[2];
   const int b = blockIdx.x, h = blockIdx.y;
   const int plen = prefix_lens[find_group(group_indptr, num_groups, b)];
   const int tlen = kv_indptr[b + 1] - kv_indptr[b] - plen;
@@ -534,6 +543,12 @@ __global__ void __launch_bounds__(128) decode_group_merge_kernel(
     e_max = n_max;
   }
   st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d, acc / e_sum);
+  if (xsum_out) {
+    const float r = wave_sum(Conv<T>::to_f32(Conv<T>::from_f32(acc / e_sum)));
+    if ((threadIdx.x & 63) == 0) xs_red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) xsum_out[(int64_t)h * xs_stride + b] = xs_red[0] + xs_red[1];
+  }
 }
 
 }  // namespace sglk
@@ -598,12 +613,13 @@ int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_stride, cons
   return SGLK_OK;
 }
 
-int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
-                          const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
-                          int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
-                          int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-                          int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
-                          int dtype, void* stream) {
+int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+                             const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                             int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+                             int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                             int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+                             int dtype, float* xsum_out, int64_t xs_stride, void* stream) {
+  SGLK_CHECK(!xsum_out || (Dv == 128 && xs_stride >= B), "decode_attention: block sums need Dv == 128 and xs_stride >= B");
   SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && attn_logits && attn_lse && num_kv_splits,
              "decode_attention: null pointer");
   SGLK_CHECK(B >= 0 && Hq > 0 && Hkv > 0 && D > 0 && Dv > 0, "decode_attention: bad shape");
@@ -653,9 +669,22 @@ int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buf
   SGLK_LAUNCH_CHECK();
   SGLK_DISPATCH_FLOAT(dtype, T,
                       hipLaunchKernelGGL((decode_stage2<T>), dim3(B, Hq), dim3(128), 0, s, attn_logits, attn_lse, o,
-                                         kv_indptr, num_kv_splits, max_kv_splits, Hq, Dv, o_stride_b, o_stride_h));
+                                         kv_indptr, num_kv_splits, max_kv_splits, Hq, Dv, o_stride_b, o_stride_h,
+                                         xsum_out, xs_stride));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+                          const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                          int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+                          int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                          int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+                          int dtype, void* stream) {
+  return sglk_decode_attention_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                                  max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b, q_stride_h, k_stride_n, k_stride_h,
+                                  v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, nullptr, 0,
+                                  stream);
 }
 
 static constexpr int kTailMaxSplits = 4;  // remainder splits per request (one block of four waves)
@@ -665,13 +694,15 @@ int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_spl
   return (int64_t)B * Hq * (max_kv_splits + kTailMaxSplits) * (Dv + 1) * (int64_t)sizeof(float);
 }
 
-int sglk_decode_attention_shared_prefix(const void* q, const void* k_buffer, const void* v_buffer, void* o,
-                                        const int32_t* kv_indptr, const int32_t* kv_indices,
-                                        const int32_t* group_indptr, const int32_t* prefix_lens, int G, float* workspace,
-                                        int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
-                                        int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-                                        int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
-                                        float logit_cap, int dtype, void* stream) {
+int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                           const int32_t* kv_indptr, const int32_t* kv_indices,
+                                           const int32_t* group_indptr, const int32_t* prefix_lens, int G,
+                                           float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
+                                           int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                           int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                           float sm_scale, float logit_cap, int dtype, float* xsum_out, int64_t xs_stride,
+                                           void* stream) {
+  SGLK_CHECK(!xsum_out || xs_stride >= B, "decode_attention_shared_prefix: xs_stride smaller than B");
   SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
              "decode_attention_shared_prefix: null pointer");
   SGLK_CHECK(B >= 0 && G > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
@@ -713,8 +744,21 @@ int sglk_decode_attention_shared_prefix(const void* q, const void* k_buffer, con
   SGLK_DISPATCH_HALF(dtype, T,
                      hipLaunchKernelGGL((decode_group_merge_kernel<T>), dim3(B, Hq), dim3(128), 0, s, part_o, part_lse, o,
                                         kv_indptr, group_indptr, prefix_lens, G, max_kv_splits, kTailMaxSplits, Hq,
-                                        o_stride_b, o_stride_h));
+                                        o_stride_b, o_stride_h, xsum_out, xs_stride));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_decode_attention_shared_prefix(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                        const int32_t* kv_indptr, const int32_t* kv_indices,
+                                        const int32_t* group_indptr, const int32_t* prefix_lens, int G, float* workspace,
+                                        int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+                                        int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                        int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+                                        float logit_cap, int dtype, void* stream) {
+  return sglk_decode_attention_shared_prefix_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens,
+                                                G, workspace, max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b, q_stride_h,
+                                                k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h,
+                                                sm_scale, logit_cap, dtype, nullptr, 0, stream);
 }
 }

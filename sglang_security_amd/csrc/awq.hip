@@ -479,18 +479,22 @@ struct Wide {
   static constexpr int kStageK = 512;
   static constexpr int kXStage = 4 * 64 * 256;          // 64 KiB
   static constexpr int kSzOff = 2 * kXStage;            // [3][8 waves][256 B]
-  static constexpr int kXsumOff = kSzOff + 3 * 8 * 256;  // float [2][4][64]
-  static constexpr int kFlagOff = kXsumOff + 2 * 4 * 64 * 4;
+  static constexpr int kXsumOff = kSzOff + 3 * 8 * 256;  // float [2][4][64] computed here, or [2][8 waves][64] fetched
+  static constexpr int kFlagOff = kXsumOff + 2 * 8 * 64 * 4;
   static constexpr int kLds = kFlagOff + 16;
   static constexpr int kTileFloats = 64 * 128;
 };
 
-template <typename T>
+// XS_EXT: the block sums X[group][row] come from the kernel that produced x (xsum_in, row stride xs_stride) instead
+// of being computed here: one barrier per stage instead of two.  partial_mode: every split stores its fp32 tile
+// row-major to partial[split][M][N] and returns; the consumer kernel adds the splits up.
+template <typename T, bool XS_EXT>
 __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     const uint16_t* __restrict__ x, const int32_t* __restrict__ packed, const uint16_t* __restrict__ scales,
     const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
     float* __restrict__ partial, int* __restrict__ tickets, int M, int N, int K, int stages_per_split, int splits,
-    int64_t x_stride, int64_t out_stride, int abl) {
+    int64_t x_stride, int64_t out_stride, int abl, const float* __restrict__ xsum_in, int64_t xs_stride,
+    int partial_mode) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xsumS = reinterpret_cast<float*>(smem + Wide::kXsumOff);
   int* flag = reinterpret_cast<int*>(smem + Wide::kFlagOff);
@@ -530,6 +534,11 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024;
 #pragma unroll
     for (int j = 0; j < 8; ++j) glds16(src + xoff[j], dst + j * 1024);
+    if constexpr (XS_EXT) {
+      // this wave's group of the stage: 64 row sums, one per lane, into the wave's own slot
+      const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
+      glds4(xsum_in + (int64_t)gq * xs_stride + min(m0 + lane, M - 1), smem + Wide::kXsumOff + (buf * 8 + wid) * 256);
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -612,10 +621,12 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   stage_wait(wreg[0]);  // sz(0), w(0), x(0) landed; sz(1) and w(1) fly on
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  xsum_pass(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
+  if constexpr (!XS_EXT) {
+    xsum_pass(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
 
   stamp(1);
   const int npad = (nst + 2) / 3 * 3;  // register set = unroll index; padded stages only keep the pipeline counts
@@ -675,7 +686,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
         }
         // zero-point term with this group's block sums
         {
-          const float* xp = xsumS + (buf * 4 + kw) * 64;
+          const float* xp = xsumS + (XS_EXT ? (buf * 8 + wid) : (buf * 4 + kw)) * 64;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 16 * q + 4 * g);
@@ -692,10 +703,12 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       stamp_in(i, 4);
-      if (!(abl & 1)) xsum_pass(buf ^ 1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
+      if constexpr (!XS_EXT) {
+        if (!(abl & 1)) xsum_pass(buf ^ 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
       stamp_in(i, 5);
     }
   }
@@ -730,6 +743,18 @@ stages_done:
   // lane (i16, g) of wave (kw, nw) now holds rows 16q + 4g + r of column n0 + 16*kw + i16
   const int n = n0 + 16 * kw + i16;
   stamp(3);
+  if (partial_mode) {
+    float* dst = partial + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * q + 4 * g + r;
+        if (m < M) dst[(int64_t)m * N + n] = fin[q][r];
+      }
+    stamp(4);
+    return;
+  }
   if (splits == 1) {
     const float bv = bias ? Conv<T>::to_f32(bias[n]) : 0.f;
 #pragma unroll
@@ -851,7 +876,7 @@ struct WidePlan {
 };
 
 // The wide kernel needs K in whole 512-k stages, N in whole 128-column tiles and 128-k scale groups.
-static WidePlan plan_awq_wide(int M, int N, int K, int group_size) {
+static WidePlan plan_awq_wide(int M, int N, int K, int group_size, bool partial_mode = false) {
   // 0: never, 1: where it is expected to be faster, 2: wherever the shape allows (read per call: a test hook)
   const char* env_wide_s = getenv("SGLK_AWQ_WIDE");
   const int env_wide = env_wide_s ? atoi(env_wide_s) : 1;
@@ -869,7 +894,7 @@ static WidePlan plan_awq_wide(int M, int N, int K, int group_size) {
   for (int sps = 1; sps <= total; ++sps) {
     const int splits = (total + sps - 1) / sps;
     const int rounds = (p.tiles * splits + 255) / 256;
-    const float cost = rounds * (sps + 2.0f) + (splits > 1 ? 0.25f * splits : 0.f);
+    const float cost = rounds * (sps + 2.0f) + (splits > 1 && !partial_mode ? 0.25f * splits : 0.f);
     if (cost < best) {
       best = cost;
       best_sps = sps;
@@ -879,7 +904,7 @@ static WidePlan plan_awq_wide(int M, int N, int K, int group_size) {
   p.stages_per_split = best_sps;
   p.splits = (total + best_sps - 1) / best_sps;
   // a block that would run a single stage is all fill and drain: the narrow kernel is faster there
-  if (best_sps < 2 && env_wide < 2) p.ok = false;
+  if (best_sps < 2 && env_wide < 2 && !partial_mode) p.ok = false;
   return p;
 }
 
@@ -939,9 +964,57 @@ int64_t sglk_awq_gemm_workspace_bytes(int M, int N, int K) {
   return bytes + (int64_t)kMaxTiles * 4;
 }
 
-int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, const void* bias,
-                  void* out, float* workspace, int M, int N, int K, int group_size, int64_t x_stride,
-                  int64_t out_stride, int dtype, void* stream) {
+static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* packed, const void* scales,
+                           const int32_t* qzeros, const void* bias, void* out, float* partial, int* tickets, int M, int N,
+                           int K, int64_t x_stride, int64_t out_stride, int dtype, const float* xsum, int64_t xs_stride,
+                           int partial_mode, hipStream_t s) {
+  static const int env_abl = getenv("SGLK_AWQ_ABL") ? atoi(getenv("SGLK_AWQ_ABL")) : 0;  // timing experiments only
+  dim3 wgrid(N / 128, wp.splits, wp.mblocks);
+#define SGLK_WIDE_LAUNCH(XS)                                                                                       \
+  {                                                                                                                \
+    static bool attr_set = false;                                                                                  \
+    if (!attr_set) {                                                                                               \
+      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_wide_kernel<T, XS>),                    \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));                       \
+      attr_set = true;                                                                                             \
+    }                                                                                                              \
+    hipLaunchKernelGGL((awq_gemm_wide_kernel<T, XS>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x, packed, \
+                       (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial, tickets, M, N, \
+                       K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl, xsum, xs_stride,          \
+                       partial_mode);                                                                              \
+  }
+  SGLK_DISPATCH_HALF(dtype, T, {
+    if (xsum) SGLK_WIDE_LAUNCH(true) else SGLK_WIDE_LAUNCH(false)
+  });
+#undef SGLK_WIDE_LAUNCH
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_awq_gemm_partial_splits(int M, int N, int K, int group_size) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const WidePlan wp = plan_awq_wide(M, N, K, group_size, true);
+  return wp.ok ? wp.splits : 0;
+}
+
+int sglk_awq_gemm_partial(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros,
+                          const float* xsum, int64_t xs_stride, float* partial, int M, int N, int K, int group_size,
+                          int64_t x_stride, int dtype, void* stream) {
+  SGLK_CHECK(x && packed && scales && qzeros && partial, "awq_gemm_partial: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0, "awq_gemm_partial: bad shape");
+  SGLK_CHECK(aligned16(x) && x_stride % 8 == 0, "awq_gemm_partial: x rows must be 16-byte aligned");
+  SGLK_CHECK(!xsum || xs_stride >= M, "awq_gemm_partial: xs_stride smaller than M");
+  const WidePlan wp = plan_awq_wide(M, N, K, group_size, true);
+  if (!wp.ok)
+    return fail(SGLK_EUNSUP, "awq_gemm_partial: needs K %% 512 == 0, N %% 128 == 0 and group size 128 (K=%d N=%d G=%d)", K,
+                N, group_size);
+  return launch_awq_wide(wp, x, packed, scales, qzeros, nullptr, nullptr, partial, nullptr, M, N, K, x_stride, N, dtype,
+                         xsum, xs_stride, 1, (hipStream_t)stream);
+}
+
+int sglk_awq_gemm_xs(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, const void* bias,
+                     void* out, float* workspace, int M, int N, int K, int group_size, int64_t x_stride,
+                     int64_t out_stride, int dtype, const float* xsum, int64_t xs_stride, void* stream) {
   SGLK_CHECK(x && packed && scales && qzeros && out && workspace, "awq_gemm: null pointer");
   SGLK_CHECK(M > 0 && N > 0 && K > 0, "awq_gemm: bad shape");
   SGLK_CHECK(K % 128 == 0, "awq_gemm: K=%d must be a multiple of 128", K);
@@ -951,27 +1024,14 @@ int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, cons
   SGLK_CHECK(aligned16(x) && x_stride % 8 == 0, "awq_gemm: x rows must be 16-byte aligned");
   SGLK_CHECK(out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7) == 0, "awq_gemm: out rows must be 8-byte aligned");
   SGLK_CHECK(aligned16(workspace), "awq_gemm: workspace must be 16-byte aligned");
+  SGLK_CHECK(!xsum || xs_stride >= M, "awq_gemm: xs_stride smaller than M");
   hipStream_t s = (hipStream_t)stream;
   int* tickets = reinterpret_cast<int*>(workspace);
   float* partial = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + (int64_t)kMaxTiles * 4);
   const WidePlan wp = plan_awq_wide(M, N, K, group_size);
-  static const int env_abl = getenv("SGLK_AWQ_ABL") ? atoi(getenv("SGLK_AWQ_ABL")) : 0;  // timing experiments only
-  if (wp.ok && wp.tiles <= kMaxTiles && aligned16(out) && out_stride % 8 == 0) {
-    dim3 wgrid(N / 128, wp.splits, wp.mblocks);
-    SGLK_DISPATCH_HALF(dtype, T, {
-      static bool attr_set = false;
-      if (!attr_set) {
-        SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_wide_kernel<T>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));
-        attr_set = true;
-      }
-      hipLaunchKernelGGL((awq_gemm_wide_kernel<T>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x, packed,
-                         (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial, tickets, M, N,
-                         K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl);
-    });
-    SGLK_LAUNCH_CHECK();
-    return SGLK_OK;
-  }
+  if (wp.ok && wp.tiles <= kMaxTiles && aligned16(out) && out_stride % 8 == 0)
+    return launch_awq_wide(wp, x, packed, scales, qzeros, bias, out, partial, tickets, M, N, K, x_stride, out_stride,
+                           dtype, xsum, xs_stride, 0, s);
   const GemmPlan p = plan_awq_gemm(M, N, K);
   SGLK_CHECK(p.tiles <= kMaxTiles, "awq_gemm: too many output tiles (%d)", p.tiles);
   dim3 grid(N / (16 * p.nw * p.tn), p.splits, p.mblocks);
@@ -1002,5 +1062,12 @@ int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, cons
 #undef SGLK_AWQ_LAUNCH
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, const void* bias,
+                  void* out, float* workspace, int M, int N, int K, int group_size, int64_t x_stride,
+                  int64_t out_stride, int dtype, void* stream) {
+  return sglk_awq_gemm_xs(x, packed, scales, qzeros, bias, out, workspace, M, N, K, group_size, x_stride, out_stride,
+                          dtype, nullptr, 0, stream);
 }
 }

@@ -129,6 +129,128 @@ static int launch_rmsnorm(void* out, const void* x, void* residual, const void* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fusion forms of the decode layer (no counterpart in the reference, which runs these steps as separate ops):
+//   * the input row may arrive as split-K partials of the preceding GEMM: x = round_T(sum_s partial[s][row][:] + bias),
+//     the value that GEMM would have stored;
+//   * the output row's sums over blocks of 128 elements (of the ROUNDED values, i.e. of what the next GEMM reads)
+//     may be written to xsum[block][row] for the following fused AWQ GEMM.
+// 16-bit types, hidden % 128 == 0, hidden <= 8192.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) rmsnorm_fused_kernel(void* __restrict__ xio, void* __restrict__ residual,
+                                                            const void* __restrict__ w, int hidden, float eps, int gemma,
+                                                            const float* __restrict__ partials, int splits,
+                                                            int64_t part_stride, const void* __restrict__ bias,
+                                                            float* __restrict__ xsum_out, int64_t xs_stride) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  uint16_t* x = reinterpret_cast<uint16_t*>(xio) + row * hidden;
+  uint16_t* res = residual ? reinterpret_cast<uint16_t*>(residual) + row * hidden : nullptr;
+  const uint16_t* wr = reinterpret_cast<const uint16_t*>(w);
+  const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
+  constexpr int MAXV = 4;
+  float keep[MAXV][8];
+  float ss = 0.f;
+  const int nvec = hidden >> 3;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 256;
+    if (v < nvec) {
+      if (partials) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < splits; ++s2) {
+          const float* pr = partials + (int64_t)s2 * part_stride + row * hidden + 8 * v;
+          const float4v a = *reinterpret_cast<const float4v*>(pr), b = *reinterpret_cast<const float4v*>(pr + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[j] += a[j];
+            acc[4 + j] += b[j];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float bj = br ? Conv<T>::to_f32(br[8 * v + j]) : 0.f;
+          keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32(acc[j] + bj));  // what the GEMM would have stored
+        }
+      } else {
+        const short8 xv = reinterpret_cast<const short8*>(x)[v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keep[it][j] = Conv<T>::to_f32((uint16_t)xv[j]);
+      }
+      if (res) {
+        const short8 rv = reinterpret_cast<const short8*>(res)[v];
+        short8 ro;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          keep[it][j] += Conv<T>::to_f32((uint16_t)rv[j]);
+          ro[j] = (short)Conv<T>::from_f32(keep[it][j]);
+        }
+        reinterpret_cast<short8*>(res)[v] = ro;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += keep[it][j] * keep[it][j];
+    }
+  }
+  const float tot = block_sum(ss, red);
+  const float inv = rsqrtf(tot / (float)hidden + eps);
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 256;
+    if (v < nvec) {  // uniform over each group of 16 lanes: hidden % 128 == 0
+      const short8 wv = reinterpret_cast<const short8*>(wr)[v];
+      short8 ov;
+      float bs = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float wf = Conv<T>::to_f32((uint16_t)wv[j]);
+        if (gemma) wf += 1.0f;
+        const uint16_t o = Conv<T>::from_f32((keep[it][j] * inv) * wf);
+        ov[j] = (short)o;
+        bs += Conv<T>::to_f32(o);
+      }
+      reinterpret_cast<short8*>(x)[v] = ov;
+      if (xsum_out) {
+#pragma unroll
+        for (int o2 = 8; o2 > 0; o2 >>= 1) bs += __shfl_xor(bs, o2, 16);
+        if ((threadIdx.x & 15) == 0) xsum_out[(int64_t)(v >> 4) * xs_stride + row] = bs;
+      }
+    }
+  }
+}
+
+// act_and_mul that also writes the 128-element block sums of its (rounded) output rows
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) act_and_mul_xs_kernel(void* __restrict__ out, const void* __restrict__ xin,
+                                                             int64_t rows, int d, float* __restrict__ xsum_out,
+                                                             int64_t xs_stride);
+
+// rope_store over a qkv row that is first assembled from split-K partials (written to qkv, as the GEMM would)
+template <typename T>
+__global__ void __launch_bounds__(256) qkv_from_partials_kernel(void* __restrict__ qkv, const float* __restrict__ partials,
+                                                                int splits, int64_t part_stride, int row_len,
+                                                                const void* __restrict__ bias) {
+  const int64_t t = blockIdx.x;
+  uint16_t* dst = reinterpret_cast<uint16_t*>(qkv) + t * row_len;
+  const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
+  for (int v = threadIdx.x; v < (row_len >> 3); v += 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s2 = 0; s2 < splits; ++s2) {
+      const float* pr = partials + (int64_t)s2 * part_stride + t * row_len + 8 * v;
+      const float4v a = *reinterpret_cast<const float4v*>(pr), b = *reinterpret_cast<const float4v*>(pr + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] += a[j];
+        acc[4 + j] += b[j];
+      }
+    }
+    short8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (short)Conv<T>::from_f32(acc[j] + (br ? Conv<T>::to_f32(br[8 * v + j]) : 0.f));
+    reinterpret_cast<short8*>(dst)[v] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // act_and_mul: out = act(x[:, :d]) * x[:, d:]; act rounded to T before the product
 // (activation.cu:22-50 of the reference: silu returns T, then T*T)
 // ---------------------------------------------------------------------------------------------
@@ -304,6 +426,35 @@ __global__ void __launch_bounds__(256) merge_state_kernel(const void* __restrict
   }
 }
 
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) act_and_mul_xs_kernel(void* __restrict__ out, const void* __restrict__ xin,
+                                                             int64_t rows, int d, float* __restrict__ xsum_out,
+                                                             int64_t xs_stride) {
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(xin);
+  uint16_t* o = reinterpret_cast<uint16_t*>(out);
+  const int nv = d >> 3;  // d % 128 == 0: every aligned group of 16 threads covers one 128-element block of one row
+  const int64_t total = rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / nv;
+    const int c = (int)(i - r * nv);
+    const short8 a = reinterpret_cast<const short8*>(x + r * 2 * d)[c];
+    const short8 g = reinterpret_cast<const short8*>(x + r * 2 * d + d)[c];
+    short8 ov;
+    float bs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sv = Conv<T>::to_f32(Conv<T>::from_f32(act_fn<ACT>(Conv<T>::to_f32((uint16_t)a[j]))));
+      const uint16_t ob = Conv<T>::from_f32(sv * Conv<T>::to_f32((uint16_t)g[j]));
+      ov[j] = (short)ob;
+      bs += Conv<T>::to_f32(ob);
+    }
+    reinterpret_cast<short8*>(o + r * d)[c] = ov;
+#pragma unroll
+    for (int o2 = 8; o2 > 0; o2 >>= 1) bs += __shfl_xor(bs, o2, 16);
+    if ((threadIdx.x & 15) == 0) xsum_out[(int64_t)(c >> 4) * xs_stride + r] = bs;
+  }
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -421,5 +572,73 @@ int sglk_merge_state(const void* v_a, const float* s_a, const void* v_b, const f
                                          s_a, v_b, s_b, v_out, s_out, nh, d));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_fused_add_rmsnorm_ex(void* x, void* residual, const void* weight, int64_t rows, int hidden, float eps, int gemma,
+                              int dtype, const float* partials, int splits, int64_t part_stride, const void* bias,
+                              float* xsum_out, int64_t xs_stride, void* stream) {
+  SGLK_CHECK(x && weight, "fused_add_rmsnorm_ex: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0 && hidden % 128 == 0 && hidden <= 8192,
+             "fused_add_rmsnorm_ex: hidden=%d must be a multiple of 128, at most 8192", hidden);
+  SGLK_CHECK(dtype == SGLK_F16 || dtype == SGLK_BF16, "fused_add_rmsnorm_ex: 16-bit types only");
+  SGLK_CHECK(aligned16(x) && (!residual || aligned16(residual)) && aligned16(weight) && (!partials || aligned16(partials)),
+             "fused_add_rmsnorm_ex: pointers must be 16-byte aligned");
+  SGLK_CHECK(!partials || (splits >= 1 && part_stride >= rows * hidden && part_stride % 4 == 0),
+             "fused_add_rmsnorm_ex: bad partial layout");
+  SGLK_CHECK(!xsum_out || xs_stride >= rows, "fused_add_rmsnorm_ex: xs_stride smaller than the row count");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((rmsnorm_fused_kernel<T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                                        x, residual, weight, hidden, eps, gemma, partials, splits, part_stride, bias,
+                                        xsum_out, xs_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_act_and_mul_xs(void* out, const void* x, int64_t rows, int d, int act, int dtype, float* xsum_out,
+                        int64_t xs_stride, void* stream) {
+  SGLK_CHECK(out && x && xsum_out, "act_and_mul_xs: null pointer");
+  SGLK_CHECK(rows >= 0 && d > 0 && d % 128 == 0, "act_and_mul_xs: d=%d must be a multiple of 128", d);
+  SGLK_CHECK(act >= 0 && act <= 2, "act_and_mul_xs: unknown activation %d", act);
+  SGLK_CHECK(dtype == SGLK_F16 || dtype == SGLK_BF16, "act_and_mul_xs: 16-bit types only");
+  SGLK_CHECK(aligned16(out) && aligned16(x) && xs_stride >= rows, "act_and_mul_xs: alignment / stride");
+  if (rows == 0) return SGLK_OK;
+  int blocks = (int)((rows * (d >> 3) + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipStream_t s = (hipStream_t)stream;
+#define SGLK_ACTX(ACT) \
+  hipLaunchKernelGGL((act_and_mul_xs_kernel<T, ACT>), dim3(blocks), dim3(256), 0, s, out, x, rows, d, xsum_out, xs_stride)
+  SGLK_DISPATCH_HALF(dtype, T, {
+    if (act == 0) {
+      SGLK_ACTX(0);
+    } else if (act == 1) {
+      SGLK_ACTX(1);
+    } else {
+      SGLK_ACTX(2);
+    }
+  });
+#undef SGLK_ACTX
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits, int64_t part_stride, const void* bias,
+                                   const float* cos_sin_cache, const int64_t* positions, void* k_buffer, void* v_buffer,
+                                   const void* loc, int loc_is64, int64_t tokens, int q_heads, int kv_heads,
+                                   int head_size, int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                                   int interleave, int dtype, void* stream) {
+  SGLK_CHECK(qkv && partials, "rope_and_store_kv_partial: null pointer");
+  const int64_t row_len = (int64_t)(q_heads + 2 * kv_heads) * head_size;
+  SGLK_CHECK(splits >= 1 && row_len % 8 == 0 && part_stride >= tokens * row_len && part_stride % 4 == 0 &&
+                 aligned16(partials) && aligned16(qkv),
+             "rope_and_store_kv_partial: bad partial layout");
+  SGLK_CHECK(dtype == SGLK_F16 || dtype == SGLK_BF16, "rope_and_store_kv_partial: 16-bit types only");
+  if (tokens == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((qkv_from_partials_kernel<T>), dim3((unsigned)tokens), dim3(256), 0,
+                                        (hipStream_t)stream, qkv, partials, splits, part_stride, (int)row_len, bias));
+  SGLK_LAUNCH_CHECK();
+  return sglk_rope_and_store_kv(qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, tokens, q_heads,
+                                kv_heads, head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave, dtype, stream);
 }
 }

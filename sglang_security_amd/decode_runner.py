@@ -129,6 +129,12 @@ class LlamaDecoder:
                          (c.inter, c.hidden)):
                 ws = max(ws, ops.awq_gemm_workspace_bytes(B, N, K))
         self.workspace = torch.zeros(max(ws, 256), dtype=torch.uint8, device=device)  # ticket words start at zero
+        # layer fusion: block sums of every GEMM input come from its producer, split-K partials go to the consumer
+        self.fused = False
+        self.xs_hidden = torch.zeros(c.hidden // 128, B, dtype=torch.float32, device=device)
+        self.xs_attn = torch.zeros(self.q_size // 128, B, dtype=torch.float32, device=device)
+        self.xs_act = torch.zeros(c.inter // 128, B, dtype=torch.float32, device=device)
+        self.partial = None
         # batch state (ScheduleBatch fields, device resident)
         self.input_ids = torch.zeros(B, dtype=torch.int64, device=device)
         self.positions = torch.zeros(B, dtype=torch.int64, device=device)
@@ -192,7 +198,67 @@ class LlamaDecoder:
         loc = self.req_to_token[self.req_pool_indices, self.positions]  # private slots are pre-assigned per request
         self.out_cache_loc.copy_(loc)
 
+    def enable_fusion(self, on: bool = True) -> bool:
+        """Decoder-layer fusion (AWQ, 16-bit, head size 128, shapes the partial GEMM covers)."""
+        c = self.cfg
+        ok = on and c.quant == "awq" and c.head_dim == 128 and c.hidden % 128 == 0 and c.inter % 128 == 0
+        if ok:
+            shapes = {"qkv": (c.hidden, self.q_size + 2 * self.kv_size), "o": (self.q_size, c.hidden),
+                      "down": (c.inter, c.hidden)}
+            self.part_splits = {k: ops.awq_gemm_partial_splits(self.B, n, kk, c.group_size) for k, (kk, n) in shapes.items()}
+            ok = all(v > 0 for v in self.part_splits.values())
+            if ok:
+                need = max(self.part_splits[k] * self.B * n for k, (kk, n) in shapes.items())
+                self.partial = torch.empty(need, dtype=torch.float32, device=self.device)
+        self.fused = bool(ok)
+        return self.fused
+
+    def _timed(self, name, fn):
+        if self.gemm_timer is not None:
+            self.gemm_timer(name, fn)
+        else:
+            fn()
+
+    def step_fused(self):
+        c = self.cfg
+        self.prepare_for_decode()
+        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
+                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
+        sm_scale = 1.0 / math.sqrt(c.head_dim)
+        q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
+        o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
+        P, S = self.partial, self.part_splits
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                self.residual.copy_(self.hidden)
+                ops.fused_add_rmsnorm_ex(self.hidden, None, L["ln1"], c.eps, xsum_out=self.xs_hidden)
+            else:  # consumes the previous layer's down-projection partials
+                ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln1"], c.eps, partials=P, splits=S["down"],
+                                         xsum_out=self.xs_hidden)
+            w = L["qkv"]
+            self._timed("qkv", lambda: ops.awq_gemm_partial(self.hidden, w.packed, w.scales, w.qzeros, P, self.xs_hidden))
+            ops.rope_and_store_kv_partial(self.qkv, P, S["qkv"], self.cos_sin, self.positions, self.k_pool[li],
+                                          self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
+            self.attention(li, q_view, o_view, sm_scale, xsum_out=self.xs_attn)
+            w = L["o"]
+            self._timed("o", lambda: ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, P, self.xs_attn))
+            ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, partials=P, splits=S["o"],
+                                     xsum_out=self.xs_hidden)
+            w = L["gate_up"]
+            self._timed("gate_up", lambda: ops.awq_gemm_xs(self.hidden, w.packed, w.scales, w.qzeros, self.xs_hidden,
+                                                           self.gate_up, self.workspace))
+            ops.act_and_mul_xs(self.act, self.gate_up, 0, self.xs_act)
+            w = L["down"]
+            self._timed("down", lambda: ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, P, self.xs_act))
+        ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])
+        ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
+        torch.argmax(self.logits, dim=-1, out=self.next_ids)
+        self.input_ids.copy_(self.next_ids)
+
     def step(self):
+        if self.fused:
+            return self.step_fused()
         c = self.cfg
         self.prepare_for_decode()
         ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
@@ -233,11 +299,16 @@ class LlamaDecoder:
             self.shared_ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
         return self.shared
 
-    def attention(self, li, q_view, o_view, sm_scale):
+    def attention(self, li, q_view, o_view, sm_scale, xsum_out=None):
         if getattr(self, "shared", False):
-            ops.decode_attention_shared_prefix(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr,
-                                               self.kv_indices, self.group_indptr, self.group_prefix, self.shared_ws,
-                                               self.max_kv_splits, sm_scale, 0.0)
+            ops.decode_attention_shared_prefix_xs(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr,
+                                                  self.kv_indices, self.group_indptr, self.group_prefix, self.shared_ws,
+                                                  self.max_kv_splits, sm_scale, 0.0, xsum_out)
+            return
+        if xsum_out is not None:
+            ops.decode_attention_fwd_xs(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
+                                        self.attn_logits, self.attn_lse, self.num_kv_splits, self.max_kv_splits, sm_scale,
+                                        0.0, xsum_out)
             return
         ops.decode_attention_fwd(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
                                  self.attn_logits, self.attn_lse, self.num_kv_splits, self.max_kv_splits, sm_scale, 0.0)

@@ -417,3 +417,94 @@ def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
                                              scales_b.stride(0), dtype_code(out_dtype), _stream(mat_a)),
           "fp8_blockwise_scaled_mm")
     return out
+
+
+# ---- fusion forms of the decode layer ---------------------------------------------------------------------
+def awq_gemm_partial_splits(M, N, K, group=128) -> int:
+    return int(lib().sglk_awq_gemm_partial_splits(M, N, K, group))
+
+
+def awq_gemm_partial(x, packed, scales, qzeros, partial, xsum=None):
+    """fp32 split-K partials [splits, M, N] of x @ W into `partial`; returns the number of splits written."""
+    _need_gpu(x, packed, scales, qzeros, partial)
+    M, K = x.shape
+    N = scales.shape[1]
+    group = K // scales.shape[0]
+    splits = awq_gemm_partial_splits(M, N, K, group)
+    if splits == 0:
+        raise SglkError(f"awq_gemm_partial: shape M={M} N={N} K={K} group={group} is not covered")
+    if partial.dtype != torch.float32 or partial.numel() < splits * M * N:
+        raise SglkError(f"awq_gemm_partial: partial must hold {splits} x {M} x {N} fp32")
+    check(lib().sglk_awq_gemm_partial(_ptr(x), _ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(xsum),
+                                      0 if xsum is None else xsum.stride(0), _ptr(partial), M, N, K, group, x.stride(0),
+                                      dtype_code(x.dtype), _stream(x)), "awq_gemm_partial")
+    return splits
+
+
+def awq_gemm_xs(x, packed, scales, qzeros, xsum, out, workspace, bias=None):
+    """awq_gemm with the block sums of x ([K/128, >= M] fp32) supplied by the producer of x."""
+    _need_gpu(x, packed, scales, qzeros, out, workspace)
+    M, K = x.shape
+    N = scales.shape[1]
+    check(lib().sglk_awq_gemm_xs(_ptr(x), _ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(out), _ptr(workspace),
+                                 M, N, K, K // scales.shape[0], x.stride(0), out.stride(0), dtype_code(x.dtype), _ptr(xsum),
+                                 0 if xsum is None else xsum.stride(0), _stream(x)), "awq_gemm_xs")
+    return out
+
+
+def fused_add_rmsnorm_ex(x, residual, weight, eps, gemma=False, partials=None, splits=0, bias=None, xsum_out=None):
+    """x (and residual) updated in place; the input row may come from `partials` [splits, rows, hidden] fp32."""
+    _need_gpu(x, weight)
+    hidden = x.shape[-1]
+    rows = x.numel() // hidden
+    check(lib().sglk_fused_add_rmsnorm_ex(_ptr(x), _ptr(residual), _ptr(weight), rows, hidden, float(eps),
+                                          1 if gemma else 0, dtype_code(x.dtype), _ptr(partials), int(splits),
+                                          rows * hidden, _ptr(bias), _ptr(xsum_out),
+                                          0 if xsum_out is None else xsum_out.stride(0), _stream(x)),
+          "fused_add_rmsnorm_ex")
+
+
+def act_and_mul_xs(out, x, act, xsum_out):
+    _need_gpu(out, x, xsum_out)
+    d = x.shape[-1] // 2
+    check(lib().sglk_act_and_mul_xs(_ptr(out), _ptr(x), x.numel() // (2 * d), d, act, dtype_code(x.dtype), _ptr(xsum_out),
+                                    xsum_out.stride(0), _stream(x)), "act_and_mul_xs")
+
+
+def rope_and_store_kv_partial(qkv, partials, splits, cos_sin_cache, positions, k_buffer, v_buffer, loc, q_heads, kv_heads,
+                              head_size, interleave=False, bias=None):
+    _need_gpu(qkv, partials, cos_sin_cache, positions, k_buffer, v_buffer, loc)
+    kb = k_buffer.view(k_buffer.shape[0], -1)
+    vb = v_buffer.view(v_buffer.shape[0], -1)
+    check(lib().sglk_rope_and_store_kv_partial(_ptr(qkv), _ptr(partials), int(splits), qkv.numel(), _ptr(bias),
+                                               _ptr(cos_sin_cache), _ptr(positions), _ptr(kb), _ptr(vb), _ptr(loc),
+                                               _is64(loc), qkv.shape[0], q_heads, kv_heads, head_size,
+                                               cos_sin_cache.shape[1], kb.stride(0), vb.stride(0), 1 if interleave else 0,
+                                               dtype_code(qkv.dtype), _stream(qkv)), "rope_and_store_kv_partial")
+
+
+def decode_attention_fwd_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                            max_kv_splits, sm_scale, logit_cap, xsum_out):
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    check(lib().sglk_decode_attention_xs(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(attn_logits),
+        _ptr(attn_lse), _ptr(num_kv_splits), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
+        k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
+        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _ptr(xsum_out),
+        0 if xsum_out is None else xsum_out.stride(0), _stream(q)), "decode_attention_xs")
+
+
+def decode_attention_shared_prefix_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens,
+                                      workspace, max_kv_splits, sm_scale, logit_cap, xsum_out):
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, workspace)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    G = group_indptr.shape[0] - 1
+    check(lib().sglk_decode_attention_shared_prefix_xs(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr),
+        _ptr(prefix_lens), G, _ptr(workspace), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
+        k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
+        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _ptr(xsum_out),
+        0 if xsum_out is None else xsum_out.stride(0), _stream(q)), "decode_attention_shared_prefix_xs")

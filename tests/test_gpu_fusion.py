@@ -1,0 +1,157 @@
+"""GPU: the fusion forms of the decode layer (split-K partials consumed by the next kernel, block sums produced by
+the previous one) against the unfused ops: bit-exact where the arithmetic is the same, oracle tolerance elsewhere."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from sglang_security_amd import ops
+
+    return ops
+
+
+def _block_sums(t):  # [rows, n] -> [n/128, rows] fp32
+    r, n = t.shape
+    return t.float().view(r, n // 128, 128).sum(-1).t().contiguous()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,hidden,splits", [(64, 4096, 4), (5, 512, 1), (33, 8192, 7)])
+def test_rmsnorm_ex_matches_unfused(dtype, rows, hidden, splits):
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + hidden)
+    parts = torch.randn(splits, rows, hidden, generator=g).to(DEV)
+    res = torch.randn(rows, hidden, generator=g).to(dtype).to(DEV)
+    w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype).to(DEV)
+    # unfused: sum in split order, round once, then the ordinary op
+    acc = torch.zeros(rows, hidden, device=DEV)
+    for s in range(splits):
+        acc = acc + parts[s]
+    x_ref = acc.to(dtype)
+    r_ref = res.clone()
+    ops.fused_add_rmsnorm(x_ref, r_ref, w, 1e-5)
+    x = torch.empty(rows, hidden, dtype=dtype, device=DEV)
+    r = res.clone()
+    xs = torch.zeros(hidden // 128, rows + 3, device=DEV)
+    ops.fused_add_rmsnorm_ex(x, r, w, 1e-5, partials=parts, splits=splits, xsum_out=xs)
+    assert torch.equal(x.view(torch.int16), x_ref.view(torch.int16))
+    assert torch.equal(r.view(torch.int16), r_ref.view(torch.int16))
+    torch.testing.assert_close(xs[:, :rows], _block_sums(x), rtol=1e-4, atol=2e-2)
+    # plain forms: no partials, no residual
+    x2 = x_ref.clone()
+    y_ref = torch.empty_like(x2)
+    ops.rmsnorm(y_ref, x2, w, 1e-5)
+    ops.fused_add_rmsnorm_ex(x2, None, w, 1e-5)
+    assert torch.equal(x2.view(torch.int16), y_ref.view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_act_and_mul_xs(dtype):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 2 * 1024, generator=g).to(dtype).to(DEV)
+    a, b = torch.empty(64, 1024, dtype=dtype, device=DEV), torch.empty(64, 1024, dtype=dtype, device=DEV)
+    xs = torch.zeros(8, 64, device=DEV)
+    ops.act_and_mul(a, x, 0)
+    ops.act_and_mul_xs(b, x, 0, xs)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    torch.testing.assert_close(xs, _block_sums(b), rtol=1e-4, atol=2e-2)
+
+
+def test_rope_and_store_kv_partial():
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    T, Hq, Hkv, D, splits = 9, 8, 2, 128, 3
+    row = (Hq + 2 * Hkv) * D
+    parts = torch.randn(splits, T, row, generator=g).to(DEV)
+    cs = torch.randn(64, D, generator=g).to(DEV)
+    pos = torch.randint(0, 64, (T,), generator=g).to(DEV)
+    loc = (torch.randperm(30, generator=g)[:T] + 1).to(DEV)
+    acc = torch.zeros(T, row, device=DEV)
+    for s in range(splits):
+        acc = acc + parts[s]
+    qkv_ref = acc.to(torch.bfloat16)
+    kb1, vb1 = torch.zeros(32, Hkv, D, dtype=torch.bfloat16, device=DEV), torch.zeros(32, Hkv, D, dtype=torch.bfloat16, device=DEV)
+    kb2, vb2 = torch.zeros_like(kb1), torch.zeros_like(vb1)
+    ops.rope_and_store_kv(qkv_ref, cs, pos, kb1, vb1, loc, Hq, Hkv, D)
+    qkv = torch.empty(T, row, dtype=torch.bfloat16, device=DEV)
+    ops.rope_and_store_kv_partial(qkv, parts, splits, cs, pos, kb2, vb2, loc, Hq, Hkv, D)
+    assert torch.equal(qkv.view(torch.int16), qkv_ref.view(torch.int16))
+    assert torch.equal(kb1, kb2) and torch.equal(vb1, vb2)
+
+
+@pytest.mark.parametrize("M,K,N", [(64, 4096, 6144), (64, 4096, 4096), (17, 1024, 256), (64, 14336, 4096)])
+def test_awq_gemm_partial_and_block_sums(M, K, N):
+    """Partials summed by the caller, and the GEMM fed with the producer's block sums, against the oracle."""
+    import oracle
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_ops import _awq_case
+
+    ops = _ops()
+    x, qw, sc, qz = _awq_case(M, K, N, 128, torch.bfloat16, seed=K + N)
+    want = oracle.awq_gemm(x, qw, sc, qz).float()
+    tol = 1e-2 * max(1.0, want.abs().max().item())
+    xd, packed, scd, qzd = x.to(DEV), ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV)
+    xs = _block_sums(xd)
+    splits = ops.awq_gemm_partial_splits(M, N, K)
+    assert splits >= 1
+    for use_xs in (None, xs):
+        part = torch.full((splits, M, N), float("nan"), device=DEV)
+        assert ops.awq_gemm_partial(xd, packed, scd, qzd, part, use_xs) == splits
+        got = part.sum(0).to(torch.bfloat16).float().cpu()
+        assert (got - want).abs().max().item() <= tol
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), 256), dtype=torch.uint8, device=DEV)
+    ops.awq_gemm_xs(xd, packed, scd, qzd, xs, out, work)
+    assert (out.float().cpu() - want).abs().max().item() <= tol
+
+
+def test_attention_block_sums():
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_attention_extend import _group_batch
+
+    ops = _ops()
+    q, kb, vb, ptr, ind, gi, pls = _group_batch([(6, 70, 1, 40)], 32, 8, torch.bfloat16, seed=3)
+    B, Hq, D = q.shape
+    sm = 1.0 / math.sqrt(D)
+    o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=DEV)
+    o2 = torch.empty_like(o1)
+    xs1, xs2 = torch.zeros(Hq, B, device=DEV), torch.zeros(Hq, B + 2, device=DEV)
+    al = torch.empty(B, Hq, 8, D, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, 8, dtype=torch.float32, device=DEV)
+    ns = torch.full((B,), 4, dtype=torch.int32, device=DEV)
+    ops.decode_attention_fwd_xs(q.to(DEV), kb.to(DEV), vb.to(DEV), o1, ptr.to(DEV), ind.to(DEV), al, lse, ns, 8, sm, 0.0, xs1)
+    ws = torch.empty(ops.decode_shared_workspace_bytes(B, Hq, D, 8) // 4, dtype=torch.float32, device=DEV)
+    ops.decode_attention_shared_prefix_xs(q.to(DEV), kb.to(DEV), vb.to(DEV), o2, ptr.to(DEV), ind.to(DEV), gi.to(DEV),
+                                          pls.to(DEV), ws, 8, sm, 0.0, xs2)
+    torch.testing.assert_close(xs1, _block_sums(o1.view(B, Hq * D)), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(xs2[:, :B], _block_sums(o2.view(B, Hq * D)), rtol=1e-4, atol=2e-2)
+    assert (o1.float() - o2.float()).abs().max().item() < 2e-2
+
+
+def test_fused_decode_step_matches_unfused():
+    """Two decoders with identical weights and batch: one runs the layer fusion, one the plain op sequence."""
+    from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
+
+    cfg = LlamaConfig.tiny()
+    outs = []
+    for fused in (False, True):
+        dec = LlamaDecoder(cfg, batch=6, pool_slots=1 + 64 + 6 * 24, max_ctx=96, device=DEV, seed=0)
+        dec.setup_shared_prefix_batch(prefix_len=64, suffix_len=5)
+        dec.enable_shared_prefix(True)
+        assert dec.enable_fusion(fused) == fused
+        for _ in range(3):
+            dec.step()
+        torch.cuda.synchronize()
+        outs.append((dec.logits.float().cpu().clone(), dec.next_ids.cpu().clone(), dec.k_pool[1].float().cpu().clone()))
+    (l0, t0, k0), (l1, t1, k1) = outs
+    assert torch.isfinite(l1).all()
+    assert (l0 - l1).abs().max().item() < 0.05 * max(1.0, l0.abs().max().item())
+    assert (k0 - k1).abs().max().item() < 0.05 * max(1.0, k0.abs().max().item())
