@@ -285,19 +285,24 @@ __device__ __forceinline__ int find_group(const int32_t* __restrict__ group_indp
   }
   return lo;
 }
-// split count of the per-request remainder in the shared-prefix path: about 128 tokens per split
+// split count of the per-request remainder in the shared-prefix path: one 32-token tile per wave while they last
 __device__ __forceinline__ int tail_splits(int len, int max_splits) {
-  return min(max(cdiv_i(len, 128), 1), max_splits);
+  return min(max(cdiv_i(len, 32), 1), max_splits);
 }
 
-template <typename T>
+// MERGE (remainder mode of the shared-prefix path only): the block's four waves are the request's four remainder
+// splits; instead of storing their partials they leave them in LDS, and the block then merges them with the prefix
+// partials that the group kernel stored (attn_logits / attn_lse, splits [0, split_offset)) and writes the final
+// output row (and its per-head sums when xsum_out is given).
+template <typename T, bool MERGE>
 __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
     float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv,
     int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
     int64_t v_stride_h, float sm_scale, float logit_cap, const int32_t* __restrict__ group_indptr,
-    const int32_t* __restrict__ prefix_lens, int num_groups, int split_offset, int total_splits) {
+    const int32_t* __restrict__ prefix_lens, int num_groups, int split_offset, int total_splits, void* __restrict__ o,
+    int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out, int64_t xs_stride) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -311,19 +316,25 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   int start = kv_indptr[b];
   int len = kv_indptr[b + 1] - start;
   int splits;
+  int plen = 0;
   if (group_indptr) {
     // remainder mode: the first prefix_lens[group of b] tokens are handled elsewhere
-    const int skip = prefix_lens[find_group(group_indptr, num_groups, b)];
-    start += skip;
-    len -= skip;
+    plen = prefix_lens[find_group(group_indptr, num_groups, b)];
+    start += plen;
+    len -= plen;
     splits = tail_splits(len, max_kv_splits);
   } else {
     splits = max(num_kv_splits[b], 1);
   }
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
-  const int s0 = per_split * split, s1 = min(s0 + per_split, len);
-  // wave-uniform exit; no block-level synchronisation is used below
-  if (split >= max_kv_splits || s1 <= s0) return;
+  const int s0 = per_split * split;
+  int s1 = min(s0 + per_split, len);
+  const bool active = split < max_kv_splits && s1 > s0;  // wave-uniform
+  if constexpr (!MERGE) {
+    if (!active) return;  // no block-level synchronisation is used in this form
+  } else {
+    if (!active) s1 = s0;  // runs no tile; joins the merge below
+  }
 
   const int hl = lane & 15;  // operand column: query head within this head tile / token within a 16-token half
   const int g = lane >> 4;   // 16-lane group
@@ -379,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     }
   };
 
-  fetch(s0);
+  if (active) fetch(s0);
   for (int t0 = s0; t0 < s1; t0 += kTile) {
     park();
     if (t0 + kTile < s1) fetch(t0 + kTile);  // next tile's rows fly while this one is multiplied
@@ -440,6 +451,65 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   // ---- epilogue: total sum over the four lane groups, normalise, store partial
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
+  if constexpr (MERGE) {
+    // this wave's partial: O[16 heads][128] fp32 over its K tile, log-sum-exp[16] at the head of its V tile
+    float* po = reinterpret_cast<float*>(kl);
+    float* pl = reinterpret_cast<float*>(vl);
+    const float inv = active ? 1.0f / lsum : 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(po + hl * 128 + 16 * n + 4 * g) = oacc[n] * inv;
+    if (g == 0) pl[hl] = active ? (m + log2f(lsum)) * 0.6931471805599453f : -INFINITY;
+    __syncthreads();
+    const int heads_here = min(16, group - ht * 16);
+    const int per_p = cdiv_i(cdiv_i(plen, split_offset), kMinBlockKV) * kMinBlockKV;  // split_offset = prefix splits
+    for (int idx = threadIdx.x; idx < ((heads_here + 1) & ~1) * 128; idx += 256) {  // two heads per trip, uniform
+      const int hh = idx >> 7, d = idx & 127;
+      const bool ok = hh < heads_here;
+      const int hq = kvh * group + ht * 16 + (ok ? hh : 0);
+      float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
+      // prefix partials (global), loads issued together
+      const int64_t base = ((int64_t)b * Hq + hq) * total_splits;
+      float tv[16], tl[16];
+#pragma unroll
+      for (int sp = 0; sp < 16; ++sp) {
+        const bool live = ok && sp < split_offset && per_p * sp < plen;
+        tv[sp] = live ? attn_logits[(base + sp) * 128 + d] : 0.f;
+        tl[sp] = live ? attn_lse[base + sp] : -INFINITY;
+      }
+#pragma unroll
+      for (int sp = 0; sp < 16 + kWavesPerBlock; ++sp) {
+        float v, l;
+        if (sp < 16) {
+          v = tv[sp];
+          l = tl[sp];
+        } else {
+          const char* wbase = lds_all + (sp - 16) * kLdsPerWave;
+          v = reinterpret_cast<const float*>(wbase)[hh * 128 + d];
+          l = reinterpret_cast<const float*>(wbase + kTileBytes)[hh];
+        }
+        if (l > -INFINITY) {
+          const float n_max = fmaxf(l, e_max);
+          const float old = expf(e_max - n_max), w = expf(l - n_max);
+          acc = acc * old + w * v;
+          e_sum = e_sum * old + w;
+          e_max = n_max;
+        }
+      }
+      const float res = acc / e_sum;
+      if (ok) st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d, res);
+      if (xsum_out) {
+        // a head is 128 consecutive idx = two waves: pair them through LDS (the V-tile area past the lse words)
+        float* xr = reinterpret_cast<float*>(lds_all + kTileBytes + 256);
+        const float r = wave_sum(ok ? Conv<T>::to_f32(Conv<T>::from_f32(res)) : 0.f);
+        if (lane == 0) xr[wid] = r;
+        __syncthreads();
+        if (threadIdx.x == 0 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[0] + xr[1];
+        if (threadIdx.x == 128 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[2] + xr[3];
+        __syncthreads();
+      }
+    }
+    return;
+  }
   if (head_ok) {
     const float inv = 1.0f / lsum;
     const int64_t ob = ((int64_t)b * Hq + head) * total_splits + split_offset + split;
@@ -511,43 +581,6 @@ __global__ void __launch_bounds__(256) decode_group_prefix_kernel(
 #pragma unroll
     for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = st.oacc[c][n] * inv;
     if (g == 0) part_lse[ob] = (st.m[c] + log2f(tot)) * 0.6931471805599453f;
-  }
-}
-
-// LSE merge of the prefix splits and the per-request remainder splits
-template <typename T>
-__global__ void __launch_bounds__(128) decode_group_merge_kernel(
-    const float* __restrict__ part_o, const float* __restrict__ part_lse, void* __restrict__ o,
-    const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ group_indptr,
-    const int32_t* __restrict__ prefix_lens, int num_groups, int prefix_splits, int tail_max_splits, int Hq,
-    int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out, int64_t xs_stride) {
-  __shared__ float xs_red[2];
-  const int b = blockIdx.x, h = blockIdx.y;
-  const int plen = prefix_lens[find_group(group_indptr, num_groups, b)];
-  const int tlen = kv_indptr[b + 1] - kv_indptr[b] - plen;
-  const int per_p = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
-  const int per_t = cdiv_i(cdiv_i(tlen, tail_splits(tlen, tail_max_splits)), kMinBlockKV) * kMinBlockKV;
-  const int total_splits = prefix_splits + tail_max_splits;
-  const int64_t base = ((int64_t)b * Hq + h) * total_splits;
-  const int d = threadIdx.x;
-  float e_sum = 0.f, e_max = -INFINITY, acc = 0.f;
-  for (int s = 0; s < total_splits; ++s) {
-    const bool live = s < prefix_splits ? (per_p * s < plen) : (per_t * (s - prefix_splits) < tlen);
-    if (!live) continue;
-    const float tv = part_o[(base + s) * 128 + d];
-    const float tl = part_lse[base + s];
-    const float n_max = fmaxf(tl, e_max);
-    const float old = expf(e_max - n_max), w = expf(tl - n_max);
-    acc = acc * old + w * tv;
-    e_sum = e_sum * old + w;
-    e_max = n_max;
-  }
-  st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d, acc / e_sum);
-  if (xsum_out) {
-    const float r = wave_sum(Conv<T>::to_f32(Conv<T>::from_f32(acc / e_sum)));
-    if ((threadIdx.x & 63) == 0) xs_red[threadIdx.x >> 6] = r;
-    __syncthreads();
-    if (threadIdx.x == 0) xsum_out[(int64_t)h * xs_stride + b] = xs_red[0] + xs_red[1];
   }
 }
 
@@ -638,11 +671,12 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
     const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
     SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
+                       hipLaunchKernelGGL((decode_stage1_mfma128<T, false>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
                                           k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse,
                                           num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h,
                                           k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap,
-                                          (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, max_kv_splits));
+                                          (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, max_kv_splits,
+                                          (void*)nullptr, (int64_t)0, (int64_t)0, (float*)nullptr, (int64_t)0));
   } else {
     dim3 grid(B, Hq, max_kv_splits);
     const size_t lds = (size_t)D * sizeof(float);
@@ -706,7 +740,7 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
   SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
              "decode_attention_shared_prefix: null pointer");
   SGLK_CHECK(B >= 0 && G > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
-  SGLK_CHECK(max_kv_splits > 0, "decode_attention_shared_prefix: max_kv_splits must be positive");
+  SGLK_CHECK(max_kv_splits > 0 && max_kv_splits <= 16, "decode_attention_shared_prefix: max_kv_splits must be in 1..16");
   if (B == 0) return SGLK_OK;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
   const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
@@ -734,18 +768,14 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
     dim3 grid(B, Hkv * head_tiles, 1);
     const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
     SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
+                       hipLaunchKernelGGL((decode_stage1_mfma128<T, true>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
                                           k_buffer, v_buffer, kv_indptr, kv_indices, part_o, part_lse,
                                           (const int32_t*)nullptr, kTailMaxSplits, Hq, Hkv, head_tiles, q_stride_b,
                                           q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap,
-                                          group_indptr, prefix_lens, G, max_kv_splits, total_splits));
+                                          group_indptr, prefix_lens, G, max_kv_splits, total_splits, o, o_stride_b,
+                                          o_stride_h, xsum_out, xs_stride));
     SGLK_LAUNCH_CHECK();
   }
-  SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((decode_group_merge_kernel<T>), dim3(B, Hq), dim3(128), 0, s, part_o, part_lse, o,
-                                        kv_indptr, group_indptr, prefix_lens, G, max_kv_splits, kTailMaxSplits, Hq,
-                                        o_stride_b, o_stride_h, xsum_out, xs_stride));
-  SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
 

@@ -136,6 +136,33 @@ static int launch_rmsnorm(void* out, const void* x, void* residual, const void* 
 //     may be written to xsum[block][row] for the following fused AWQ GEMM.
 // 16-bit types, hidden % 128 == 0, hidden <= 8192.
 // ---------------------------------------------------------------------------------------------
+// acc[0..7] = sum over splits (in split order) of the 8 floats at partials[s][off .. off+7]; four splits' loads are in
+// flight together
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int splits, int64_t part_stride,
+                                             int64_t off, float (&acc)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int s0 = 0; s0 < splits; s0 += 4) {
+    float4v a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* pr = partials + (int64_t)min(s0 + u, splits - 1) * part_stride + off;
+      a[u] = *reinterpret_cast<const float4v*>(pr);
+      b[u] = *reinterpret_cast<const float4v*>(pr + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (s0 + u < splits) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] += a[u][j];
+          acc[4 + j] += b[u][j];
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) rmsnorm_fused_kernel(void* __restrict__ xio, void* __restrict__ residual,
                                                             const void* __restrict__ w, int hidden, float eps, int gemma,
@@ -157,16 +184,8 @@ __global__ void __launch_bounds__(256) rmsnorm_fused_kernel(void* __restrict__ x
     const int v = threadIdx.x + it * 256;
     if (v < nvec) {
       if (partials) {
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int s2 = 0; s2 < splits; ++s2) {
-          const float* pr = partials + (int64_t)s2 * part_stride + row * hidden + 8 * v;
-          const float4v a = *reinterpret_cast<const float4v*>(pr), b = *reinterpret_cast<const float4v*>(pr + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[j] += a[j];
-            acc[4 + j] += b[j];
-          }
-        }
+        float acc[8];
+        sum_partials(partials, splits, part_stride, row * hidden + 8 * v, acc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float bj = br ? Conv<T>::to_f32(br[8 * v + j]) : 0.f;
@@ -224,29 +243,64 @@ __global__ void __launch_bounds__(256) act_and_mul_xs_kernel(void* __restrict__ 
                                                              int64_t rows, int d, float* __restrict__ xsum_out,
                                                              int64_t xs_stride);
 
-// rope_store over a qkv row that is first assembled from split-K partials (written to qkv, as the GEMM would)
+// rope_store over a qkv row that is first assembled from split-K partials: the row is summed, rounded (the value
+// the GEMM would have stored) and kept in LDS, then rotated; q goes to the qkv buffer, k and v to the pool rows
 template <typename T>
-__global__ void __launch_bounds__(256) qkv_from_partials_kernel(void* __restrict__ qkv, const float* __restrict__ partials,
-                                                                int splits, int64_t part_stride, int row_len,
-                                                                const void* __restrict__ bias) {
+__global__ void __launch_bounds__(256) rope_store_partial_kernel(
+    void* __restrict__ qkv, const float* __restrict__ partials, int splits, int64_t part_stride,
+    const void* __restrict__ bias, const float* __restrict__ cos_sin, const int64_t* __restrict__ positions,
+    void* __restrict__ k_buffer, void* __restrict__ v_buffer, const void* loc, int loc_is64, int q_heads, int kv_heads,
+    int head_size, int rot, int64_t kbuf_stride_n, int64_t vbuf_stride_n, int interleave) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t rowS[];  // (q_heads + 2 kv_heads) * head_size
   const int64_t t = blockIdx.x;
-  uint16_t* dst = reinterpret_cast<uint16_t*>(qkv) + t * row_len;
+  const int row_len = (q_heads + 2 * kv_heads) * head_size;
   const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
   for (int v = threadIdx.x; v < (row_len >> 3); v += 256) {
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int s2 = 0; s2 < splits; ++s2) {
-      const float* pr = partials + (int64_t)s2 * part_stride + t * row_len + 8 * v;
-      const float4v a = *reinterpret_cast<const float4v*>(pr), b = *reinterpret_cast<const float4v*>(pr + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[j] += a[j];
-        acc[4 + j] += b[j];
-      }
-    }
+    float acc[8];
+    sum_partials(partials, splits, part_stride, t * row_len + 8 * v, acc);
     short8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (short)Conv<T>::from_f32(acc[j] + (br ? Conv<T>::to_f32(br[8 * v + j]) : 0.f));
-    reinterpret_cast<short8*>(dst)[v] = o;
+    reinterpret_cast<short8*>(rowS)[v] = o;
+  }
+  __syncthreads();
+  uint16_t* qdst = reinterpret_cast<uint16_t*>(qkv) + t * row_len;
+  const float* cs = cos_sin + positions[t] * rot;
+  const int half = rot / 2;
+  const int64_t slot = ld_idx(loc, loc_is64, t);
+  uint16_t* kdst = reinterpret_cast<uint16_t*>(k_buffer) + slot * kbuf_stride_n;
+  uint16_t* vdst = reinterpret_cast<uint16_t*>(v_buffer) + slot * vbuf_stride_n;
+  const int nrot = (q_heads + kv_heads) * half;
+  for (int i = threadIdx.x; i < nrot; i += 256) {
+    const int h = i / half, p = i - h * half;
+    const int a = interleave ? 2 * p : p, b = interleave ? 2 * p + 1 : p + half;
+    const uint16_t* v = rowS + h * head_size;
+    const float c = cs[p], s = cs[half + p];
+    const float xa = Conv<T>::to_f32(v[a]), xb = Conv<T>::to_f32(v[b]);
+    const uint16_t ra = Conv<T>::from_f32(xa * c - xb * s), rb = Conv<T>::from_f32(xb * c + xa * s);
+    uint16_t* d = h < q_heads ? qdst + h * head_size : kdst + (h - q_heads) * head_size;
+    d[a] = ra;
+    d[b] = rb;
+    if (h >= q_heads) {  // the qkv buffer keeps the rotated k as well, as the unfused op leaves it
+      qdst[h * head_size + a] = ra;
+      qdst[h * head_size + b] = rb;
+    }
+  }
+  // pass-through dims (rot < head_size) of q and k, and all of v
+  if (rot < head_size) {
+    const int pass = head_size - rot;
+    for (int i = threadIdx.x; i < (q_heads + kv_heads) * pass; i += 256) {
+      const int h = i / pass, p = rot + (i - h * pass);
+      const uint16_t val = rowS[h * head_size + p];
+      qdst[h * head_size + p] = val;
+      if (h >= q_heads) kdst[(h - q_heads) * head_size + p] = val;
+    }
+  }
+  const int voff = (q_heads + kv_heads) * head_size;
+  for (int i = threadIdx.x; i < kv_heads * head_size; i += 256) {
+    const uint16_t val = rowS[voff + i];
+    vdst[i] = val;
+    qdst[voff + i] = val;
   }
 }
 
@@ -634,11 +688,16 @@ int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits,
              "rope_and_store_kv_partial: bad partial layout");
   SGLK_CHECK(dtype == SGLK_F16 || dtype == SGLK_BF16, "rope_and_store_kv_partial: 16-bit types only");
   if (tokens == 0) return SGLK_OK;
+  SGLK_CHECK(cos_sin_cache && positions && k_buffer && v_buffer && loc, "rope_and_store_kv_partial: null pointer");
+  SGLK_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope_and_store_kv_partial: bad rotary dim");
+  SGLK_CHECK(row_len * 2 <= 64 * 1024, "rope_and_store_kv_partial: qkv row of %lld elements does not fit in LDS",
+             (long long)row_len);
   SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((qkv_from_partials_kernel<T>), dim3((unsigned)tokens), dim3(256), 0,
-                                        (hipStream_t)stream, qkv, partials, splits, part_stride, (int)row_len, bias));
+                     hipLaunchKernelGGL((rope_store_partial_kernel<T>), dim3((unsigned)tokens), dim3(256),
+                                        (size_t)row_len * 2, (hipStream_t)stream, qkv, partials, splits, part_stride, bias,
+                                        cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, q_heads, kv_heads,
+                                        head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave));
   SGLK_LAUNCH_CHECK();
-  return sglk_rope_and_store_kv(qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, tokens, q_heads,
-                                kv_heads, head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave, dtype, stream);
+  return SGLK_OK;
 }
 }
