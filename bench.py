@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--tiny", action="store_true", help="2-layer toy model (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--kv-splits", type=int, default=8, help="max_kv_splits of the attention backend")
     ap.add_argument("--no-fusion", action="store_true", help="plain op sequence per layer (no partial / block-sum hand-over)")
     ap.add_argument("--no-prefix-hit", action="store_true", help="skip the prefix-hit speedup measurements")
     return ap.parse_args()
@@ -262,7 +263,7 @@ def main():
     # pool sized for the variant without sharing too (every request holds its own copy of the prefix)
     slots = 1 + (B * (args.prefix + per_req) if want_hit else args.prefix + B * per_req)
     max_ctx = args.prefix + per_req
-    dec = LlamaDecoder(cfg, B, slots, max_ctx, device=dev)
+    dec = LlamaDecoder(cfg, B, slots, max_ctx, device=dev, max_kv_splits=args.kv_splits)
     dec.cu_count = torch.cuda.get_device_properties(dev).multi_processor_count
     fused = (not args.no_fusion) and dec.enable_fusion(True)
 

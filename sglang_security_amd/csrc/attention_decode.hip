@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
 // shared-prefix decode: the prefix of a group is streamed once per (kv head, split, 128 columns)
 // and multiplied against every (request, head) column of the group
 // ---------------------------------------------------------------------------------------------
-static constexpr int kGroupNC = 2;
+static constexpr int kGroupNC = 1;
 static constexpr int kGroupCols = 64 * kGroupNC;  // columns per block
 
 template <typename T>
@@ -568,9 +568,9 @@ __global__ void __launch_bounds__(256) decode_group_prefix_kernel(
                     : nullptr);
   }
   // every request of the group lists the same slots for the prefix: walk the first request's list
-  st.template run<false, true>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-                               reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
-                               v_stride_n, kv_indices + kv_indptr[gstart], t0, t1, qpos, 0, sm_scale, logit_cap);
+  st.template run<false, true, 2>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+                                  reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
+                                  v_stride_n, kv_indices + kv_indptr[gstart], t0, t1, qpos, 0, sm_scale, logit_cap);
 #pragma unroll
   for (int c = 0; c < kGroupNC; ++c) {
     const float tot = st.total(c);

@@ -91,7 +91,8 @@ struct BlockAttn {
   // Stream tokens [t_begin, t_end) (block-uniform, non-empty).  GATHER: token t lives in pool row idx[t],
   // else in row t of kbase/vbase.  CAUSAL: column tile c of this lane sees token t only if t <= qpos[c];
   // wave_qmax is the largest qpos of the wave (tiles wholly above it are skipped by the wave).
-  template <bool CAUSAL, bool GATHER>
+  // PF: tiles in flight ahead of the one being multiplied (registers: 4 x 16-byte per tile and thread).
+  template <bool CAUSAL, bool GATHER, int PF = 1>
   __device__ __forceinline__ void run(char* lds, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
                                       int64_t v_stride_n, const int32_t* idx, int t_begin, int t_end,
                                       const int (&qpos)[NC], int wave_qmax, float sm_scale, float logit_cap) {
@@ -102,33 +103,18 @@ struct BlockAttn {
     const float LOG2E = 1.4426950408889634f;
     const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
 
-    int4v kreg[2], vreg[2];
-    auto fetch = [&](int t0) {
+    int4v kreg[PF][2], vreg[PF][2];
+    auto fetch = [&](int4v(&kr)[2], int4v(&vr)[2], int t0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         int tok = t0 + frow + 16 * i;
         tok = tok < t_end ? tok : t_begin;  // rows past the end re-read a valid row; their scores are masked
         const int64_t row = GATHER ? (int64_t)idx[tok] : (int64_t)tok;
-        kreg[i] = *reinterpret_cast<const int4v*>(kbase + row * k_stride_n + chunk * 8);
-        vreg[i] = *reinterpret_cast<const int4v*>(vbase + row * v_stride_n + chunk * 8);
+        kr[i] = *reinterpret_cast<const int4v*>(kbase + row * k_stride_n + chunk * 8);
+        vr[i] = *reinterpret_cast<const int4v*>(vbase + row * v_stride_n + chunk * 8);
       }
     };
-
-    __syncthreads();  // a previous run() may still be reading the stages
-    fetch(t_begin);
-    int stage = 0;
-    for (int t0 = t_begin; t0 < t_end; t0 += kTile, stage ^= 1) {
-      char* kl = lds + stage * 2 * kTileBytes;
-      char* vl = kl + kTileBytes;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int r = frow + 16 * i;
-        *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[i];
-        *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[i];
-      }
-      __syncthreads();
-      if (t0 + kTile < t_end) fetch(t0 + kTile);  // the next tile flies while this one is multiplied
-      if (CAUSAL && t0 > wave_qmax) continue;     // wave-uniform: nothing visible to this wave
+    auto compute = [&](int t0, const char* kl, const char* vl) {
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         float4v sacc[2];
@@ -180,6 +166,32 @@ struct BlockAttn {
           const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
           const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           oacc[c][n] = Mfma16<T>::mma(vf, pf, oacc[c][n]);
+        }
+      }
+    };
+
+    __syncthreads();  // a previous run() may still be reading the stages
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (t_begin + p * kTile < t_end) fetch(kreg[p], vreg[p], t_begin + p * kTile);
+    int stage = 0;
+    for (int tb = t_begin; tb < t_end; tb += kTile * PF) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int t0 = tb + p * kTile;
+        if (t0 < t_end) {  // block-uniform
+          char* kl = lds + stage * 2 * kTileBytes;
+          char* vl = kl + kTileBytes;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int r = frow + 16 * i;
+            *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[p][i];
+            *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[p][i];
+          }
+          __syncthreads();
+          if (t0 + PF * kTile < t_end) fetch(kreg[p], vreg[p], t0 + PF * kTile);  // flies while tiles are multiplied
+          if (!(CAUSAL && t0 > wave_qmax)) compute(t0, kl, vl);                   // wave-uniform skip
+          stage ^= 1;
         }
       }
     }

@@ -155,6 +155,13 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 __device__ __forceinline__ void glds16(const void* src, char* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void_ptr)lds_base, 16, 0, 0);
 }
+// same with an instruction offset, which the hardware adds to BOTH addresses: pieces that are OFF bytes apart in LDS
+// share one LDS base (one M0 write) when the source pointer is moved back by OFF
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const void* src_minus_off, char* lds_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_minus_off, (lds_void_ptr)lds_base,
+                                   16, OFF, 0);
+}
 __device__ __forceinline__ void glds4(const void* src, char* lds_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (lds_void_ptr)lds_base, 4, 0, 0);
 }
@@ -532,8 +539,15 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   auto issue_x = [&](int stage, int buf) {
     const uint16_t* src = x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) glds16(src + xoff[j], dst + j * 1024);
+    // eight 1-KiB pieces, two LDS bases (the instruction offset reaches 4095)
+    glds16_off<0>(src + xoff[0], dst);
+    glds16_off<1024>(src + xoff[1] - 512, dst);
+    glds16_off<2048>(src + xoff[2] - 1024, dst);
+    glds16_off<3072>(src + xoff[3] - 1536, dst);
+    glds16_off<0>(src + xoff[4], dst + 4096);
+    glds16_off<1024>(src + xoff[5] - 512, dst + 4096);
+    glds16_off<2048>(src + xoff[6] - 1024, dst + 4096);
+    glds16_off<3072>(src + xoff[7] - 1536, dst + 4096);
     if constexpr (XS_EXT) {
       // this wave's group of the stage: 64 row sums, one per lane, into the wave's own slot
       const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
