@@ -319,14 +319,12 @@ ORACLE_API void oracle_half_matmul(const float* x, const uint16_t* w, const floa
 }
 
 /* ---------- E1: elementwise ----------
- * rmsnorm / fused_add_rmsnorm: python/sglang/srt/layers/layernorm.py:88-107 (forward_native):
- * x32 = x.float(); (residual: x32 += residual.float(); residual = x32.to(dtype));
- * x32 *= rsqrt(mean(x32^2) + eps); out = (x32 * weight).to(dtype)  [weight multiply in fp32
- * after casting x to... the reference does x.to(orig_dtype) * weight; see note below].
- * sgl-kernel/tests/test_norm.py:8-33 holds the same statement.  In forward_native the
- * normalised x is cast to the activation dtype BEFORE the weight multiply (layernorm.py:105:
- * `x = (x * self.weight).to(orig_dtype)` multiplies fp32 x by the weight, then casts) -- the
- * fp32 form is restated here; the half-precision difference is below the stated 1e-3 tolerance. */
+ * rmsnorm / fused_add_rmsnorm: python/sglang/srt/layers/layernorm.py:88-107 (forward_native) and
+ * sgl-kernel/tests/test_norm.py:8-33:
+ *   x32 = x.float(); with a residual: x32 += residual.float(), residual = x32.to(dtype);
+ *   x32 *= rsqrt(mean(x32^2) + eps); out = (x32 * weight.float()).to(dtype)
+ * i.e. the weight multiply runs in fp32 on the unrounded normalised row (layernorm.py:105) and the
+ * result is rounded once. */
 ORACLE_API void oracle_rmsnorm(const float* x, const float* w, float* out, int64_t rows, int hidden,
                                float eps, int dtype) {
   for (int64_t r = 0; r < rows; ++r) {

@@ -120,21 +120,6 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) dense_reduce_kernel(const float* __restrict__ partial,
-                                                           const uint16_t* __restrict__ bias,
-                                                           uint16_t* __restrict__ out, int M, int Mpad, int N,
-                                                           int splits, int64_t out_stride) {
-  const int64_t total = (int64_t)M * N;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int m = (int)(i / N), c = (int)(i - (int64_t)m * N);
-    float a = 0.f;
-    for (int s = 0; s < splits; ++s) a += partial[((int64_t)s * Mpad + m) * N + c];
-    if (bias) a += Conv<T>::to_f32(bias[c]);
-    out[(int64_t)m * out_stride + c] = Conv<T>::from_f32(a);
-  }
-}
-
 }  // namespace sglk
 
 using namespace sglk;
