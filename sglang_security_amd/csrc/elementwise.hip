@@ -2,6 +2,8 @@
 // gated activations, rotary embedding, KV-pool row scatter, LSE merge of two partial attentions.
 // All are HBM-bound byte movers: 16-byte accesses per lane, fp32 arithmetic, one rounding to the
 // activation type where the reference rounds.
+#include <algorithm>
+
 #include "common.h"
 
 namespace sglk {
@@ -136,22 +138,22 @@ static int launch_rmsnorm(void* out, const void* x, void* residual, const void* 
 //     may be written to xsum[block][row] for the following fused AWQ GEMM.
 // 16-bit types, hidden % 128 == 0, hidden <= 8192.
 // ---------------------------------------------------------------------------------------------
-// acc[0..7] = sum over splits (in split order) of the 8 floats at partials[s][off .. off+7]; four splits' loads are in
-// flight together
+// acc[0..7] = sum over splits (in split order) of the 8 floats at partials[s][off .. off+7]; up to eight splits'
+// loads are in flight together
 __device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int splits, int64_t part_stride,
                                              int64_t off, float (&acc)[8]) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int s0 = 0; s0 < splits; s0 += 4) {
-    float4v a[4], b[4];
+  for (int s0 = 0; s0 < splits; s0 += 8) {
+    float4v a[8], b[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const float* pr = partials + (int64_t)min(s0 + u, splits - 1) * part_stride + off;
       a[u] = *reinterpret_cast<const float4v*>(pr);
       b[u] = *reinterpret_cast<const float4v*>(pr + 4);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (s0 + u < splits) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -164,7 +166,7 @@ __device__ __forceinline__ void sum_partials(const float* __restrict__ partials,
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) rmsnorm_fused_kernel(void* __restrict__ xio, void* __restrict__ residual,
+__global__ void __launch_bounds__(1024) rmsnorm_fused_kernel(void* __restrict__ xio, void* __restrict__ residual,
                                                             const void* __restrict__ w, int hidden, float eps, int gemma,
                                                             const float* __restrict__ partials, int splits,
                                                             int64_t part_stride, const void* __restrict__ bias,
@@ -175,13 +177,13 @@ __global__ void __launch_bounds__(256) rmsnorm_fused_kernel(void* __restrict__ x
   uint16_t* res = residual ? reinterpret_cast<uint16_t*>(residual) + row * hidden : nullptr;
   const uint16_t* wr = reinterpret_cast<const uint16_t*>(w);
   const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
-  constexpr int MAXV = 4;
+  constexpr int MAXV = 4;  // 8192 elements at 256 threads; one vector per thread at hidden/8 threads
   float keep[MAXV][8];
   float ss = 0.f;
   const int nvec = hidden >> 3;
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
-    const int v = threadIdx.x + it * 256;
+    const int v = threadIdx.x + it * blockDim.x;
     if (v < nvec) {
       if (partials) {
         float acc[8];
@@ -214,7 +216,7 @@ __global__ void __launch_bounds__(256) rmsnorm_fused_kernel(void* __restrict__ x
   const float inv = rsqrtf(tot / (float)hidden + eps);
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
-    const int v = threadIdx.x + it * 256;
+    const int v = threadIdx.x + it * blockDim.x;
     if (v < nvec) {  // uniform over each group of 16 lanes: hidden % 128 == 0
       const short8 wv = reinterpret_cast<const short8*>(wr)[v];
       short8 ov;
@@ -246,7 +248,7 @@ __global__ void __launch_bounds__(256) act_and_mul_xs_kernel(void* __restrict__ 
 // rope_store over a qkv row that is first assembled from split-K partials: the row is summed, rounded (the value
 // the GEMM would have stored) and kept in LDS, then rotated; q goes to the qkv buffer, k and v to the pool rows
 template <typename T>
-__global__ void __launch_bounds__(256) rope_store_partial_kernel(
+__global__ void __launch_bounds__(1024) rope_store_partial_kernel(
     void* __restrict__ qkv, const float* __restrict__ partials, int splits, int64_t part_stride,
     const void* __restrict__ bias, const float* __restrict__ cos_sin, const int64_t* __restrict__ positions,
     void* __restrict__ k_buffer, void* __restrict__ v_buffer, const void* loc, int loc_is64, int q_heads, int kv_heads,
@@ -255,7 +257,7 @@ __global__ void __launch_bounds__(256) rope_store_partial_kernel(
   const int64_t t = blockIdx.x;
   const int row_len = (q_heads + 2 * kv_heads) * head_size;
   const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
-  for (int v = threadIdx.x; v < (row_len >> 3); v += 256) {
+  for (int v = threadIdx.x; v < (row_len >> 3); v += blockDim.x) {
     float acc[8];
     sum_partials(partials, splits, part_stride, t * row_len + 8 * v, acc);
     short8 o;
@@ -271,7 +273,7 @@ __global__ void __launch_bounds__(256) rope_store_partial_kernel(
   uint16_t* kdst = reinterpret_cast<uint16_t*>(k_buffer) + slot * kbuf_stride_n;
   uint16_t* vdst = reinterpret_cast<uint16_t*>(v_buffer) + slot * vbuf_stride_n;
   const int nrot = (q_heads + kv_heads) * half;
-  for (int i = threadIdx.x; i < nrot; i += 256) {
+  for (int i = threadIdx.x; i < nrot; i += blockDim.x) {
     const int h = i / half, p = i - h * half;
     const int a = interleave ? 2 * p : p, b = interleave ? 2 * p + 1 : p + half;
     const uint16_t* v = rowS + h * head_size;
@@ -289,7 +291,7 @@ __global__ void __launch_bounds__(256) rope_store_partial_kernel(
   // pass-through dims (rot < head_size) of q and k, and all of v
   if (rot < head_size) {
     const int pass = head_size - rot;
-    for (int i = threadIdx.x; i < (q_heads + kv_heads) * pass; i += 256) {
+    for (int i = threadIdx.x; i < (q_heads + kv_heads) * pass; i += blockDim.x) {
       const int h = i / pass, p = rot + (i - h * pass);
       const uint16_t val = rowS[h * head_size + p];
       qdst[h * head_size + p] = val;
@@ -297,7 +299,7 @@ __global__ void __launch_bounds__(256) rope_store_partial_kernel(
     }
   }
   const int voff = (q_heads + kv_heads) * head_size;
-  for (int i = threadIdx.x; i < kv_heads * head_size; i += 256) {
+  for (int i = threadIdx.x; i < kv_heads * head_size; i += blockDim.x) {
     const uint16_t val = rowS[voff + i];
     vdst[i] = val;
     qdst[voff + i] = val;
@@ -642,7 +644,9 @@ int sglk_fused_add_rmsnorm_ex(void* x, void* residual, const void* weight, int64
   SGLK_CHECK(!xsum_out || xs_stride >= rows, "fused_add_rmsnorm_ex: xs_stride smaller than the row count");
   if (rows == 0) return SGLK_OK;
   SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((rmsnorm_fused_kernel<T>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     hipLaunchKernelGGL((rmsnorm_fused_kernel<T>), dim3((unsigned)rows),
+                                        dim3(std::min(1024, std::max(256, (hidden / 8 + 63) / 64 * 64))), 0,
+                                        (hipStream_t)stream,
                                         x, residual, weight, hidden, eps, gemma, partials, splits, part_stride, bias,
                                         xsum_out, xs_stride));
   SGLK_LAUNCH_CHECK();
@@ -693,7 +697,8 @@ int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits,
   SGLK_CHECK(row_len * 2 <= 64 * 1024, "rope_and_store_kv_partial: qkv row of %lld elements does not fit in LDS",
              (long long)row_len);
   SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((rope_store_partial_kernel<T>), dim3((unsigned)tokens), dim3(256),
+                     hipLaunchKernelGGL((rope_store_partial_kernel<T>), dim3((unsigned)tokens),
+                                        dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(256, (row_len / 8 + 63) / 64 * 64))),
                                         (size_t)row_len * 2, (hipStream_t)stream, qkv, partials, splits, part_stride, bias,
                                         cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, q_heads, kv_heads,
                                         head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave));

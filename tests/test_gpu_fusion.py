@@ -39,15 +39,18 @@ def test_rmsnorm_ex_matches_unfused(dtype, rows, hidden, splits):
     r = res.clone()
     xs = torch.zeros(hidden // 128, rows + 3, device=DEV)
     ops.fused_add_rmsnorm_ex(x, r, w, 1e-5, partials=parts, splits=splits, xsum_out=xs)
-    assert torch.equal(x.view(torch.int16), x_ref.view(torch.int16))
+    # the residual is a plain sum: bit-exact.  The normalised row depends on the order of the sum of squares (the
+    # fused kernel uses wider blocks), so it may differ from the unfused kernel by one rounding step in a few places
     assert torch.equal(r.view(torch.int16), r_ref.view(torch.int16))
+    assert (x.view(torch.int16).int() - x_ref.view(torch.int16).int()).abs().max().item() <= 1
+    assert (x.view(torch.int16) != x_ref.view(torch.int16)).float().mean().item() < 1e-3
     torch.testing.assert_close(xs[:, :rows], _block_sums(x), rtol=1e-4, atol=2e-2)
     # plain forms: no partials, no residual
     x2 = x_ref.clone()
     y_ref = torch.empty_like(x2)
     ops.rmsnorm(y_ref, x2, w, 1e-5)
     ops.fused_add_rmsnorm_ex(x2, None, w, 1e-5)
-    assert torch.equal(x2.view(torch.int16), y_ref.view(torch.int16))
+    assert (x2.view(torch.int16).int() - y_ref.view(torch.int16).int()).abs().max().item() <= 1
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
