@@ -219,6 +219,24 @@ class LlamaDecoder:
         else:
             fn()
 
+    def gemm_sweep(self, name: str):
+        """Launch projection `name` of every layer back to back, in the form the decode step uses (timing aid)."""
+        c = self.cfg
+        for L in self.layers:
+            w = L[name]
+            if not self.fused:
+                src = {"qkv": self.hidden, "o": self.attn_out, "gate_up": self.hidden, "down": self.act}[name]
+                dst = {"qkv": self.qkv, "o": self.hidden, "gate_up": self.gate_up, "down": self.hidden}[name]
+                self._linear(name, w, src, dst)
+            elif name == "qkv":
+                ops.awq_gemm_partial(self.hidden, w.packed, w.scales, w.qzeros, self.partial, self.xs_hidden)
+            elif name == "o":
+                ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, self.partial, self.xs_attn)
+            elif name == "gate_up":
+                ops.awq_gemm_xs(self.hidden, w.packed, w.scales, w.qzeros, self.xs_hidden, self.gate_up, self.workspace)
+            else:
+                ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, self.partial, self.xs_act)
+
     def step_fused(self):
         c = self.cfg
         self.prepare_for_decode()
