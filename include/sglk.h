@@ -126,6 +126,18 @@ SGLK_API int sglk_extend_attention(const void* q_extend, const void* k_extend, c
                                    int max_extend_len, float sm_scale, float logit_cap, int causal,
                                    int dtype, void* stream);
 
+/* Paged prefill: like sglk_extend_attention, but the new tokens are already in the pool and kv_indices lists
+ * every token of each sequence (prefix + new); with causal != 0 query row i of a sequence with q_len rows and
+ * kv_len tokens sees tokens 0 .. kv_len - q_len + i.  This is the form the reference's ROCm default backend
+ * calls (aiter.mha_batch_prefill_func, python/sglang/srt/layers/attention/aiter_backend.py:353-367). */
+SGLK_API int sglk_prefill_attention_paged(const void* q, void* o, const void* k_buffer, const void* v_buffer,
+                                          const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                          const int32_t* kv_indices, int B, int Hq, int Hkv, int D, int Dv,
+                                          int64_t q_stride_t, int64_t q_stride_h, int64_t o_stride_t,
+                                          int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                          int64_t v_stride_n, int64_t v_stride_h, int max_q_len, float sm_scale,
+                                          float logit_cap, int causal, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ A3: merge_state ----------- */
 
 /* LSE merge of two partial attention results, v:[n,h,d] (dtype), s:[n,h] fp32; s_out may be NULL.

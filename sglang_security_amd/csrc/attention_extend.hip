@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
 
   BlockAttn<T, NC> st;
   st.init();
-  int qpos[NC];
+  int qpos[NC], qrow[NC];
   bool col_ok[NC];
   int wave_qmax = 0;
   const uint16_t* qb = reinterpret_cast<const uint16_t*>(q_extend) + (int64_t)h * q_stride_h;
@@ -49,10 +49,29 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     const int row = block_q0 + tile * 16 + hl;
     col_ok[c] = row < ext_len;
     qpos[c] = min(row, ext_len - 1);
+    qrow[c] = qpos[c];
     wave_qmax = max(wave_qmax, min(block_q0 + tile * 16 + 15, ext_len - 1));
     st.load_q(c, qb + (int64_t)(q0 + qpos[c]) * q_stride_t);
   }
 
+  if (k_extend == nullptr) {
+    // paged form: kv_indices lists ALL tokens of the sequence (the new ones are already in the pool); query row i
+    // sees tokens 0 .. plen - ext_len + i
+    const int shift = plen - ext_len;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) qpos[c] += shift;
+    const uint16_t* kb = reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h;
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h;
+    if (causal) {
+      const int t_end = min(plen, shift + block_q0 + 64 * NC);
+      if (t_end > 0)
+        st.template run<true, true>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, t_end, qpos,
+                                    wave_qmax + shift, sm_scale, logit_cap);
+    } else if (plen > 0) {
+      st.template run<false, true>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, plen, qpos, 0, sm_scale,
+                                   logit_cap);
+    }
+  } else {
   if (plen > 0) {
     st.template run<false, true>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
                                  reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
@@ -68,13 +87,14 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     st.template run<false, false>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, ext_len, qpos, wave_qmax, sm_scale,
                                   logit_cap);
   }
+  }
 
   uint16_t* ob = reinterpret_cast<uint16_t*>(o_extend) + (int64_t)h * o_stride_h;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float inv = 1.0f / st.total(c);
     if (!col_ok[c]) continue;
-    uint16_t* dst = ob + (int64_t)(q0 + qpos[c]) * o_stride_t;
+    uint16_t* dst = ob + (int64_t)(q0 + qrow[c]) * o_stride_t;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
       // lane (hl, g) holds O[row hl][16n + 4g + r], r = 0..3
@@ -107,8 +127,9 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
   const int lane = threadIdx.x;
   for (int d = lane; d < D; d += 64) qs[d] = ld<T>(q_extend, (int64_t)(q0 + qi) * q_stride_t + (int64_t)h * q_stride_h + d);
   __syncthreads();
-  const int vis = causal ? qi + 1 : ext_len;  // visible new tokens
-  const int total = plen + vis;
+  const bool paged = k_extend == nullptr;   // kv_indices lists every token; row qi sees plen - ext_len + qi + 1 of them
+  const int vis = paged ? 0 : (causal ? qi + 1 : ext_len);  // visible new tokens
+  const int total = paged ? (causal ? plen - ext_len + qi + 1 : plen) : plen + vis;
   float m = -INFINITY, l = 0.f;
   float acc[DV_PER_LANE];
 #pragma unroll
@@ -117,7 +138,7 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
     const int tok = t0 + lane;
     const bool valid = tok < total;
     // where this lane's token lives
-    const bool in_prefix = tok < plen;
+    const bool in_prefix = paged || tok < plen;
     const void* kp = in_prefix ? k_buffer : k_extend;
     const void* vp = in_prefix ? v_buffer : v_extend;
     int64_t kb = 0, vb = 0;
@@ -150,7 +171,7 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
     for (int j = 0; j < cnt; ++j) {
       const float pj = __shfl(p, j, 64);
       const int64_t vj = __shfl((long long)vb, j, 64);
-      const void* vsrc = (t0 + j) < plen ? v_buffer : v_extend;
+      const void* vsrc = (paged || (t0 + j) < plen) ? v_buffer : v_extend;
 #pragma unroll
       for (int i = 0; i < DV_PER_LANE; ++i) {
         const int d = lane + 64 * i;
@@ -171,15 +192,16 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
 
 using namespace sglk;
 
-extern "C" int sglk_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
-                                     const void* k_buffer, const void* v_buffer, const int32_t* qo_indptr,
-                                     const int32_t* kv_indptr, const int32_t* kv_indices, int B, int Hq, int Hkv, int D,
-                                     int Dv, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
-                                     int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
-                                     int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-                                     int64_t v_stride_h, int max_extend_len, float sm_scale, float logit_cap, int causal,
-                                     int dtype, void* stream) {
-  SGLK_CHECK(q_extend && k_extend && v_extend && o_extend && qo_indptr && kv_indptr, "extend_attention: null pointer");
+static int extend_attention_impl(const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+                                 const void* k_buffer, const void* v_buffer, const int32_t* qo_indptr,
+                                 const int32_t* kv_indptr, const int32_t* kv_indices, int B, int Hq, int Hkv, int D, int Dv,
+                                 int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+                                 int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
+                                 int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                 int max_extend_len, float sm_scale, float logit_cap, int causal, int dtype, void* stream,
+                                 bool paged) {
+  SGLK_CHECK(q_extend && o_extend && qo_indptr && kv_indptr && (paged || (k_extend && v_extend)),
+             "extend_attention: null pointer");
   SGLK_CHECK(B >= 0 && Hq > 0 && Hkv > 0 && D > 0 && Dv > 0, "extend_attention: bad shape");
   SGLK_CHECK(Hq % Hkv == 0, "extend_attention: Hq %d not a multiple of Hkv %d", Hq, Hkv);
   SGLK_CHECK(Dv <= 1024 && D <= 4096, "extend_attention: head size too large");
@@ -188,10 +210,11 @@ extern "C" int sglk_extend_attention(const void* q_extend, const void* k_extend,
   // a batch without any cached prefix may pass no pool at all
   if (!k_buffer) k_buffer = k_extend;
   if (!v_buffer) v_buffer = v_extend;
+  if (paged) k_extend = v_extend = nullptr;  // the kernels take a null k_extend as "every token is in the pool"
   hipStream_t s = (hipStream_t)stream;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
   const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
-                    aligned16(k_extend) && aligned16(v_extend) && aligned16(k_buffer) && aligned16(v_buffer) &&
+                    (paged || (aligned16(k_extend) && aligned16(v_extend))) && aligned16(k_buffer) && aligned16(v_buffer) &&
                     ((uintptr_t)o_extend % 8 == 0) && mult8(q_stride_t) && mult8(q_stride_h) && mult8(ke_stride_t) &&
                     mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && mult8(k_stride_n) &&
                     mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h) && o_stride_t % 4 == 0 &&
@@ -230,4 +253,30 @@ extern "C" int sglk_extend_attention(const void* q_extend, const void* k_extend,
   }
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+extern "C" int sglk_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend, void* o_extend,
+                                     const void* k_buffer, const void* v_buffer, const int32_t* qo_indptr,
+                                     const int32_t* kv_indptr, const int32_t* kv_indices, int B, int Hq, int Hkv, int D,
+                                     int Dv, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                     int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
+                                     int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                     int64_t v_stride_h, int max_extend_len, float sm_scale, float logit_cap, int causal,
+                                     int dtype, void* stream) {
+  return extend_attention_impl(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                               B, Hq, Hkv, D, Dv, q_stride_t, q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h,
+                               o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
+                               sm_scale, logit_cap, causal, dtype, stream, false);
+}
+
+extern "C" int sglk_prefill_attention_paged(const void* q, void* o, const void* k_buffer, const void* v_buffer,
+                                            const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                            int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_t, int64_t q_stride_h,
+                                            int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                            int64_t v_stride_n, int64_t v_stride_h, int max_q_len, float sm_scale,
+                                            float logit_cap, int causal, int dtype, void* stream) {
+  SGLK_CHECK(k_buffer && v_buffer && kv_indices, "prefill_attention_paged: null pointer");
+  return extend_attention_impl(q, nullptr, nullptr, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, B, Hq, Hkv, D,
+                               Dv, q_stride_t, q_stride_h, 8, 8, 8, 8, o_stride_t, o_stride_h, k_stride_n, k_stride_h,
+                               v_stride_n, v_stride_h, max_q_len, sm_scale, logit_cap, causal, dtype, stream, true);
 }

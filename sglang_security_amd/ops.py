@@ -508,3 +508,19 @@ def decode_attention_shared_prefix_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_in
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
         float(sm_scale), float(logit_cap), dtype_code(q.dtype), _ptr(xsum_out),
         0 if xsum_out is None else xsum_out.stride(0), _stream(q)), "decode_attention_shared_prefix_xs")
+
+
+def prefill_attention_paged(q, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, max_q_len, sm_scale,
+                            logit_cap=0.0, causal=True):
+    """Prefill over a paged pool that already holds the new tokens (kv_indices lists every token)."""
+    _need_gpu(q, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
+    T, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[-2], v_buffer.shape[-1]
+    kb = k_buffer.reshape(-1, Hkv, D)
+    vb = v_buffer.reshape(-1, Hkv, Dv)
+    B = qo_indptr.shape[0] - 1
+    check(lib().sglk_prefill_attention_paged(
+        _ptr(q), _ptr(o), _ptr(kb), _ptr(vb), _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), B, Hq, Hkv, D, Dv,
+        q.stride(0), q.stride(1), o.stride(0), o.stride(1), kb.stride(0), kb.stride(1), vb.stride(0), vb.stride(1),
+        int(max_q_len), float(sm_scale), float(logit_cap), 1 if causal else 0, dtype_code(q.dtype), _stream(q)),
+        "prefill_attention_paged")

@@ -243,3 +243,49 @@ def test_shared_prefix_unsupported_shape():
     i32 = lambda *v: torch.tensor(v, dtype=torch.int32, device=DEV)
     with pytest.raises(SglkError):
         ops.decode_attention_shared_prefix(q, kb, kb, o, i32(0, 3), i32(1, 2, 3), i32(0, 1), i32(2), ws, 4, 1.0)
+
+
+# ------------------------------------------------------------------------------------------ aiter call surface
+@pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 128), (torch.float16, 128), (torch.float32, 64)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_aiter_shim_prefill_and_decode(dtype, D, causal):
+    """The two entry points of the reference's ROCm default backend (aiter_backend.py:353-417): paged prefill with the
+    new tokens already in the pool, and ragged paged decode, against the oracle."""
+    import oracle
+    import sglang_security_amd.aiter_shim as shim
+
+    Hq, Hkv, B = 8, 2, 3
+    gen = torch.Generator().manual_seed(17 + D)
+    pre, ext = [40, 0, 150], [33, 70, 5]
+    n = 1 + sum(pre) + sum(ext)
+    kb = torch.randn(n, 1, Hkv, D, generator=gen).to(dtype)
+    vb = torch.randn(n, 1, Hkv, D, generator=gen).to(dtype)
+    perm = (torch.randperm(n - 1, generator=gen) + 1).to(torch.int32)
+    rows, at = [], 0
+    for p, e in zip(pre, ext):
+        rows.append(perm[at:at + p + e])
+        at += p + e
+    T = sum(ext)
+    q = torch.randn(T, Hq, D, generator=gen).to(dtype)
+    qo = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32)
+    kvp = torch.tensor([0] + list(torch.tensor([p + e for p, e in zip(pre, ext)]).cumsum(0)), dtype=torch.int32)
+    ki = torch.cat(rows)
+    o = shim.mha_batch_prefill_func(q.to(DEV), kb.to(DEV), vb.to(DEV), qo.to(DEV), kvp.to(DEV), ki.to(DEV), max(ext),
+                                    max(p + e for p, e in zip(pre, ext)), causal=causal, logits_soft_cap=0.0)
+    # oracle: the same thing stated as prefix (through indices) + new tokens (contiguous, gathered from the pool)
+    k_new = torch.cat([kb[r[p:].long(), 0] for r, p in zip(rows, pre)])
+    v_new = torch.cat([vb[r[p:].long(), 0] for r, p in zip(rows, pre)])
+    pref_ptr = torch.tensor([0] + list(torch.tensor(pre).cumsum(0)), dtype=torch.int32)
+    pref_idx = torch.cat([r[:p] for r, p in zip(rows, pre)])
+    want = oracle.extend_attention(q, k_new, v_new, kb[:, 0], vb[:, 0], qo, pref_ptr, pref_idx, D ** -0.5, 0.0, causal)
+    tol = {torch.bfloat16: 2e-2, torch.float16: 4e-3, torch.float32: 2e-5}[dtype]
+    assert (o.float().cpu() - want).abs().max().item() < tol
+    if causal:
+        # decode of the last token of every sequence == last prefill row
+        qd = torch.stack([q[int(qo[b + 1]) - 1] for b in range(B)])
+        od = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
+        shim.paged_attention_ragged(od, None, qd.to(DEV), kb.to(DEV), vb.to(DEV), D ** -0.5, kvp.to(DEV), ki.to(DEV),
+                                    torch.ones(B, dtype=torch.int32, device=DEV), 1, 8, None, "auto", "NHD", 0.0, None, None,
+                                    None, 256)
+        last = torch.stack([want[int(qo[b + 1]) - 1] for b in range(B)])
+        assert (od.float().cpu() - last).abs().max().item() < tol
