@@ -601,7 +601,11 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   float s_cur[4] = {1.f, 1.f, 1.f, 1.f};
   int zsh[4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) zsh[t] = 4 * kAwqOrd[(n0 + 16 * t + i16) & 7];
+  for (int t = 0; t < 4; ++t) {
+    // AWQ order {0,4,1,5,2,6,3,7} in arithmetic: a table lookup here would be a load the stage pipeline waits for
+    const int j = (n0 + 16 * t + i16) & 7;
+    zsh[t] = 4 * ((j >> 1) + 4 * (j & 1));
+  }
   int aoff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) aoff[ks] = kw * 16384 + x_off(i16, 4 * ks + g);

@@ -1,0 +1,42 @@
+"""Micro-benchmark of the fp8 matmuls on the Llama-3-70B TP=8 per-GPU projection shapes (M = 64) and one DeepSeek
+block-scaled shape; weights rotate over enough copies to come from HBM."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sglang_security_amd import ops  # noqa: E402
+
+dev = "cuda"
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+F8 = torch.float8_e4m3fn
+gen = torch.Generator(device=dev).manual_seed(0)
+cases = [("qkv", 8192, 1280, False), ("o", 1024, 8192, False), ("gate_up", 8192, 7168, False), ("down", 3584, 8192, False),
+         ("block 7168x4608", 7168, 4608, True)]
+for name, K, N, block in cases:
+    copies = max(2, int(600e6 // (K * N)) + 1)
+    a = (torch.randn(M, K, device=dev, generator=gen) * 0.5).to(F8)
+    ws = [(torch.randn(N, K, device=dev, generator=gen) * 0.5).to(F8) for _ in range(copies)]
+    if block:
+        sa = torch.rand(M, K // 128, device=dev, generator=gen) + 0.1
+        sb = torch.rand(K // 128, (N + 127) // 128, device=dev, generator=gen) + 0.1
+        run = lambda i: ops.fp8_blockwise_scaled_mm(a, ws[i % copies].t(), sa, sb, torch.bfloat16)
+    else:
+        sa = torch.rand(M, 1, device=dev, generator=gen)
+        sb = torch.rand(N, 1, device=dev, generator=gen)
+        run = lambda i: ops.fp8_scaled_mm(a, ws[i % copies].t(), sa, sb, torch.bfloat16)
+    for i in range(copies):
+        run(i)
+    torch.cuda.synchronize()
+    iters = 40
+    torch.cuda._sleep(int(20e-3 * 2e9))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        run(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    byts = K * N + M * K + 2 * M * N
+    print(f"{name:18s} M={M} K={K:5d} N={N:5d}  {us:8.2f} us  {byts / us / 1e3:8.1f} GB/s  {2 * M * K * N / us / 1e6:7.1f} TFLOP/s", flush=True)
