@@ -241,11 +241,25 @@ SGLK_API int sglk_awq_gemm_partial(const void* x, const int32_t* packed, const v
                                    int dtype, void* stream);
 /* fused_add_rmsnorm (residual may be NULL: plain rmsnorm in place) whose input row may be given as split-K
  * partials (+bias) instead of x, and which may write the block sums of its output.  16-bit types,
- * hidden % 128 == 0, hidden <= 8192. */
+ * hidden % 128 == 0, hidden <= 8192.  zero_out / zero_count: fp32 words cleared on the way (the accumulation
+ * buffer of a later kernel), or NULL / 0. */
 SGLK_API int sglk_fused_add_rmsnorm_ex(void* x, void* residual, const void* weight, int64_t rows, int hidden,
                                        float eps, int gemma, int dtype, const float* partials, int splits,
                                        int64_t part_stride, const void* bias, float* xsum_out,
-                                       int64_t xs_stride, void* stream);
+                                       int64_t xs_stride, float* zero_out, int64_t zero_count,
+                                       void* stream);
+/* gate_up projection with the gated activation in its epilogue: out[M, N/2] = silu(x @ W_gate) * (x @ W_up),
+ * rounded exactly where sglk_awq_gemm followed by sglk_act_and_mul rounds.  W must have been re-laid-out from a
+ * weight whose columns were interleaved in blocks of 64: new columns [128t, 128t+64) = gate columns
+ * [64t, 64t+64), new columns [128t+64, 128t+128) = up columns [64t, 64t+64) (scales and zeros likewise).
+ * xsum (may be NULL): block sums of x.  xsum_out (may be NULL): block sums of the output rows are ADDED to it
+ * (it must be zero on entry: sglk_fused_add_rmsnorm_ex can clear it with zero_out / zero_count).
+ * N % 256 == 0, K % 512 == 0, group size 128. */
+SGLK_API int sglk_awq_gemm_silu_mul(const void* x, const int32_t* packed, const void* scales,
+                                    const int32_t* qzeros, void* out, int M, int N, int K, int group_size,
+                                    int64_t x_stride, int64_t out_stride, int dtype, const float* xsum,
+                                    int64_t xs_stride, float* xsum_out, int64_t xs_out_stride,
+                                    void* stream);
 /* sglk_act_and_mul that also writes the block sums of its output rows (d % 128 == 0). */
 SGLK_API int sglk_act_and_mul_xs(void* out, const void* x, int64_t rows, int d, int act, int dtype,
                                  float* xsum_out, int64_t xs_stride, void* stream);

@@ -51,7 +51,8 @@ _SIGS = {
     "sglk_awq_gemm_xs": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p, i64, p]),
     "sglk_awq_gemm_partial_splits": (i32, [i32, i32, i32, i32]),
     "sglk_awq_gemm_partial": (i32, [p, p, p, p, p, i64, p, i32, i32, i32, i32, i64, i32, p]),
-    "sglk_fused_add_rmsnorm_ex": (i32, [p, p, p, i64, i32, f32, i32, i32, p, i32, i64, p, p, i64, p]),
+    "sglk_fused_add_rmsnorm_ex": (i32, [p, p, p, i64, i32, f32, i32, i32, p, i32, i64, p, p, i64, p, i64, p]),
+    "sglk_awq_gemm_silu_mul": (i32, [p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p, i64, p, i64, p]),
     "sglk_act_and_mul_xs": (i32, [p, p, i64, i32, i32, i32, p, i64, p]),
     "sglk_rope_and_store_kv_partial": (i32, [p, p, i32, i64, p, p, p, p, p, p, i32, i64, i32, i32, i32, i32, i64, i64, i32, i32, p]),
     "sglk_decode_attention_xs": (i32, [p] * 9 + [i32] * 6 + [i64] * 8 + [f32, f32, i32, p, i64, p]),

@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
     float* __restrict__ partial, int* __restrict__ tickets, int M, int N, int K, int stages_per_split, int splits,
     int64_t x_stride, int64_t out_stride, int abl, const float* __restrict__ xsum_in, int64_t xs_stride,
-    int partial_mode) {
+    int partial_mode, int act_mode, float* __restrict__ xsum_out, int64_t xs_out_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xsumS = reinterpret_cast<float*>(smem + Wide::kXsumOff);
   int* flag = reinterpret_cast<int*>(smem + Wide::kFlagOff);
@@ -520,11 +520,11 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   // timing experiments (abl & 16): thread 0 drops 100 MHz clock stamps behind the ticket words in use
   const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   auto stamp = [&](int k) {
-    if ((abl & 16) && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
+    if ((abl & 16) && tickets && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
   };
   // abl & 32: six stamps inside stage 3 (wave 0 lane 0) instead
   auto stamp_in = [&](int stage, int k) {
-    if ((abl & 32) && stage == 3 && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
+    if ((abl & 32) && tickets && stage == 3 && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
   };
   stamp(0);
 
@@ -748,6 +748,51 @@ stages_done:
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  if (act_mode) {
+    // Gated-activation epilogue (single split only).  The tile's first 64 columns are gate columns, its last 64 the
+    // matching up columns (the caller interleaved the weight that way), so out[m, 64*tile + j] =
+    // round(round(silu(round(gate))) * round(up)): the values the unfused GEMM + silu_and_mul sequence stores.
+    // Wave (kw, nw) finishes strip kw for row tiles q = 2*nw, 2*nw + 1; it also leaves the block's row sums
+    // (for the next projection's zero-point term) in xsum_out, two tiles per 128-column block, by one atomic
+    // add per row and tile (two addends: order-independent).
+    float* rs = reinterpret_cast<float*>(smem + Wide::kSzOff);  // [4 strips][64 rows], the sz ring is idle now
+    const int ncol = blockIdx.x * 64 + 16 * kw + i16;
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int q = 2 * nw + qq;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gsum = 0.f, usum = 0.f;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) {
+          gsum += red[(((0 * 4 + k2) * 16 + kw * 4 + q) * 4 + r) * 64 + lane];
+          usum += red[(((1 * 4 + k2) * 16 + kw * 4 + q) * 4 + r) * 64 + lane];
+        }
+        const float gb = Conv<T>::to_f32(Conv<T>::from_f32(gsum));
+        const float ub = Conv<T>::to_f32(Conv<T>::from_f32(usum));
+        const float sv = Conv<T>::to_f32(Conv<T>::from_f32(gb / (1.0f + __expf(-gb))));
+        const uint16_t ob = Conv<T>::from_f32(sv * ub);
+        const int m = m0 + 16 * q + 4 * g + r;
+        if (m < M) out[(int64_t)m * out_stride + ncol] = ob;
+        if (xsum_out) {
+          float v = Conv<T>::to_f32(ob);
+#pragma unroll
+          for (int o2 = 8; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 16);
+          if (i16 == 0) rs[kw * 64 + 16 * q + 4 * g + r] = v;
+        }
+      }
+    }
+    if (xsum_out) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tid < 64 && m0 + tid < M) {
+        const float v = ((rs[tid] + rs[64 + tid]) + rs[128 + tid]) + rs[192 + tid];
+        atomicAdd(&xsum_out[(int64_t)(blockIdx.x >> 1) * xs_out_stride + m0 + tid], v);
+      }
+    }
+    return;
+  }
   float4v fin[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q)
@@ -898,7 +943,8 @@ static WidePlan plan_awq_wide(int M, int N, int K, int group_size, bool partial_
   // 0: never, 1: where it is expected to be faster, 2: wherever the shape allows (read per call: a test hook)
   const char* env_wide_s = getenv("SGLK_AWQ_WIDE");
   const int env_wide = env_wide_s ? atoi(env_wide_s) : 1;
-  static const int env_sps = getenv("SGLK_AWQ_WIDE_SPS") ? atoi(getenv("SGLK_AWQ_WIDE_SPS")) : 0;
+  const char* env_sps_s = getenv("SGLK_AWQ_WIDE_SPS");  // stages per split, read per call (test hook)
+  const int env_sps = env_sps_s ? atoi(env_sps_s) : 0;
   WidePlan p{};
   p.ok = env_wide && group_size == 128 && K % Wide::kStageK == 0 && N % 128 == 0;
   if (!p.ok) return p;
@@ -985,7 +1031,8 @@ int64_t sglk_awq_gemm_workspace_bytes(int M, int N, int K) {
 static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* packed, const void* scales,
                            const int32_t* qzeros, const void* bias, void* out, float* partial, int* tickets, int M, int N,
                            int K, int64_t x_stride, int64_t out_stride, int dtype, const float* xsum, int64_t xs_stride,
-                           int partial_mode, hipStream_t s) {
+                           int partial_mode, hipStream_t s, int act_mode = 0, float* xsum_out = nullptr,
+                           int64_t xs_out_stride = 0) {
   static const int env_abl = getenv("SGLK_AWQ_ABL") ? atoi(getenv("SGLK_AWQ_ABL")) : 0;  // timing experiments only
   dim3 wgrid(N / 128, wp.splits, wp.mblocks);
 #define SGLK_WIDE_LAUNCH(XS)                                                                                       \
@@ -999,7 +1046,7 @@ static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* pac
     hipLaunchKernelGGL((awq_gemm_wide_kernel<T, XS>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x, packed, \
                        (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial, tickets, M, N, \
                        K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl, xsum, xs_stride,          \
-                       partial_mode);                                                                              \
+                       partial_mode, act_mode, xsum_out, xs_out_stride);                                           \
   }
   SGLK_DISPATCH_HALF(dtype, T, {
     if (xsum) SGLK_WIDE_LAUNCH(true) else SGLK_WIDE_LAUNCH(false)
@@ -1028,6 +1075,25 @@ int sglk_awq_gemm_partial(const void* x, const int32_t* packed, const void* scal
                 N, group_size);
   return launch_awq_wide(wp, x, packed, scales, qzeros, nullptr, nullptr, partial, nullptr, M, N, K, x_stride, N, dtype,
                          xsum, xs_stride, 1, (hipStream_t)stream);
+}
+
+int sglk_awq_gemm_silu_mul(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, void* out,
+                           int M, int N, int K, int group_size, int64_t x_stride, int64_t out_stride, int dtype,
+                           const float* xsum, int64_t xs_stride, float* xsum_out, int64_t xs_out_stride, void* stream) {
+  SGLK_CHECK(x && packed && scales && qzeros && out, "awq_gemm_silu_mul: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && N % 256 == 0, "awq_gemm_silu_mul: N=%d must be a multiple of 256", N);
+  SGLK_CHECK(aligned16(x) && x_stride % 8 == 0, "awq_gemm_silu_mul: x rows must be 16-byte aligned");
+  SGLK_CHECK(out_stride >= N / 2, "awq_gemm_silu_mul: out_stride smaller than N/2");
+  SGLK_CHECK(!xsum || xs_stride >= M, "awq_gemm_silu_mul: xs_stride smaller than M");
+  SGLK_CHECK(!xsum_out || xs_out_stride >= M, "awq_gemm_silu_mul: xs_out_stride smaller than M");
+  WidePlan wp = plan_awq_wide(M, N, K, group_size, true);
+  if (!wp.ok)
+    return fail(SGLK_EUNSUP, "awq_gemm_silu_mul: needs K %% 512 == 0 and group size 128 (K=%d G=%d)", K, group_size);
+  // the activation needs whole sums: one split, whatever the planner would pick
+  wp.stages_per_split = K / Wide::kStageK;
+  wp.splits = 1;
+  return launch_awq_wide(wp, x, packed, scales, qzeros, nullptr, out, nullptr, nullptr, M, N, K, x_stride, out_stride,
+                         dtype, xsum, xs_stride, 0, (hipStream_t)stream, 1, xsum_out, xs_out_stride);
 }
 
 int sglk_awq_gemm_xs(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, const void* bias,

@@ -170,9 +170,12 @@ __global__ void __launch_bounds__(1024) rmsnorm_fused_kernel(void* __restrict__ 
                                                             const void* __restrict__ w, int hidden, float eps, int gemma,
                                                             const float* __restrict__ partials, int splits,
                                                             int64_t part_stride, const void* __restrict__ bias,
-                                                            float* __restrict__ xsum_out, int64_t xs_stride) {
+                                                            float* __restrict__ xsum_out, int64_t xs_stride,
+                                                            float* __restrict__ zero_out, int64_t zero_count) {
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
+  // clears an accumulation buffer of a later kernel on the way (block sums gathered with atomic adds)
+  for (int64_t i = row * blockDim.x + threadIdx.x; i < zero_count; i += (int64_t)gridDim.x * blockDim.x) zero_out[i] = 0.f;
   uint16_t* x = reinterpret_cast<uint16_t*>(xio) + row * hidden;
   uint16_t* res = residual ? reinterpret_cast<uint16_t*>(residual) + row * hidden : nullptr;
   const uint16_t* wr = reinterpret_cast<const uint16_t*>(w);
@@ -632,7 +635,8 @@ int sglk_merge_state(const void* v_a, const float* s_a, const void* v_b, const f
 
 int sglk_fused_add_rmsnorm_ex(void* x, void* residual, const void* weight, int64_t rows, int hidden, float eps, int gemma,
                               int dtype, const float* partials, int splits, int64_t part_stride, const void* bias,
-                              float* xsum_out, int64_t xs_stride, void* stream) {
+                              float* xsum_out, int64_t xs_stride, float* zero_out, int64_t zero_count, void* stream) {
+  SGLK_CHECK(zero_count >= 0 && (zero_count == 0 || zero_out), "fused_add_rmsnorm_ex: bad zero_out");
   SGLK_CHECK(x && weight, "fused_add_rmsnorm_ex: null pointer");
   SGLK_CHECK(rows >= 0 && hidden > 0 && hidden % 128 == 0 && hidden <= 8192,
              "fused_add_rmsnorm_ex: hidden=%d must be a multiple of 128, at most 8192", hidden);
@@ -648,7 +652,7 @@ int sglk_fused_add_rmsnorm_ex(void* x, void* residual, const void* weight, int64
                                         dim3(std::min(1024, std::max(256, (hidden / 8 + 63) / 64 * 64))), 0,
                                         (hipStream_t)stream,
                                         x, residual, weight, hidden, eps, gemma, partials, splits, part_stride, bias,
-                                        xsum_out, xs_stride));
+                                        xsum_out, xs_stride, zero_out, zero_count));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -75,13 +75,14 @@ class LlamaDecoder:
     def __init__(self, cfg: LlamaConfig, batch: int, pool_slots: int, max_ctx: int, dtype=torch.bfloat16,
                  device="cuda", seed=0, max_kv_splits=8, keep_reference_layout=False):
         self.cfg, self.B, self.dtype, self.device = cfg, batch, dtype, device
+        self._keep_ref = keep_reference_layout
         gen = torch.Generator(device=device).manual_seed(seed)
         c = cfg
         self.q_size, self.kv_size = c.q_heads * c.head_dim, c.kv_heads * c.head_dim
 
-        def lin(K, N):
+        def lin(K, N, keep=False):
             if c.quant == "awq":
-                return _AwqLinear(K, N, c.group_size, dtype, device, gen, keep_reference_layout)
+                return _AwqLinear(K, N, c.group_size, dtype, device, gen, keep_reference_layout or keep)
             return _DenseLinear(K, N, dtype, device, gen)
 
         self.embed = (torch.randn(c.vocab, c.hidden, device=device, generator=gen) * 0.5).to(dtype)
@@ -94,7 +95,7 @@ class LlamaDecoder:
                 ln2=(1.0 + 0.1 * torch.randn(c.hidden, device=device, generator=gen)).to(dtype),
                 qkv=lin(c.hidden, self.q_size + 2 * self.kv_size),
                 o=lin(self.q_size, c.hidden),
-                gate_up=lin(c.hidden, 2 * c.inter),
+                gate_up=lin(c.hidden, 2 * c.inter, keep=True),  # kept until the fused layout has been derived
                 down=lin(c.inter, c.hidden),
             ))
         # rotary cache, layout of RotaryEmbedding._compute_cos_sin_cache (layers/rotary_embedding.py)
@@ -211,6 +212,17 @@ class LlamaDecoder:
                 need = max(self.part_splits[k] * self.B * n for k, (kk, n) in shapes.items())
                 self.partial = torch.empty(need, dtype=torch.float32, device=self.device)
         self.fused = bool(ok)
+        # gate_up with the activation in its epilogue: columns interleaved in blocks of 64 (gate, up, gate, up, ...)
+        self.fused_act = self.fused and c.inter % 128 == 0 and c.hidden % 512 == 0
+        if self.fused_act:
+            for L in self.layers:
+                w = L["gate_up"]
+                if "gate_up_il" not in L and w.qweight is not None:
+                    qw, sc, qz = ops.awq_interleave_gate_up(w.qweight, w.scales, w.qzeros)
+                    L["gate_up_il"] = (ops.awq_repack(qw), sc, qz)
+                    if not self._keep_ref:
+                        w.qweight = None
+            self.fused_act = all("gate_up_il" in L for L in self.layers)
         return self.fused
 
     def _timed(self, name, fn):
@@ -232,6 +244,9 @@ class LlamaDecoder:
                 ops.awq_gemm_partial(self.hidden, w.packed, w.scales, w.qzeros, self.partial, self.xs_hidden)
             elif name == "o":
                 ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, self.partial, self.xs_attn)
+            elif name == "gate_up" and getattr(self, "fused_act", False):
+                il = L["gate_up_il"]
+                ops.awq_gemm_silu_mul(self.hidden, il[0], il[1], il[2], self.act, self.xs_hidden, self.xs_act)
             elif name == "gate_up":
                 ops.awq_gemm_xs(self.hidden, w.packed, w.scales, w.qzeros, self.xs_hidden, self.gate_up, self.workspace)
             else:
@@ -262,11 +277,16 @@ class LlamaDecoder:
             w = L["o"]
             self._timed("o", lambda: ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, P, self.xs_attn))
             ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, partials=P, splits=S["o"],
-                                     xsum_out=self.xs_hidden)
-            w = L["gate_up"]
-            self._timed("gate_up", lambda: ops.awq_gemm_xs(self.hidden, w.packed, w.scales, w.qzeros, self.xs_hidden,
-                                                           self.gate_up, self.workspace))
-            ops.act_and_mul_xs(self.act, self.gate_up, 0, self.xs_act)
+                                     xsum_out=self.xs_hidden, zero_out=self.xs_act if self.fused_act else None)
+            if self.fused_act:
+                il = L["gate_up_il"]
+                self._timed("gate_up", lambda: ops.awq_gemm_silu_mul(self.hidden, il[0], il[1], il[2], self.act,
+                                                                     self.xs_hidden, self.xs_act))
+            else:
+                w = L["gate_up"]
+                self._timed("gate_up", lambda: ops.awq_gemm_xs(self.hidden, w.packed, w.scales, w.qzeros, self.xs_hidden,
+                                                               self.gate_up, self.workspace))
+                ops.act_and_mul_xs(self.act, self.gate_up, 0, self.xs_act)
             w = L["down"]
             self._timed("down", lambda: ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, P, self.xs_act))
         ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])

@@ -452,7 +452,35 @@ def awq_gemm_xs(x, packed, scales, qzeros, xsum, out, workspace, bias=None):
     return out
 
 
-def fused_add_rmsnorm_ex(x, residual, weight, eps, gemma=False, partials=None, splits=0, bias=None, xsum_out=None):
+def awq_interleave_gate_up(qweight, scales, qzeros):
+    """Column order sglk_awq_gemm_silu_mul expects: blocks of 64 gate columns alternate with the matching 64 up
+    columns.  Inputs in the reference layout ([K, N/8] int32, [K/G, N], [K/G, N/8]) with N = 2 * intermediate size."""
+    N = scales.shape[1]
+    inter = N // 2
+    if inter % 64:
+        raise SglkError("awq_interleave_gate_up: intermediate size must be a multiple of 64")
+    t = torch.arange(inter // 64, device=scales.device)
+    blocks = torch.stack([t, t + inter // 64], dim=1).reshape(-1)  # 64-column block order: g0, u0, g1, u1, ...
+    cols = (blocks[:, None] * 64 + torch.arange(64, device=scales.device)[None, :]).reshape(-1)
+    packs = (blocks[:, None] * 8 + torch.arange(8, device=scales.device)[None, :]).reshape(-1)
+    return (qweight.index_select(1, packs).contiguous(), scales.index_select(1, cols).contiguous(),
+            qzeros.index_select(1, packs).contiguous())
+
+
+def awq_gemm_silu_mul(x, packed, scales, qzeros, out, xsum=None, xsum_out=None):
+    """out[M, N/2] = silu(x @ W_gate) * (x @ W_up) on a weight interleaved by awq_interleave_gate_up."""
+    _need_gpu(x, packed, scales, qzeros, out)
+    M, K = x.shape
+    N = scales.shape[1]
+    check(lib().sglk_awq_gemm_silu_mul(_ptr(x), _ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(out), M, N, K,
+                                       K // scales.shape[0], x.stride(0), out.stride(0), dtype_code(x.dtype), _ptr(xsum),
+                                       0 if xsum is None else xsum.stride(0), _ptr(xsum_out),
+                                       0 if xsum_out is None else xsum_out.stride(0), _stream(x)), "awq_gemm_silu_mul")
+    return out
+
+
+def fused_add_rmsnorm_ex(x, residual, weight, eps, gemma=False, partials=None, splits=0, bias=None, xsum_out=None,
+                         zero_out=None):
     """x (and residual) updated in place; the input row may come from `partials` [splits, rows, hidden] fp32."""
     _need_gpu(x, weight)
     hidden = x.shape[-1]
@@ -460,7 +488,8 @@ def fused_add_rmsnorm_ex(x, residual, weight, eps, gemma=False, partials=None, s
     check(lib().sglk_fused_add_rmsnorm_ex(_ptr(x), _ptr(residual), _ptr(weight), rows, hidden, float(eps),
                                           1 if gemma else 0, dtype_code(x.dtype), _ptr(partials), int(splits),
                                           rows * hidden, _ptr(bias), _ptr(xsum_out),
-                                          0 if xsum_out is None else xsum_out.stride(0), _stream(x)),
+                                          0 if xsum_out is None else xsum_out.stride(0), _ptr(zero_out),
+                                          0 if zero_out is None else zero_out.numel(), _stream(x)),
           "fused_add_rmsnorm_ex")
 
 

@@ -158,3 +158,40 @@ def test_fused_decode_step_matches_unfused():
     assert torch.isfinite(l1).all()
     assert (l0 - l1).abs().max().item() < 0.05 * max(1.0, l0.abs().max().item())
     assert (k0 - k1).abs().max().item() < 0.05 * max(1.0, k0.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K,inter", [(64, 1024, 512), (17, 512, 128), (64, 4096, 14336)])
+def test_gate_up_with_activation_epilogue(dtype, M, K, inter):
+    """gate_up GEMM with silu(gate) * up in its epilogue on the interleaved weight: bit-identical to the planner's
+    GEMM on the original weight followed by silu_and_mul (same accumulation order, same rounding points), and the
+    row-block sums it leaves match its output."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_ops import _awq_case
+
+    ops = _ops()
+    N = 2 * inter
+    x, qw, sc, qz = _awq_case(M, K, N, 128, dtype, seed=K + inter)
+    xd, qwd, scd, qzd = x.to(DEV), qw.to(DEV), sc.to(DEV), qz.to(DEV)
+    import os as _os
+    _os.environ["SGLK_AWQ_WIDE"] = "2"  # the comparison kernel must be the wide one (same accumulation order)
+    _os.environ["SGLK_AWQ_WIDE_SPS"] = str(K // 512)  # ... with a single split
+    try:
+        gu = ops.awq_gemm(xd, ops.awq_repack(qwd), scd, qzd)
+    finally:
+        _os.environ.pop("SGLK_AWQ_WIDE", None)
+        _os.environ.pop("SGLK_AWQ_WIDE_SPS", None)
+    want = torch.empty(M, inter, dtype=dtype, device=DEV)
+    ops.act_and_mul(want, gu, 0)
+    qi, si, zi = ops.awq_interleave_gate_up(qwd, scd, qzd)
+    out = torch.full((M, inter), float("nan"), dtype=dtype, device=DEV)
+    xs_out = torch.zeros(inter // 128, M + 1, device=DEV)
+    xs_in = _block_sums(xd)
+    ops.awq_gemm_silu_mul(xd, ops.awq_repack(qi), si, zi, out, None, xs_out)
+    assert torch.equal(out.view(torch.int16), want.view(torch.int16))
+    torch.testing.assert_close(xs_out[:, :M], _block_sums(out), rtol=1e-4, atol=2e-2)
+    # with the producer's block sums of x: same result up to the order of the fp32 block sums
+    out2 = torch.empty_like(out)
+    ops.awq_gemm_silu_mul(xd, ops.awq_repack(qi), si, zi, out2, xs_in, None)
+    assert (out2.float() - out.float()).abs().max().item() <= 2e-2 * max(1.0, out.float().abs().max().item())
