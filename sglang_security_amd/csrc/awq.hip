@@ -556,6 +556,24 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
+  // the same in two halves, issued between the k-steps of the stage being multiplied: the CU's address unit takes 16
+  // cycles per 1-KiB instruction, so eight waves issuing everything at the top of a stage stall each other
+  auto issue_x_half = [&](int stage, int buf, int half) {
+    const uint16_t* src = x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK;
+    char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024 + half * 4096;
+    glds16_off<0>(src + xoff[4 * half + 0], dst);
+    glds16_off<1024>(src + xoff[4 * half + 1] - 512, dst);
+    glds16_off<2048>(src + xoff[4 * half + 2] - 1024, dst);
+    glds16_off<3072>(src + xoff[4 * half + 3] - 1536, dst);
+    if constexpr (XS_EXT) {
+      if (half == 1) {
+        const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
+        glds4(xsum_in + (int64_t)gq * xs_stride + min(m0 + lane, M - 1), smem + Wide::kXsumOff + (buf * 8 + wid) * 256);
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
   // ---- sz DMA: lanes [0, 32) scale pairs of the wave's 64 columns, [32, 40) zero words, the rest repeat
   const bool sz_is_zero = lane >= 32 && lane < 40;
   const int sz_col = lane < 32 ? 2 * lane : 0;
@@ -587,6 +605,10 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   // here were issued before it, so they have landed too
   auto stage_wait = [&](int4v(&w)[4]) {
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
+  };
+  // when x(i+1) was issued last (between the k-steps), everything this wave has in flight must land
+  auto stage_wait_all = [&](int4v(&w)[4]) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
   };
 
   // One accumulator set: R[t][q] holds the running sum of strip t in units of the current group's scale,
@@ -654,7 +676,8 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       const int i = i0 + u;
       const int buf = i & 1;
       stamp_in(i, 0);
-      issue_x((abl & 2) ? 0 : i + 1, buf ^ 1);
+      const bool spread = !(abl & 64);  // x(i+1) goes out between the k-steps below (abl & 64: all at the top)
+      if (!spread || i >= nst) issue_x((abl & 2) ? 0 : i + 1, buf ^ 1);
       issue_sz(i + 2, (u + 2) % 3);
       load_w((abl & 8) ? 0 : i + 2, wreg[(u + 2) % 3]);
       stamp_in(i, 1);
@@ -701,6 +724,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
           }
+          if (spread && ks < 2) issue_x_half(i + 1, buf ^ 1, ks);
         }
         // zero-point term with this group's block sums
         {
@@ -716,7 +740,10 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       }
       stamp_in(i, 2);
       if (i + 1 >= nst) goto stages_done;  // block-uniform: the look-ahead loads are drained below
-      stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
+      if (spread)
+        stage_wait_all(wreg[(u + 1) % 3]);
+      else
+        stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
       stamp_in(i, 3);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

@@ -2,7 +2,7 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SGLK_AWQ_ABL"] = "16"
+os.environ.setdefault("SGLK_AWQ_ABL", "16")
 os.environ["SGLK_AWQ_WIDE"] = "2"
 from sglang_security_amd import ops
 dev = "cuda"
@@ -30,13 +30,19 @@ for name, K, N in [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 286
         torch.cuda.synchronize()
     t = work.view(torch.int32)[2048:4096].view(256, 8).cpu().double()
     t = t[t[:, 0] != 0]
+    if t.shape[0] == 0:
+        print(f"{name}: no stamps")
+        continue
     t0 = t[:, 0].min()
     names = ["start", "prologue", "loop", "reduce", "stored", "split-reduce"]
+    if int(os.environ["SGLK_AWQ_ABL"]) & 32:
+        names = ["stage3", "issued", "computed", "landed", "barrier", "end"]
+        t0 = None
     msg = [f"{name}: blocks={t.shape[0]}"]
     for k in range(6):
         col = t[:, k]
         ok = col != 0
         if ok.any():
-            d = (col[ok] - t0) / 100.0
+            d = (col[ok] - (t0 if t0 is not None else t[ok][:, 0])) / 100.0
             msg.append(f"{names[k]} {d.mean():.2f}/{d.max():.2f}us")
     print("  ".join(msg), flush=True)
