@@ -606,10 +606,6 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   auto stage_wait = [&](int4v(&w)[4]) {
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
   };
-  // when x(i+1) was issued last (between the k-steps), everything this wave has in flight must land
-  auto stage_wait_all = [&](int4v(&w)[4]) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
-  };
 
   // One accumulator set: R[t][q] holds the running sum of strip t in units of the current group's scale,
   //   R = sum_{g' <= g} (s_g' / s_g) * (x . (OFF + q_g') - (OFF + z_g') * X_g'),
@@ -676,10 +672,16 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       const int i = i0 + u;
       const int buf = i & 1;
       stamp_in(i, 0);
-      const bool spread = !(abl & 64);  // x(i+1) goes out between the k-steps below (abl & 64: all at the top)
-      if (!spread || i >= nst) issue_x((abl & 2) ? 0 : i + 1, buf ^ 1);
-      issue_sz(i + 2, (u + 2) % 3);
-      load_w((abl & 8) ? 0 : i + 2, wreg[(u + 2) % 3]);
+      // spread (default): this stage's memory instructions go out between its k-steps, x(i+1) after k-steps 0 and 1,
+      // then sz(i+2) and w(i+2) after k-step 2 -- the CU's address unit takes 16 cycles per 1-KiB instruction, and
+      // eight waves issuing everything at the top of a stage would stall each other there.  Same order as the
+      // all-at-the-top form (abl & 64), so the same counted wait holds.
+      const bool spread = !(abl & 64) && i < nst;
+      if (!spread) {
+        issue_x((abl & 2) ? 0 : i + 1, buf ^ 1);
+        issue_sz(i + 2, (u + 2) % 3);
+        load_w((abl & 8) ? 0 : i + 2, wreg[(u + 2) % 3]);
+      }
       stamp_in(i, 1);
       if (i < nst && !(abl & 4)) {  // block-uniform
         const char* xt = smem + buf * Wide::kXStage;
@@ -724,7 +726,14 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
           }
-          if (spread && ks < 2) issue_x_half(i + 1, buf ^ 1, ks);
+          if (spread) {
+            if (ks < 2) {
+              issue_x_half(i + 1, buf ^ 1, ks);
+            } else if (ks == 2) {
+              issue_sz(i + 2, (u + 2) % 3);
+              load_w(i + 2, wreg[(u + 2) % 3]);
+            }
+          }
         }
         // zero-point term with this group's block sums
         {
@@ -740,10 +749,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       }
       stamp_in(i, 2);
       if (i + 1 >= nst) goto stages_done;  // block-uniform: the look-ahead loads are drained below
-      if (spread)
-        stage_wait_all(wreg[(u + 1) % 3]);
-      else
-        stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
+      stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
       stamp_in(i, 3);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
