@@ -529,25 +529,29 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   stamp(0);
 
   // ---- x DMA: wave w fills pieces 8w .. 8w+7 of a stage; piece p = (tile p >> 4, rows 4 * (p & 15) + g)
-  uint32_t xoff[8];  // element offset of this lane's 16-byte source chunk inside stage 0
+  // byte offset of this lane's 16-byte source chunk inside stage 0, biased so that "uniform base + 32-bit lane offset +
+  // instruction offset" addresses it: piece j is issued with instruction offset 1024 * (j & 3) (which also moves its
+  // LDS destination), the base is moved back by 3072 bytes, and the lane offset carries 3072 - 1024 * (j & 3)
+  uint32_t xoff[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int p = 8 * wid + j;
     const int row = 4 * (p & 15) + g;
-    xoff[j] = (uint32_t)(min(m0 + row, M - 1) * x_stride + 128 * (p >> 4) + 8 * (i16 ^ (row & 15)));
+    xoff[j] = (uint32_t)(2 * (min(m0 + row, M - 1) * x_stride + 128 * (p >> 4) + 8 * (i16 ^ (row & 15))) + 3072 -
+                         1024 * (j & 3));
   }
   auto issue_x = [&](int stage, int buf) {
-    const uint16_t* src = x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK;
+    const char* src = reinterpret_cast<const char*>(x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK) - 3072;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024;
     // eight 1-KiB pieces, two LDS bases (the instruction offset reaches 4095)
     glds16_off<0>(src + xoff[0], dst);
-    glds16_off<1024>(src + xoff[1] - 512, dst);
-    glds16_off<2048>(src + xoff[2] - 1024, dst);
-    glds16_off<3072>(src + xoff[3] - 1536, dst);
+    glds16_off<1024>(src + xoff[1], dst);
+    glds16_off<2048>(src + xoff[2], dst);
+    glds16_off<3072>(src + xoff[3], dst);
     glds16_off<0>(src + xoff[4], dst + 4096);
-    glds16_off<1024>(src + xoff[5] - 512, dst + 4096);
-    glds16_off<2048>(src + xoff[6] - 1024, dst + 4096);
-    glds16_off<3072>(src + xoff[7] - 1536, dst + 4096);
+    glds16_off<1024>(src + xoff[5], dst + 4096);
+    glds16_off<2048>(src + xoff[6], dst + 4096);
+    glds16_off<3072>(src + xoff[7], dst + 4096);
     if constexpr (XS_EXT) {
       // this wave's group of the stage: 64 row sums, one per lane, into the wave's own slot
       const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
@@ -559,12 +563,12 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   // the same in two halves, issued between the k-steps of the stage being multiplied: the CU's address unit takes 16
   // cycles per 1-KiB instruction, so eight waves issuing everything at the top of a stage stall each other
   auto issue_x_half = [&](int stage, int buf, int half) {
-    const uint16_t* src = x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK;
+    const char* src = reinterpret_cast<const char*>(x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK) - 3072;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024 + half * 4096;
     glds16_off<0>(src + xoff[4 * half + 0], dst);
-    glds16_off<1024>(src + xoff[4 * half + 1] - 512, dst);
-    glds16_off<2048>(src + xoff[4 * half + 2] - 1024, dst);
-    glds16_off<3072>(src + xoff[4 * half + 3] - 1536, dst);
+    glds16_off<1024>(src + xoff[4 * half + 1], dst);
+    glds16_off<2048>(src + xoff[4 * half + 2], dst);
+    glds16_off<3072>(src + xoff[4 * half + 3], dst);
     if constexpr (XS_EXT) {
       if (half == 1) {
         const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
