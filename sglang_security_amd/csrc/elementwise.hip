@@ -184,6 +184,17 @@ __global__ void __launch_bounds__(1024) rmsnorm_fused_kernel(void* __restrict__ 
   float keep[MAXV][8];
   float ss = 0.f;
   const int nvec = hidden >> 3;
+  // everything that does not depend on the row statistics is requested up front (norm weights, residual), so that
+  // it travels together with the partial sums instead of after the block reduction
+  short8 wpre[MAXV], rpre[MAXV];
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * blockDim.x;
+    if (v < nvec) {
+      wpre[it] = reinterpret_cast<const short8*>(wr)[v];
+      if (res) rpre[it] = reinterpret_cast<const short8*>(res)[v];
+    }
+  }
 #pragma unroll
   for (int it = 0; it < MAXV; ++it) {
     const int v = threadIdx.x + it * blockDim.x;
@@ -202,7 +213,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_fused_kernel(void* __restrict__ 
         for (int j = 0; j < 8; ++j) keep[it][j] = Conv<T>::to_f32((uint16_t)xv[j]);
       }
       if (res) {
-        const short8 rv = reinterpret_cast<const short8*>(res)[v];
+        const short8 rv = rpre[it];
         short8 ro;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -221,7 +232,7 @@ __global__ void __launch_bounds__(1024) rmsnorm_fused_kernel(void* __restrict__ 
   for (int it = 0; it < MAXV; ++it) {
     const int v = threadIdx.x + it * blockDim.x;
     if (v < nvec) {  // uniform over each group of 16 lanes: hidden % 128 == 0
-      const short8 wv = reinterpret_cast<const short8*>(wr)[v];
+      const short8 wv = wpre[it];
       short8 ov;
       float bs = 0.f;
 #pragma unroll
