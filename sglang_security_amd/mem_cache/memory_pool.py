@@ -138,3 +138,48 @@ class MHATokenToKVPool:
             cache_k = cache_k.to(self.dtype)
             cache_v = cache_v.to(self.dtype)
         ops.set_kv_buffer(self.get_key_buffer(layer_id), self.get_value_buffer(layer_id), loc, cache_k, cache_v)
+
+
+class MLATokenToKVPool:
+    """memory_pool.py:511-647: one latent row per token, kv_buffer [size + page, 1, kv_lora_rank + rope_dim]; keys are
+    the whole row, values its first kv_lora_rank elements (a strided view: the decode kernel takes strides)."""
+
+    def __init__(self, size: int, page_size: int, dtype: torch.dtype, kv_lora_rank: int, qk_rope_head_dim: int,
+                 layer_num: int, device: str, enable_memory_saver: bool = False, start_layer: Optional[int] = None,
+                 end_layer: Optional[int] = None):
+        self.size = size
+        self.page_size = page_size
+        self.dtype = dtype
+        self.store_dtype = dtype
+        self.kv_lora_rank = kv_lora_rank
+        self.qk_rope_head_dim = qk_rope_head_dim
+        self.layer_num = layer_num
+        self.device = device
+        self.start_layer = start_layer or 0
+        self.end_layer = end_layer if end_layer is not None else layer_num - 1
+        self.kv_buffer = [torch.zeros((size + page_size, 1, kv_lora_rank + qk_rope_head_dim), dtype=dtype, device=device)
+                          for _ in range(layer_num)]
+
+    def get_kv_size_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.kv_buffer)
+
+    def get_key_buffer(self, layer_id: int):
+        return self.kv_buffer[layer_id - self.start_layer]
+
+    def get_value_buffer(self, layer_id: int):
+        return self.kv_buffer[layer_id - self.start_layer][..., : self.kv_lora_rank]
+
+    def get_kv_buffer(self, layer_id: int):
+        return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
+
+    def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor):
+        """memory_pool.py:595-611: cache_k is the whole latent row; cache_v is ignored (it is a view of the same data)."""
+        layer_id = layer.layer_id if hasattr(layer, "layer_id") else int(layer)
+        buf = self.kv_buffer[layer_id - self.start_layer]
+        row = cache_k.to(self.dtype).reshape(loc.numel(), 1, -1)
+        ops.set_kv_buffer(buf, buf, loc, row, row)
+
+    def set_mla_kv_buffer(self, layer, loc: torch.Tensor, cache_k_nope: torch.Tensor, cache_k_rope: torch.Tensor):
+        """memory_pool.py:613-625 (set_mla_kv_buffer_triton :446-508): the row is [nope | rope]."""
+        row = torch.cat([cache_k_nope.reshape(loc.numel(), -1), cache_k_rope.reshape(loc.numel(), -1)], dim=-1)
+        self.set_kv_buffer(layer, loc, row, row)

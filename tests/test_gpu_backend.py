@@ -263,3 +263,36 @@ def test_torch_ops_registration():
     mm = torch.ops.sgl_kernel.fp8_scaled_mm.default(a8.to(DEV), b8.to(DEV).t(), sa.to(DEV), sb.to(DEV), torch.bfloat16, None)
     want = oracle.fp8_scaled_mm(a8, b8.t(), sa, sb, torch.bfloat16)
     torch.testing.assert_close(mm.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_mla_pool_and_decode():
+    """MLA latent pool (576 = 512 latent + 64 rope per token, one kv head): pool write, then absorbed-MLA decode (keys =
+    whole row, values = its first 512 elements, a strided view) through the generic kernel, against the oracle."""
+    import oracle
+    from sglang_security_amd import ops
+    from sglang_security_amd.mem_cache.memory_pool import MLATokenToKVPool
+
+    pool = MLATokenToKVPool(256, 1, torch.bfloat16, 512, 64, 2, DEV)
+    g = torch.Generator().manual_seed(6)
+    n = 90
+    nope = torch.randn(n, 1, 512, generator=g).to(torch.bfloat16)
+    rope = torch.randn(n, 1, 64, generator=g).to(torch.bfloat16)
+    loc = (torch.randperm(255, generator=g)[:n] + 1).to(DEV)
+    layer = types.SimpleNamespace(layer_id=1)
+    pool.set_mla_kv_buffer(layer, loc, nope.to(DEV), rope.to(DEV))
+    kb, vb = pool.get_kv_buffer(1)
+    assert torch.equal(kb[loc, 0, :512].cpu(), nope[:, 0]) and torch.equal(kb[loc, 0, 512:].cpu(), rope[:, 0])
+    assert vb.shape[-1] == 512 and not vb.is_contiguous()
+    B, Hq = 2, 16
+    lens = [50, 40]
+    q = torch.randn(B, Hq, 576, generator=g).to(torch.bfloat16)
+    ind = loc[:90].int()
+    ptr = torch.tensor([0, 50, 90], dtype=torch.int32)
+    sm = 1.0 / math.sqrt(192)
+    want = oracle.decode_attention(q, kb.cpu(), vb.cpu().contiguous(), ptr, ind.cpu(), torch.tensor([2, 1], dtype=torch.int32), sm)
+    o = torch.empty(B, Hq, 512, dtype=torch.bfloat16, device=DEV)
+    al = torch.empty(B, Hq, 4, 512, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, 4, dtype=torch.float32, device=DEV)
+    ops.decode_attention_fwd(q.to(DEV), kb, vb, o, ptr.to(DEV), ind, al, lse, torch.tensor([2, 1], dtype=torch.int32, device=DEV),
+                             4, sm, 0.0)
+    assert (o.float().cpu() - want).abs().max().item() < 2e-2
