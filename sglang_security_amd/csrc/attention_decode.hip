@@ -336,121 +336,24 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     if (!active) s1 = s0;  // runs no tile; joins the merge below
   }
 
-  const int hl = lane & 15;  // operand column: query head within this head tile / token within a 16-token half
+  const int hl = lane & 15;  // operand column: query head within this head tile
   const int g = lane >> 4;   // 16-lane group
   const int head_in_group = ht * 16 + hl;
   const bool head_ok = head_in_group < group;
   const int head = kvh * group + head_in_group;
 
-  // Q^T operand: lane (hl, g) holds q[head][32*ks + 8*g .. +8) for ks = 0..3
-  short8 qf[4];
-  {
-    const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (head_ok)
-        qf[ks] = *reinterpret_cast<const short8*>(qp + 32 * ks + 8 * g);
-      else
-        qf[ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-  }
-
-  const float LOG2E = 1.4426950408889634f;
-  const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
-
-  float m = -INFINITY;  // running max (log2 domain), replicated over the four lane groups
-  float lsum = 0.f;     // this lane's share of the running sum
-  float4v oacc[8];
-#pragma unroll
-  for (int n = 0; n < 8; ++n) oacc[n] = float4v{0.f, 0.f, 0.f, 0.f};
-
-  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h;
-  const uint16_t* vbase = reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h;
-  const int32_t* idx = kv_indices + start;
-  const int chunk = lane & 15;  // 16-byte piece of the row this lane fetches
-
-  int4v kreg[8], vreg[8];
-  // fetch tile starting at token t0 into registers: instruction i covers rows 4i + g
-  auto fetch = [&](int t0) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      int tok = t0 + 4 * i + g;
-      tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
-      const int64_t slot = idx[tok];
-      kreg[i] = *reinterpret_cast<const int4v*>(kbase + slot * k_stride_n + chunk * 8);
-      vreg[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
-    }
-  };
-  auto park = [&]() {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = 4 * i + g;
-      *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[i];
-      *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[i];
-    }
-  };
-
-  if (active) fetch(s0);
-  for (int t0 = s0; t0 < s1; t0 += kTile) {
-    park();
-    if (t0 + kTile < s1) fetch(t0 + kTile);  // next tile's rows fly while this one is multiplied
-
-    // ---- S^T = K . Q^T : two 16-token halves, lane (hl, g) gets tokens 16*hh + 4*g + r of head hl
-    float4v sacc[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
-        sacc[hh] = Mfma16<T>::mma(kf, qf[ks], sacc[hh]);
-      }
-    }
-    // ---- scale / cap / mask, online softmax (exp2 domain)
-    float sv[8];
-    float tmax = -INFINITY;
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = sacc[hh][r] * qk_scale;
-        if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
-        const int tok = t0 + 16 * hh + 4 * g + r;
-        s = tok < s1 ? s : -INFINITY;
-        sv[hh * 4 + r] = s;
-        tmax = fmaxf(tmax, s);
-      }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);  // finite: token t0 of this tile is always valid
-    const float alpha = exp2f(m - m_new);
-    m = m_new;
-    float psum = 0.f;
-    short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float p = exp2f(sv[j] - m_new);
-      psum += p;
-      pf[j] = (short)Conv<T>::from_f32(p);
-    }
-    lsum = lsum * alpha + psum;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
-    // ---- O^T += V^T . P^T : eight 16-column blocks of V, read transposed
-    const int i16 = lane & 15;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const int byte_in_row = 32 * n + 8 * (i16 & 3);
-      const short4v lo = lds_read_tr16(vl + v_off(4 * g + (i16 >> 2), byte_in_row));
-      const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (i16 >> 2), byte_in_row));
-      const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
-    }
-  }
+  WaveAttn<T> wa;
+  wa.init();
+  wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                    : nullptr);
+  wa.run(kl, vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+         reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+         kv_indices + start, s0, s1, sm_scale, logit_cap);
+  const float m = wa.m;
+  const float4v(&oacc)[8] = wa.oacc;
 
   // ---- epilogue: total sum over the four lane groups, normalise, store partial
-  lsum += __shfl_xor(lsum, 16, 64);
-  lsum += __shfl_xor(lsum, 32, 64);
+  const float lsum = wa.total();
   if constexpr (MERGE) {
     // this wave's partial: O[16 heads][128] fp32 over its K tile, log-sum-exp[16] at the head of its V tile
     float* po = reinterpret_cast<float*>(kl);

@@ -206,4 +206,154 @@ struct BlockAttn {
   }
 };
 
+// ---------------------------------------------------------------------------------------------------
+// Wave-private streaming attention: one wave walks a gathered token range through its own K/V tile
+// pair in LDS (no block-level synchronisation) and multiplies it against one column tile of 16
+// query rows.  Rows of the next tile fly in registers while the current one is multiplied.
+// ---------------------------------------------------------------------------------------------------
+static constexpr int kWaveAttnLds = 2 * kTileBytes;  // K tile + V tile per wave
+
+template <typename T>
+struct WaveAttn {
+  float m;     // running maximum (log2 domain), replicated over the four lane groups
+  float lsum;  // this lane's share of the running sum
+  float4v oacc[8];
+  short8 qf[4];
+
+  __device__ __forceinline__ void init() {
+    m = -INFINITY;
+    lsum = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) oacc[n] = float4v{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // Q^T operand: this lane's column is the 128-element row at qrow (nullptr: zeros); lane (hl, g)
+  // keeps elements 32*ks + 8*g .. +8 for ks = 0..3.
+  __device__ __forceinline__ void load_q(const uint16_t* qrow) {
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (qrow)
+        qf[ks] = *reinterpret_cast<const short8*>(qrow + 32 * ks + 8 * g);
+      else
+        qf[ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
+  int4v kreg[8], vreg[8];  // one tile in flight: instruction i covers rows 4i + g
+  // pool slots of this lane's eight rows of the tile starting at token t0
+  __device__ __forceinline__ void load_slots(const int32_t* idx, int t0, int s0, int s1, int32_t (&slot)[8]) const {
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      int tok = t0 + 4 * i + g;
+      tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
+      slot[i] = idx[tok];
+    }
+  }
+  __device__ __forceinline__ void fetch_rows(const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                             int64_t v_stride_n, const int32_t (&slot)[8]) {
+    const int chunk = threadIdx.x & 15;  // 16-byte piece of the row this lane fetches
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      kreg[i] = *reinterpret_cast<const int4v*>(kbase + (int64_t)slot[i] * k_stride_n + chunk * 8);
+      vreg[i] = *reinterpret_cast<const int4v*>(vbase + (int64_t)slot[i] * v_stride_n + chunk * 8);
+    }
+  }
+  __device__ __forceinline__ void fetch(const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                        int64_t v_stride_n, const int32_t* idx, int t0, int s0, int s1) {
+    int32_t slot[8];
+    load_slots(idx, t0, s0, s1, slot);
+    fetch_rows(kbase, vbase, k_stride_n, v_stride_n, slot);
+  }
+
+  // Stream tokens [s0, s1) of the slot list idx (wave-uniform range, may be empty).  PREFETCHED: the caller has
+  // already requested the rows of the tile at s0 (fetch / fetch_rows) for a non-empty range.
+  template <bool PREFETCHED = false>
+  __device__ __forceinline__ void run(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
+                                      int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
+                                      float sm_scale, float logit_cap) {
+    const int lane = threadIdx.x & 63;
+    const int hl = lane & 15, g = lane >> 4;
+    const int chunk = lane & 15;
+    const float LOG2E = 1.4426950408889634f;
+    const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+
+    auto park = [&]() {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 4 * i + g;
+        *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[i];
+        *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[i];
+      }
+    };
+
+    if (!PREFETCHED && s1 > s0) fetch(kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
+    for (int t0 = s0; t0 < s1; t0 += kTile) {
+      park();
+      if (t0 + kTile < s1)  // next tile's rows fly while this one is multiplied
+        fetch(kbase, vbase, k_stride_n, v_stride_n, idx, t0 + kTile, s0, s1);
+
+      // ---- S^T = K . Q^T : two 16-token halves, lane (hl, g) gets tokens 16*hh + 4*g + r of column hl
+      float4v sacc[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
+          sacc[hh] = Mfma16<T>::mma(kf, qf[ks], sacc[hh]);
+        }
+      }
+      // ---- scale / cap / mask, online softmax (exp2 domain)
+      float sv[8];
+      float tmax = -INFINITY;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = sacc[hh][r] * qk_scale;
+          if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
+          const int tok = t0 + 16 * hh + 4 * g + r;
+          s = tok < s1 ? s : -INFINITY;
+          sv[hh * 4 + r] = s;
+          tmax = fmaxf(tmax, s);
+        }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m, tmax);  // finite: token t0 of this tile is always valid
+      const float alpha = exp2f(m - m_new);
+      m = m_new;
+      float psum = 0.f;
+      short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float p = exp2f(sv[j] - m_new);
+        psum += p;
+        pf[j] = (short)Conv<T>::from_f32(p);
+      }
+      lsum = lsum * alpha + psum;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
+      // ---- O^T += V^T . P^T : eight 16-column blocks of V, read transposed
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int byte_in_row = 32 * n + 8 * (hl & 3);
+        const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
+        const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
+        const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
+      }
+    }
+  }
+
+  // total of the running sum over the four lane groups
+  __device__ __forceinline__ float total() const {
+    float s = lsum;
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    return s;
+  }
+};
+
 }  // namespace sglk

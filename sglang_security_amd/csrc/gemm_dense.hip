@@ -1,7 +1,8 @@
 // Skinny dense GEMM  out[M,N] = x[M,K] @ W[N,K]^T (+bias)  for 16-bit types: the unquantised lm_head
 // and the bf16 configuration at decode batch sizes.  HBM-bound on W: every wave streams a strip of 16
-// weight rows straight into MFMA operand registers (64 contiguous bytes per lane per 128-k block, no
-// LDS round trip for the operand that is read once), while the activations, which every wave
+// weight rows straight into MFMA operand registers (per load instruction the four lanes of a row
+// cover 64 contiguous bytes, so one instruction touches one cache line per row; no LDS round trip
+// for the operand that is read once), while the activations, which every wave
 // re-reads, are staged through an XOR-swizzled LDS tile shared by the block.
 #include "common.h"
 
@@ -27,7 +28,7 @@ struct DenseMma<f16_t> {
 static constexpr int kDenseXTile = 64 * 256;
 __device__ __forceinline__ int dx_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
 
-template <typename T>
+template <typename T, int NS, int PF>
 __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* __restrict__ x,
                                                                const uint16_t* __restrict__ w,
                                                                const uint16_t* __restrict__ bias,
@@ -41,40 +42,52 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
   const int m0 = blockIdx.z * 64;
   const int kb0 = blockIdx.y * kb_per_split;
   const int nkb = min(kb_per_split, kblocks - kb0);
-  const int n = (blockIdx.x * 4 + wid) * 16 + i16;  // weight row (output column) of this lane
-  const bool n_ok = n < N;
+  const int n0 = (blockIdx.x * 4 + wid) * 16 * NS + i16;  // weight row (output column) of this lane, strip 0
 
   const int xr = threadIdx.x >> 2, xq = threadIdx.x & 3;
   const bool xrow_ok = (m0 + xr) < M;
   const uint16_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
-  int4v xreg[4];
-  auto x_fetch = [&](int kb) {
+  // Activations are requested two k-blocks ahead: loads return in order, so the wait before a tile is
+  // parked leaves only the weight loads issued after its request in flight, and that has to be the
+  // whole weight prefetch depth.
+  int4v xreg[2][4];
+  auto x_fetch = [&](int4v(&xr4)[4], int kb) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      xreg[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * kb + 8 * c) : int4v{0, 0, 0, 0};
+      xr4[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * kb + 8 * c) : int4v{0, 0, 0, 0};
   };
-  auto x_park = [&](int buf) {
+  auto x_park = [&](const int4v(&xr4)[4], int buf) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<int4v*>(xs + buf * kDenseXTile + dx_off(xr, 4 * xq + c)) = xreg[c];
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<int4v*>(xs + buf * kDenseXTile + dx_off(xr, 4 * xq + c)) = xr4[c];
   };
 
-  // lane (i16, g) owns bytes [64g, 64g+64) of its weight row in every 128-k block
-  const uint16_t* wsrc = w + (int64_t)(n_ok ? n : 0) * w_stride + 128 * (int64_t)kb0 + 32 * g;
-  constexpr int PF = 4;
-  int4v wq[PF][4];
+  // lane (i16, g) owns the 16-byte chunks g, 4+g, 8+g, 12+g of its weight row in every 128-k block
+  const uint16_t* wsrc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int n = n0 + 16 * s;
+    wsrc[s] = w + (int64_t)(n < N ? n : 0) * w_stride + 128 * (int64_t)kb0 + 8 * g;
+  }
+  int4v wq[PF][NS][4];
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p < nkb) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) wq[p][c] = *reinterpret_cast<const int4v*>(wsrc + 128 * p + 8 * c);
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wq[p][s][c] = *reinterpret_cast<const int4v*>(wsrc[s] + 128 * p + 32 * c);
     }
 
-  float4v oacc[4];
+  float4v oacc[NS][4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) oacc[mt] = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) oacc[s][mt] = float4v{0.f, 0.f, 0.f, 0.f};
 
-  x_fetch(kb0);
-  x_park(0);
+  static_assert(PF % 2 == 0, "the activation registers alternate with the parity of the k-block");
+  x_fetch(xreg[0], kb0);
+  if (nkb > 1) x_fetch(xreg[1], kb0 + 1);
+  x_park(xreg[0], 0);
   __syncthreads();
 
   for (int base = 0; base < nkb; base += PF) {
@@ -83,38 +96,45 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
       const int j = base + p;
       if (j < nkb) {
         const int buf = j & 1;
-        if (j + 1 < nkb) x_fetch(kb0 + j + 1);
+        if (j + 2 < nkb) x_fetch(xreg[p & 1], kb0 + j + 2);  // block j's own registers were parked a step ago
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          // k-slots of step ks: k = 128*kb + 32*g + 8*ks + e  <->  activation chunk 4*g + ks
+          // k-slots of step ks: k = 128*kb + 32*ks + 8*g + e  <->  activation chunk 4*ks + g
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
-            const int4v af = *reinterpret_cast<const int4v*>(xs + buf * kDenseXTile + dx_off(16 * mt + i16, 4 * g + ks));
-            oacc[mt] = DenseMma<T>::mma(af, wq[p][ks], oacc[mt]);
+            const int4v af = *reinterpret_cast<const int4v*>(xs + buf * kDenseXTile + dx_off(16 * mt + i16, 4 * ks + g));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) oacc[s][mt] = DenseMma<T>::mma(af, wq[p][s][ks], oacc[s][mt]);
           }
         }
         if (j + PF < nkb) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) wq[p][c] = *reinterpret_cast<const int4v*>(wsrc + 128 * (int64_t)(j + PF) + 8 * c);
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              wq[p][s][c] = *reinterpret_cast<const int4v*>(wsrc[s] + 128 * (int64_t)(j + PF) + 32 * c);
         }
-        if (j + 1 < nkb) x_park(buf ^ 1);
+        if (j + 1 < nkb) x_park(xreg[(p + 1) & 1], buf ^ 1);
         __syncthreads();
       }
     }
   }
 
   const bool direct = partial == nullptr;
-  const float bv = (direct && bias && n_ok) ? Conv<T>::to_f32(bias[n]) : 0.f;
-  if (n_ok) {
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int n = n0 + 16 * s;
+    if (n >= N) continue;
+    const float bv = (direct && bias) ? Conv<T>::to_f32(bias[n]) : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + 16 * mt + 4 * g + r;
         if (direct) {
-          if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(oacc[mt][r] + bv);
+          if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(oacc[s][mt][r] + bv);
         } else {
-          partial[((int64_t)blockIdx.y * Mpad + m) * N + n] = oacc[mt][r];
+          partial[((int64_t)blockIdx.y * Mpad + m) * N + n] = oacc[s][mt][r];
         }
       }
   }
@@ -127,8 +147,8 @@ using namespace sglk;
 extern "C" {
 
 // Dense split-K needs scratch; this entry point keeps the weights' whole K in one block when N gives
-// enough blocks (lm_head: 2004 blocks) and otherwise runs unsplit as well: the strips are 16 rows of W,
-// so even N = 4096 yields 64 blocks x 4 waves.  (The AWQ path owns the split-K machinery.)
+// enough blocks (lm_head: 1002 blocks of 128 rows) and otherwise runs unsplit as well: the strips are
+// 16 rows of W, so even N = 4096 yields 64 blocks x 4 waves.  (The AWQ path owns the split-K machinery.)
 int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
                        int64_t x_stride, int64_t w_stride, int64_t out_stride, int dtype, void* stream) {
   SGLK_CHECK(x && w && out, "dense_gemm_nt: null pointer");
@@ -137,12 +157,26 @@ int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out
   SGLK_CHECK(aligned16(x) && aligned16(w) && x_stride % 8 == 0 && w_stride % 8 == 0,
              "dense_gemm_nt: rows must be 16-byte aligned");
   const int mblocks = (M + 63) / 64;
-  dim3 grid((N + 63) / 64, 1, mblocks);
-  SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((dense_gemm_nt_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream,
-                                        (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias, (uint16_t*)out,
-                                        (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride, w_stride,
-                                        out_stride));
+  // two strips per wave halve the activation re-reads; kept for wide outputs only, where the grid still
+  // fills the chip several times over
+  const char* env = getenv("SGLK_DENSE_NS");  // 1 / 2 forces the strips per wave (tests)
+  const int force = env ? atoi(env) : 0;
+  const bool two = force ? force == 2 : N >= 64 * 1024;
+  if (two) {
+    dim3 grid((N + 127) / 128, 1, mblocks);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 2, 2>), grid, dim3(256), 0, (hipStream_t)stream,
+                                          (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,
+                                          (uint16_t*)out, (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride,
+                                          w_stride, out_stride));
+  } else {
+    dim3 grid((N + 63) / 64, 1, mblocks);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 1, 4>), grid, dim3(256), 0, (hipStream_t)stream,
+                                          (const uint16_t*)x, (const uint16_t*)w, (const uint16_t*)bias,
+                                          (uint16_t*)out, (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride,
+                                          w_stride, out_stride));
+  }
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -162,9 +162,14 @@ def _run_shared(ops, q, kb, vb, ptr, ind, gi, pls, max_splits, dtype, sm, cap=0.
     B, Hq, D = q.shape
     o = torch.full((B, Hq, D), float("nan"), dtype=dtype, device=DEV)
     ws = torch.empty(ops.decode_shared_workspace_bytes(B, Hq, D, max_splits) // 4, dtype=torch.float32, device=DEV)
-    ops.decode_attention_shared_prefix(q.to(DEV), kb.to(DEV), vb.to(DEV), o, ptr.to(DEV), ind.to(DEV), gi.to(DEV),
-                                       pls.to(DEV), ws, max_splits, sm, cap)
+    args = (q.to(DEV), kb.to(DEV), vb.to(DEV))
+    meta = (ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV))
+    ops.decode_attention_shared_prefix(*args, o, *meta, ws, max_splits, sm, cap)
     torch.cuda.synchronize()
+    o2 = torch.full_like(o, float("nan"))  # the workspace carries nothing from one call to the next
+    ops.decode_attention_shared_prefix(*args, o2, *meta, ws, max_splits, sm, cap)
+    torch.cuda.synchronize()
+    assert torch.equal(o.view(torch.int16), o2.view(torch.int16))
     return o.float().cpu()
 
 
@@ -174,6 +179,9 @@ def _run_shared(ops, q, kb, vb, ptr, ind, gi, pls, max_splits, dtype, sm, cap=0.
     ([(3, 200, 1, 30), (1, 0, 5, 90), (7, 33, 1, 300)], 32, 8, 8),  # three groups; one without prefix; long tails
     ([(40, 64, 1, 10)], 8, 8, 2),                       # MHA, more columns than one block holds
     ([(2, 1, 1, 1), (2, 700, 600, 600)], 16, 2, 16),    # prefix of one token; tails longer than four splits' worth
+    ([(21, 150, 1, 70), (3, 40, 1, 5)], 28, 4, 5),      # 7 heads per kv head: requests straddle column blocks
+    ([(3, 70, 1, 40)], 32, 1, 3),                       # 32 heads per kv head: two head tiles
+    ([(4, 64, 0, 0), (2, 0, 1, 3)], 8, 2, 2),           # empty remainders beside a group without a prefix
 ])
 def test_shared_prefix_decode_vs_oracle(dtype, groups, Hq, Hkv, max_splits):
     import oracle

@@ -124,9 +124,11 @@ def test_awq_gemm_llama8b_shapes_linearity(M, K, N):
 
 @pytest.mark.parametrize("M,K,N", [(64, 512, 256), (3, 1024, 100), (64, 4096, 1000)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_dense_gemm_nt(M, K, N, dtype):
+@pytest.mark.parametrize("strips", [1, 2])
+def test_dense_gemm_nt(M, K, N, dtype, strips, monkeypatch):
     import oracle
 
+    monkeypatch.setenv("SGLK_DENSE_NS", str(strips))  # both kernel shapes (two strips per wave is the lm_head one)
     ops = _ops()
     g = torch.Generator().manual_seed(N)
     x = torch.randn(M, K, generator=g).to(dtype)

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--m", type=int, default=64)
 ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--dense", action="store_true")
+ap.add_argument("--copies", type=int, default=0, help="weight copies to rotate over (1: weights stay in the Infinity Cache)")
 ap.add_argument("--eager", action="store_true", help="plain launches, no graph (counter collection)")
 ap.add_argument("--stamps", action="store_true", help="per-phase clock stamps of the wide AWQ kernel (run with SGLK_AWQ_ABL=16)")
 args = ap.parse_args()
@@ -26,7 +27,7 @@ if args.dense:
 gen = torch.Generator(device=dev).manual_seed(0)
 for name, K, N in shapes:
     wbytes = K * N // 2 + (K // 128) * N * 2 + (K // 128) * N // 2 if not args.dense else K * N * 2
-    copies = max(2, int(600e6 // wbytes) + 1)
+    copies = args.copies or max(2, int(600e6 // wbytes) + 1)
     x = torch.randn(M, K, device=dev, generator=gen).to(torch.bfloat16)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     ws = []
