@@ -428,6 +428,166 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
 
 
 // ---------------------------------------------------------------------------------------------
+// absorbed-MLA decode (D = 576, Dv = 512, V = the first 512 elements of the K row): a token's latent row
+// is fetched once and serves as K (all 576 elements) and as V.  A block of four waves owns one tile of
+// 16 query heads and walks its token range in tiles of 32 rows through one LDS stage:
+//   S^T = K . Q^T   the 18 k-steps of the 576-deep product are dealt round-robin to the four waves,
+//                   whose partial score tiles meet in LDS (every wave then holds the full scores and
+//                   runs the same online softmax);
+//   O^T += V^T . P^T  wave w owns output elements [128w, 128w + 128).
+// Rows sit in LDS at a padded pitch of 1168 bytes: the 16 rows of a K operand read fall on 16
+// different 16-byte slots of the bank row without a swizzle, and the transposed V reads address the
+// same bytes.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kMlaD = 576, kMlaDv = 512;
+static constexpr int kMlaPitch = kMlaD * 2 + 16;
+static constexpr int kMlaTileBytes = kTile * kMlaPitch;  // 37376
+static constexpr int kMlaScoreBytes = 4 * 2 * 64 * 16;   // four waves' partial score tiles
+static constexpr int kMlaLds = kMlaTileBytes + kMlaScoreBytes;
+
+template <typename T>
+__global__ void __launch_bounds__(256, 3) decode_stage1_mla(
+    const void* __restrict__ q, const void* __restrict__ kv_buffer, const int32_t* __restrict__ kv_indptr,
+    const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits, float* __restrict__ attn_lse,
+    const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, float sm_scale, float logit_cap) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* tile = lds;
+  float4v* sbuf = reinterpret_cast<float4v*>(lds + kMlaTileBytes);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int hl = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  const int kvh = blockIdx.y / head_tiles, ht = blockIdx.y - kvh * head_tiles;
+  const int split = blockIdx.z;
+  const int group = Hq / Hkv;
+  const int start = kv_indptr[b];
+  const int len = kv_indptr[b + 1] - start;
+  const int splits = max(num_kv_splits[b], 1);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int s0 = per_split * split, s1 = min(s0 + per_split, len);
+  if (s1 <= s0) return;  // block-uniform
+  const int head_in_group = ht * 16 + hl;
+  const bool head_ok = head_in_group < group;
+  const int head = kvh * group + head_in_group;
+
+  // Q^T operand of this wave's k-steps wid, wid + 4, ...: lane (hl, g) holds q[head][32*ks + 8*g .. +8)
+  constexpr int kSteps = kMlaD / 32;  // 18
+  short8 qf[5];
+  {
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int ks = wid + 4 * i;
+      if (head_ok && ks < kSteps)
+        qf[i] = *reinterpret_cast<const short8*>(qp + 32 * ks + 8 * g);
+      else
+        qf[i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+  const float LOG2E = 1.4426950408889634f;
+  const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+  float m = -INFINITY, lsum = 0.f;
+  float4v oacc[8];
+#pragma unroll
+  for (int n = 0; n < 8; ++n) oacc[n] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  // tile fetch: eight threads per row, thread (row, sub) takes 16-byte pieces sub, sub + 8, ..., sub + 64
+  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(kv_buffer) + (int64_t)kvh * k_stride_h;
+  const int32_t* idx = kv_indices + start;
+  const int frow = threadIdx.x >> 3, fsub = threadIdx.x & 7;
+  int4v kreg[9];
+  auto fetch = [&](int t0) {
+    int tok = t0 + frow;
+    tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
+    const uint16_t* row = kbase + (int64_t)idx[tok] * k_stride_n + fsub * 8;
+#pragma unroll
+    for (int j = 0; j < 9; ++j) kreg[j] = *reinterpret_cast<const int4v*>(row + 64 * j);
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) *reinterpret_cast<int4v*>(tile + frow * kMlaPitch + (fsub + 8 * j) * 16) = kreg[j];
+  };
+
+  fetch(s0);
+  for (int t0 = s0; t0 < s1; t0 += kTile) {
+    __syncthreads();  // every wave is done with the previous tile
+    park();
+    __syncthreads();
+    if (t0 + kTile < s1) fetch(t0 + kTile);  // next tile's rows fly while this one is multiplied
+    // ---- this wave's share of S^T = K . Q^T
+    float4v sacc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int ks = wid + 4 * i;
+        if (ks < kSteps) {  // wave-uniform
+          const short8 kf = *reinterpret_cast<const short8*>(tile + (16 * hh + hl) * kMlaPitch + (4 * ks + g) * 16);
+          sacc[hh] = Mfma16<T>::mma(kf, qf[i], sacc[hh]);
+        }
+      }
+      sbuf[(wid * 2 + hh) * 64 + lane] = sacc[hh];
+    }
+    __syncthreads();
+    // ---- full scores (same sum order in every wave), scale / cap / mask, online softmax (exp2 domain)
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      float4v tot = sbuf[hh * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) tot += sbuf[(w * 2 + hh) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float sc = tot[r] * qk_scale;
+        if (logit_cap > 0.f) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
+        const int tok = t0 + 16 * hh + 4 * g + r;
+        sc = tok < s1 ? sc : -INFINITY;
+        sv[hh * 4 + r] = sc;
+        tmax = fmaxf(tmax, sc);
+      }
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);  // finite: token t0 of this tile is always valid
+    const float alpha = exp2f(m - m_new);
+    m = m_new;
+    float psum = 0.f;
+    short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p = exp2f(sv[j] - m_new);
+      psum += p;
+      pf[j] = (short)Conv<T>::from_f32(p);
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
+    // ---- O^T += V^T . P^T over this wave's 128 output elements, V read transposed out of the K rows
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int byte_in_row = 256 * wid + 32 * n + 8 * (hl & 3);
+      const short4v lo = lds_read_tr16(tile + (4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
+      const short4v hi = lds_read_tr16(tile + (16 + 4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
+      const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
+    }
+  }
+
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (head_ok) {
+    const float inv = 1.0f / lsum;
+    const int64_t ob = ((int64_t)b * Hq + head) * max_kv_splits + split;
+    float* dst = attn_logits + ob * kMlaDv + 128 * wid;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[n] * inv;
+    if (wid == 0 && g == 0) attn_lse[ob] = (m + log2f(lsum)) * 0.6931471805599453f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // shared-prefix decode: the prefix of a group is streamed once per (kv head, split, 128 columns)
 // and multiplied against every (request, head) column of the group
 // ---------------------------------------------------------------------------------------------
@@ -569,7 +729,19 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
                     aligned16(k_buffer) && aligned16(v_buffer) && aligned16(attn_logits) && (q_stride_b % 8 == 0) &&
                     (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) && (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) &&
                     (v_stride_h % 8 == 0);
-  if (fast) {
+  // absorbed MLA: V is a view of the first 512 elements of the 576-element K rows (memory_pool.py:492-521)
+  const bool mla = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == kMlaD && Dv == kMlaDv && v_buffer == k_buffer &&
+                   v_stride_n == k_stride_n && v_stride_h == k_stride_h && aligned16(q) && aligned16(k_buffer) &&
+                   aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
+                   (k_stride_h % 8 == 0);
+  if (mla) {
+    const int head_tiles = (group + 15) / 16;
+    dim3 grid(B, Hkv * head_tiles, max_kv_splits);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((decode_stage1_mla<T>), grid, dim3(256), kMlaLds, s, q, k_buffer, kv_indptr,
+                                          kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv,
+                                          head_tiles, q_stride_b, q_stride_h, k_stride_n, k_stride_h, sm_scale, logit_cap));
+  } else if (fast) {
     const int head_tiles = (group + 15) / 16;
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
     const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;

@@ -161,6 +161,47 @@ def test_decode_attention_vs_oracle(dtype, B, Hq, Hkv, prefix, max_splits):
     assert cos.item() > 0.999
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Hq,max_len,max_splits,cap", [(3, 16, 70, 4, 0.0), (4, 128, 500, 8, 0.0), (2, 24, 1300, 16, 30.0),
+                                                        (5, 16, 31, 2, 0.0)])
+def test_decode_attention_mla(dtype, B, Hq, max_len, max_splits, cap):
+    """Absorbed-MLA decode (memory_pool.py:492-521: one latent row of 576 per token, values = a view of its first
+    512 elements) on the matrix-core kernel, against the C oracle and against the generic kernel (which a separate
+    copy of the values selects)."""
+    import oracle
+
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B * 1000 + Hq)
+    lens = [int(torch.randint(1, max_len + 1, (1,), generator=gen)) for _ in range(B)]
+    lens[0] = max_len
+    n = sum(lens) + 7
+    kv = torch.randn(n, 1, 576, generator=gen).to(dtype)
+    q = (torch.randn(B, Hq, 576, generator=gen) * 0.5).to(dtype)
+    perm = torch.randperm(n - 1, generator=gen)[:sum(lens)] + 1
+    ind = perm.to(torch.int32)
+    ptr = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    ns_d = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(ns_d, torch.tensor(lens, device=DEV), Hq, 1, max_splits, 256)
+    sm = 1.0 / math.sqrt(192)
+    want = oracle.decode_attention(q, kv, kv[..., :512].contiguous(), ptr, ind, ns_d.cpu(), sm, cap)
+    kv_d = kv.to(DEV)
+
+    def run(vb):
+        o = torch.full((B, Hq, 512), float("nan"), dtype=dtype, device=DEV)
+        al = torch.empty(B, Hq, max_splits, 512, dtype=torch.float32, device=DEV)
+        lse = torch.empty(B, Hq, max_splits, dtype=torch.float32, device=DEV)
+        ops.decode_attention_fwd(q.to(DEV), kv_d, vb, o, ptr.to(DEV), ind.to(DEV), al, lse, ns_d, max_splits, sm, cap)
+        torch.cuda.synchronize()
+        return o.float().cpu()
+
+    fast = run(kv_d[..., :512])
+    generic = run(kv_d[..., :512].contiguous())
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(fast).all()
+    assert (fast - want).abs().max().item() < tol
+    assert (fast - generic).abs().max().item() < tol
+
+
 def test_decode_attention_noncontiguous_pool():
     """Pools with permuted head/token strides, as the reference CPU test builds them
     (test/srt/cpu/test_decode.py:103-107)."""

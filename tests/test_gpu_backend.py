@@ -267,7 +267,7 @@ def test_torch_ops_registration():
 
 def test_mla_pool_and_decode():
     """MLA latent pool (576 = 512 latent + 64 rope per token, one kv head): pool write, then absorbed-MLA decode (keys =
-    whole row, values = its first 512 elements, a strided view) through the generic kernel, against the oracle."""
+    whole row, values = its first 512 elements, a strided view of the same rows), against the oracle."""
     import oracle
     from sglang_security_amd import ops
     from sglang_security_amd.mem_cache.memory_pool import MLATokenToKVPool
