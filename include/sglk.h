@@ -327,6 +327,34 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm(const void* a, const void* b_nk, const
                                           int64_t sb_stride_n, int64_t sb_stride_k, int out_dtype,
                                           void* stream);
 
+/* Batched fp8 matmul with one scale per operand: out[b] = (A[b] @ B[b]) * scale_a[0] * scale_b[0], A [batch, M, K]
+ * row-major, B given as [batch, N, K] row-major (the reference's column-major [batch, K, N]); either operand (not
+ * both) may be e5m2.  Replaces bmm_fp8, sgl-kernel/csrc/gemm/bmm_fp8.cu:23-76 (python/sgl_kernel/gemm.py:66-82),
+ * which DeepSeek's absorbed MLA uses for the per-head q / o projections. */
+SGLK_API int sglk_bmm_fp8(const void* a, const void* b_nk, const float* scale_a, const float* scale_b,
+                          void* out, int batch, int M, int N, int K, int64_t a_batch_stride,
+                          int64_t a_stride, int64_t b_batch_stride, int64_t b_stride,
+                          int64_t out_batch_stride, int64_t out_stride, int a_e5m2, int b_e5m2,
+                          int out_dtype, void* stream);
+
+/* ------------------------------------------------------------------ MoE routing helpers ------- */
+
+/* Group the numel (token, k) slots of topk_ids by expert, every expert's run padded to a multiple of
+ * block_size: sorted_token_ids (pre-filled by the caller with numel, the padding value), expert_ids
+ * [num_tokens_post_pad / block_size], num_tokens_post_pad [1]; cumsum_buffer [num_experts + 1] (optional)
+ * receives the padded prefix sums.  Slots of one expert keep their order of appearance.  Replaces
+ * moe_align_block_size, sgl-kernel/csrc/moe/moe_align_kernel.cu:160-227 (torch_extension_rocm.cc:60-63). */
+SGLK_API int sglk_moe_align_block_size(const void* topk_ids, int ids_is64, int64_t numel,
+                                       int num_experts, int block_size, int32_t* sorted_token_ids,
+                                       int32_t* expert_ids, int32_t* num_tokens_post_pad,
+                                       int32_t* cumsum_buffer, void* stream);
+/* Softmax over the experts of gating_output [num_tokens, num_experts], then the topk largest per row:
+ * topk_weights fp32, topk_ids int32, token_expert_indices[t, j] = j * num_tokens + t.  Replaces topk_softmax,
+ * sgl-kernel/csrc/moe/moe_topk_softmax_kernels.cu:477-505 (torch_extension_rocm.cc:65-68). */
+SGLK_API int sglk_topk_softmax(const void* gating_output, float* topk_weights, int32_t* topk_ids,
+                               int32_t* token_expert_indices, int num_tokens, int num_experts,
+                               int topk, int64_t gating_stride, int dtype, void* stream);
+
 /* ------------------------------------------------------------------ C1: custom all-reduce ----- */
 
 /* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.

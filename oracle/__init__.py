@@ -249,3 +249,36 @@ def allreduce_sum(bufs, dtype):
     out = np.zeros(arrs[0].shape, dtype=np.float32)
     lib().oracle_allreduce_sum(ptrs, C.c_int(len(arrs)), _p(out), C.c_int64(n), C.c_int(_DT[dtype]))
     return torch.from_numpy(out).to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------- MoE routing, bmm_fp8
+def moe_align_block_size(topk_ids, num_experts, block_size):
+    """Returns (sorted_token_ids padded with numel, expert_ids, num_tokens_post_pad) as int32 tensors."""
+    ids = _i64(topk_ids).reshape(-1)
+    numel = ids.shape[0]
+    cap = numel + num_experts * (block_size - 1)
+    srt = np.full(cap, numel, dtype=np.int32)
+    ex = np.full((cap + block_size - 1) // block_size, -1, dtype=np.int32)
+    tot = np.zeros(1, dtype=np.int32)
+    lib().oracle_moe_align_block_size(_p(ids), C.c_int64(numel), C.c_int(num_experts), C.c_int(block_size), _p(srt),
+                                      _p(ex), _p(tot))
+    return torch.from_numpy(srt), torch.from_numpy(ex), int(tot[0])
+
+
+def topk_softmax(gating_output, topk):
+    g = _f32(gating_output)
+    T, E = g.shape
+    w = np.zeros((T, topk), dtype=np.float32)
+    ids = np.zeros((T, topk), dtype=np.int32)
+    src = np.zeros((T, topk), dtype=np.int32)
+    lib().oracle_topk_softmax(_p(g), _p(w), _p(ids), _p(src), C.c_int(T), C.c_int(E), C.c_int(topk))
+    return torch.from_numpy(w), torch.from_numpy(ids), torch.from_numpy(src)
+
+
+def bmm_fp8(A, B, A_scale, B_scale, dtype):
+    """out[b] = (A[b] @ B[b]) * A_scale * B_scale with the fp8 operands widened exactly and fp32 accumulation
+    (the arithmetic of bmm_fp8, sgl-kernel/csrc/gemm/bmm_fp8.cu:23-76, up to summation order); rounded to dtype."""
+    a = A.detach().cpu().to(torch.float32)
+    b = B.detach().cpu().to(torch.float32)
+    out = torch.bmm(a, b) * float(A_scale) * float(B_scale)
+    return out.to(dtype)

@@ -543,3 +543,53 @@ ORACLE_API void oracle_allreduce_sum(const float* const* bufs, int world, float*
     out[i] = round_to(acc, dtype);
   }
 }
+
+
+/* ------------------------------------------------------------------------------------------------
+ * MoE routing helpers.
+ * moe_align_block_size: sgl-kernel/csrc/moe/moe_align_kernel.cu:43-100 (counts, padded prefix sums, expert id per
+ * block) with the placement of :27-41 made deterministic: slots of one expert in order of appearance.
+ * ------------------------------------------------------------------------------------------------ */
+void oracle_moe_align_block_size(const int64_t* topk_ids, int64_t numel, int num_experts, int block_size,
+                                 int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad) {
+  int32_t* counts = (int32_t*)calloc((size_t)num_experts, sizeof(int32_t));
+  int32_t* cumsum = (int32_t*)calloc((size_t)num_experts + 1, sizeof(int32_t));
+  for (int64_t i = 0; i < numel; ++i)
+    if (topk_ids[i] >= 0 && topk_ids[i] < num_experts) counts[topk_ids[i]]++;
+  for (int e = 0; e < num_experts; ++e)
+    cumsum[e + 1] = cumsum[e] + (counts[e] + block_size - 1) / block_size * block_size;
+  *num_tokens_post_pad = cumsum[num_experts];
+  for (int e = 0; e < num_experts; ++e)
+    for (int32_t i = cumsum[e]; i < cumsum[e + 1]; i += block_size) expert_ids[i / block_size] = e;
+  for (int e = 0; e < num_experts; ++e) counts[e] = 0;
+  for (int64_t i = 0; i < numel; ++i) {
+    const int64_t e = topk_ids[i];
+    if (e >= 0 && e < num_experts) sorted_token_ids[cumsum[e] + counts[e]++] = (int32_t)i;
+  }
+  free(counts);
+  free(cumsum);
+}
+
+/* topk_softmax: softmax over the experts, k rounds of arg-max, ties to the lowest expert id
+ * (sgl-kernel/csrc/moe/moe_topk_softmax_kernels.cu:104-160). */
+void oracle_topk_softmax(const float* gating, float* weights, int32_t* ids, int32_t* source_rows, int rows,
+                         int num_experts, int k) {
+  float* p = (float*)malloc((size_t)num_experts * sizeof(float));
+  for (int r = 0; r < rows; ++r) {
+    const float* g = gating + (int64_t)r * num_experts;
+    float mx = -INFINITY, sum = 0.f;
+    for (int e = 0; e < num_experts; ++e) mx = fmaxf(mx, g[e]);
+    for (int e = 0; e < num_experts; ++e) sum += expf(g[e] - mx);
+    for (int e = 0; e < num_experts; ++e) p[e] = g[e];
+    for (int j = 0; j < k; ++j) {
+      int best = 0;
+      for (int e = 1; e < num_experts; ++e)
+        if (p[e] > p[best]) best = e;
+      weights[(int64_t)r * k + j] = expf(p[best] - mx) / sum;
+      ids[(int64_t)r * k + j] = best;
+      source_rows[(int64_t)r * k + j] = j * rows + r;
+      p[best] = -INFINITY;
+    }
+  }
+  free(p);
+}

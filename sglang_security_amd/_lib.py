@@ -63,6 +63,9 @@ _SIGS = {
     "sglk_per_tensor_quant_fp8": (i32, [p, p, p, i64, i32, i32, p]),
     "sglk_fp8_scaled_mm": (i32, [p, p, p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_fp8_blockwise_scaled_mm": (i32, [p, p, p, p, p, i32, i32, i32, i64, i64, i64, i64, i32, p]),
+    "sglk_bmm_fp8": (i32, [p, p, p, p, p, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, p]),
+    "sglk_moe_align_block_size": (i32, [p, i32, i64, i32, i32, p, p, p, p, p]),
+    "sglk_topk_softmax": (i32, [p, p, p, p, i32, i32, i32, i64, i32, p]),
     "sglk_ar_meta_size": (i64, []),
     "sglk_ar_init": (i64, [p, i32, i32, i32, i64]),
     "sglk_ar_dispose": (i32, [i64]),

@@ -181,7 +181,20 @@ struct MmArgs {
   int M, N, K;
   int64_t a_stride, b_stride, out_stride;
   int64_t sa_m, sa_k, sb_n, sb_k;
+  int64_t a_batch, b_batch, out_batch;  // element strides between the matrices of a batch (blockIdx.z)
+  int scalar_scales;                    // one scale per operand for the whole batch (bmm_fp8)
 };
+
+// operand formats of the 16x16x32 MFMA: e4m3 x e4m3, e5m2 x e4m3, e4m3 x e5m2
+template <int FMT>
+__device__ __forceinline__ f32x4 mma_f8(long a, long b, f32x4 c) {
+  if constexpr (FMT == 1)
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(a, b, c, 0, 0, 0);
+  else if constexpr (FMT == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(a, b, c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ void load32(const uint8_t* row, int k, int K, long (&r)[4]) {
   // K % 16 == 0: 16-byte chunks are all-or-nothing
@@ -194,7 +207,7 @@ __device__ __forceinline__ void load32(const uint8_t* row, int k, int K, long (&
   r[3] = (long)(uint32_t)hi.z | ((long)hi.w << 32);
 }
 
-template <typename TO, int MT, bool BLOCKWISE>
+template <typename TO, int MT, bool BLOCKWISE, int FMT = 0>
 __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
   __shared__ float red[4][MT * 2][64][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -205,14 +218,14 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     mrow[i] = min(m0 + 16 * i + l16, p.M - 1);
-    arow[i] = p.a + (int64_t)mrow[i] * p.a_stride;
+    arow[i] = p.a + (int64_t)blockIdx.z * p.a_batch + (int64_t)mrow[i] * p.a_stride;
   }
   const uint8_t* brow[2];
   int ncol[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     ncol[j] = min(n0 + 16 * j + l16, p.N - 1);
-    brow[j] = p.b + (int64_t)ncol[j] * p.b_stride;
+    brow[j] = p.b + (int64_t)blockIdx.z * p.b_batch + (int64_t)ncol[j] * p.b_stride;
   }
   f32x4 tot[MT][2];
 #pragma unroll
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
       for (int j = 0; j < 2; ++j) {
         f32x4 acc = BLOCKWISE ? f32x4{0.f, 0.f, 0.f, 0.f} : tot[i][j];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(af[i][s], bf[j][s], acc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) acc = mma_f8<FMT>(af[i][s], bf[j][s], acc);
         if constexpr (BLOCKWISE) {
           // C layout: column = lane & 15, row = 4 * (lane >> 4) + r
           const float bs = p.sb[(int64_t)(ncol[j] / 128) * p.sb_n + (int64_t)kb * p.sb_k];
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
     if (n >= p.N) continue;
     float sbn = 1.f, bn = 0.f;
     if constexpr (!BLOCKWISE) {
-      sbn = p.sb[n];
+      sbn = p.sb[p.scalar_scales ? 0 : n];
       if (p.bias) bn = ld<TO>(p.bias, n);
     }
 #pragma unroll
@@ -276,21 +289,22 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
       const int m = m0 + 16 * i + 4 * g + r;
       if (m >= p.M) continue;
       float v = s[r];
-      if constexpr (!BLOCKWISE) v = v * p.sa[m] * sbn + bn;
-      st<TO>(p.out, (int64_t)m * p.out_stride + n, v);
+      if constexpr (!BLOCKWISE) v = v * p.sa[p.scalar_scales ? 0 : m] * sbn + bn;
+      st<TO>(p.out, (int64_t)blockIdx.z * p.out_batch + (int64_t)m * p.out_stride + n, v);
     }
   }
 }
 
-template <typename TO, bool BLOCKWISE>
-int launch_mm(const MmArgs& p, hipStream_t s) {
+template <typename TO, bool BLOCKWISE, int FMT = 0>
+int launch_mm(const MmArgs& p, hipStream_t s, int batch = 1) {
   const dim3 block(256);
+  const unsigned nb = (p.N + 31) / 32, z = (unsigned)batch;
   if (p.M <= 16) {
-    hipLaunchKernelGGL((fp8_mm_kernel<TO, 1, BLOCKWISE>), dim3((p.N + 31) / 32, (p.M + 15) / 16), block, 0, s, p);
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 1, BLOCKWISE, FMT>), dim3(nb, (p.M + 15) / 16, z), block, 0, s, p);
   } else if (p.M <= 32) {
-    hipLaunchKernelGGL((fp8_mm_kernel<TO, 2, BLOCKWISE>), dim3((p.N + 31) / 32, (p.M + 31) / 32), block, 0, s, p);
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 2, BLOCKWISE, FMT>), dim3(nb, (p.M + 31) / 32, z), block, 0, s, p);
   } else {
-    hipLaunchKernelGGL((fp8_mm_kernel<TO, 4, BLOCKWISE>), dim3((p.N + 31) / 32, (p.M + 63) / 64), block, 0, s, p);
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 4, BLOCKWISE, FMT>), dim3(nb, (p.M + 63) / 64, z), block, 0, s, p);
   }
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
@@ -377,6 +391,45 @@ int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* scales_a, c
   MmArgs p{(const uint8_t*)a, (const uint8_t*)b_nk, scales_a, scales_b, bias, out, M, N, K, a_stride, b_stride,
            out_stride,        0,                    0,        0,        0};
   SGLK_DISPATCH_HALF(out_dtype, TO, return (launch_mm<TO, false>(p, (hipStream_t)stream)));
+  return SGLK_OK;
+}
+
+int sglk_bmm_fp8(const void* a, const void* b_nk, const float* scale_a, const float* scale_b, void* out, int batch, int M,
+                 int N, int K, int64_t a_batch_stride, int64_t a_stride, int64_t b_batch_stride, int64_t b_stride,
+                 int64_t out_batch_stride, int64_t out_stride, int a_e5m2, int b_e5m2, int out_dtype, void* stream) {
+  SGLK_CHECK(a && b_nk && scale_a && scale_b && out, "bmm_fp8: null pointer");
+  SGLK_CHECK(batch >= 0 && M >= 0 && N > 0 && K > 0, "bmm_fp8: bad shape batch=%d M=%d N=%d K=%d", batch, M, N, K);
+  SGLK_CHECK(!(a_e5m2 && b_e5m2), "bmm_fp8: both operands e5m2 is not a valid combination");
+  SGLK_CHECK(K % 16 == 0, "bmm_fp8: K=%d must be a multiple of 16", K);
+  SGLK_CHECK(a_stride % 16 == 0 && b_stride % 16 == 0 && a_batch_stride % 16 == 0 && b_batch_stride % 16 == 0 &&
+                 aligned16(a) && aligned16(b_nk),
+             "bmm_fp8: operand rows must be 16-byte aligned");
+  SGLK_CHECK(a_stride >= K && b_stride >= K && out_stride >= N, "bmm_fp8: stride smaller than the row");
+  SGLK_CHECK(batch <= 65535, "bmm_fp8: batch %d too large", batch);
+  if (M == 0 || batch == 0) return SGLK_OK;
+  MmArgs p{};
+  p.a = (const uint8_t*)a;
+  p.b = (const uint8_t*)b_nk;
+  p.sa = scale_a;
+  p.sb = scale_b;
+  p.bias = nullptr;
+  p.out = out;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.a_stride = a_stride;
+  p.b_stride = b_stride;
+  p.out_stride = out_stride;
+  p.a_batch = a_batch_stride;
+  p.b_batch = b_batch_stride;
+  p.out_batch = out_batch_stride;
+  p.scalar_scales = 1;
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_HALF(out_dtype, TO, {
+    if (a_e5m2) return (launch_mm<TO, false, 1>(p, s, batch));
+    if (b_e5m2) return (launch_mm<TO, false, 2>(p, s, batch));
+    return (launch_mm<TO, false, 0>(p, s, batch));
+  });
   return SGLK_OK;
 }
 

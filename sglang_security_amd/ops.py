@@ -396,6 +396,69 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
     return out
 
 
+def bmm_fp8(A, B, A_scale, B_scale, dtype, out=None):
+    """bmm_fp8 (sgl-kernel/python/sgl_kernel/gemm.py:66-82): A [b, M, K] row-major, B [b, K, N] column-major (a
+    transposed view of [b, N, K]), one fp32 scale per operand; e4m3 or e5m2 operands (not both e5m2)."""
+    _need_gpu(A, B, A_scale, B_scale)
+    if A.dim() != 3 or B.dim() != 3 or A.shape[0] != B.shape[0] or A.shape[2] != B.shape[1]:
+        raise SglkError("bmm_fp8: A must be [b, M, K] and B [b, K, N]")
+    if A.stride(2) != 1 or B.stride(1) != 1:
+        raise SglkError("bmm_fp8: A must be row-major and B column-major")
+    f8 = (torch.float8_e4m3fn, torch.float8_e5m2)
+    if A.dtype not in f8 or B.dtype not in f8:
+        raise SglkError("bmm_fp8: operands must be float8_e4m3fn / float8_e5m2")
+    b, M, K = A.shape
+    N = B.shape[2]
+    if out is None:
+        out = torch.empty((b, M, N), dtype=dtype, device=A.device)
+    if out.stride(2) != 1:
+        raise SglkError("bmm_fp8: out must be row-major")
+    check(lib().sglk_bmm_fp8(_ptr(A), _ptr(B), _ptr(A_scale), _ptr(B_scale), _ptr(out), b, M, N, K, A.stride(0),
+                             A.stride(1), B.stride(0), B.stride(2), out.stride(0), out.stride(1),
+                             1 if A.dtype == torch.float8_e5m2 else 0, 1 if B.dtype == torch.float8_e5m2 else 0,
+                             dtype_code(out.dtype), _stream(A)), "bmm_fp8")
+    return out
+
+
+def moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad,
+                         token_cnts_buffer=None, cumsum_buffer=None):
+    """moe_align_block_size (sgl-kernel/python/sgl_kernel/moe.py:4-23); token_cnts_buffer is not needed."""
+    _need_gpu(topk_ids, sorted_token_ids, experts_ids, num_tokens_post_pad)
+    if topk_ids.dtype not in (torch.int32, torch.int64) or not topk_ids.is_contiguous():
+        raise SglkError("moe_align_block_size: topk_ids must be contiguous int32 / int64")
+    for t in (sorted_token_ids, experts_ids, num_tokens_post_pad):
+        if t.dtype != torch.int32:
+            raise SglkError("moe_align_block_size: outputs must be int32")
+    if cumsum_buffer is not None and (cumsum_buffer.dtype != torch.int32 or cumsum_buffer.numel() < num_experts + 1):
+        raise SglkError("moe_align_block_size: cumsum_buffer must be int32 [num_experts + 1]")
+    numel = topk_ids.numel()
+    if sorted_token_ids.numel() < numel + num_experts * (block_size - 1):  # the bound fused_moe allocates
+        raise SglkError("moe_align_block_size: sorted_token_ids smaller than numel + num_experts * (block_size - 1)")
+    if experts_ids.numel() < (numel + num_experts * (block_size - 1) + block_size - 1) // block_size:
+        raise SglkError("moe_align_block_size: experts_ids too small for the padded layout")
+    check(lib().sglk_moe_align_block_size(_ptr(topk_ids), 1 if topk_ids.dtype == torch.int64 else 0, numel, num_experts,
+                                          block_size, _ptr(sorted_token_ids), _ptr(experts_ids),
+                                          _ptr(num_tokens_post_pad), _ptr(cumsum_buffer), _stream(topk_ids)),
+          "moe_align_block_size")
+
+
+def topk_softmax(topk_weights, topk_ids, token_expert_indices, gating_output):
+    """topk_softmax (sgl-kernel/python/sgl_kernel/moe.py:26-34)."""
+    _need_gpu(topk_weights, topk_ids, token_expert_indices, gating_output)
+    if gating_output.dim() != 2 or gating_output.stride(1) != 1:
+        raise SglkError("topk_softmax: gating_output must be [num_tokens, num_experts] with unit inner stride")
+    T, E = gating_output.shape
+    k = topk_weights.shape[-1]
+    if topk_weights.dtype != torch.float32 or topk_ids.dtype != torch.int32 or token_expert_indices.dtype != torch.int32:
+        raise SglkError("topk_softmax: topk_weights must be float32, the index outputs int32")
+    for t in (topk_weights, topk_ids, token_expert_indices):
+        if tuple(t.shape) != (T, k) or not t.is_contiguous():
+            raise SglkError(f"topk_softmax: outputs must be contiguous [{T}, {k}]")
+    check(lib().sglk_topk_softmax(_ptr(gating_output), _ptr(topk_weights), _ptr(topk_ids), _ptr(token_expert_indices), T,
+                                  E, k, gating_output.stride(0), dtype_code(gating_output.dtype),
+                                  _stream(gating_output)), "topk_softmax")
+
+
 def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
     """fp8_blockwise_scaled_mm (sgl-kernel/python/sgl_kernel/gemm.py:36-45): scales_a [M, K/128] (any strides),
     scales_b [K/128, N/128] as the reference passes it (the transpose of the [N/128, K/128] checkpoint tensor)."""

@@ -21,8 +21,8 @@ from .._lib import SglkError  # noqa: F401
 __all__ = [
     "rmsnorm", "fused_add_rmsnorm", "gemma_rmsnorm", "gemma_fused_add_rmsnorm", "silu_and_mul", "gelu_tanh_and_mul",
     "gelu_and_mul", "apply_rope_with_cos_sin_cache_inplace", "awq_dequantize", "fp8_scaled_mm",
-    "fp8_blockwise_scaled_mm", "sgl_per_token_quant_fp8", "sgl_per_token_group_quant_fp8", "sgl_per_tensor_quant_fp8",
-    "merge_state", "merge_state_v2", "install",
+    "fp8_blockwise_scaled_mm", "bmm_fp8", "sgl_per_token_quant_fp8", "sgl_per_token_group_quant_fp8",
+    "sgl_per_tensor_quant_fp8", "moe_align_block_size", "topk_softmax", "merge_state", "merge_state_v2", "install",
 ]
 
 
@@ -113,6 +113,24 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
 def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
     """gemm.py:24-31."""
     return _ops.fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype)
+
+
+def bmm_fp8(A, B, A_scale, B_scale, dtype, out=None):
+    """gemm.py:66-82."""
+    return _ops.bmm_fp8(A, B, A_scale, B_scale, dtype, out)
+
+
+# ---- moe.py -------------------------------------------------------------------------------------------------
+def moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad,
+                         token_cnts_buffer, cumsum_buffer):
+    """moe.py:4-23."""
+    _ops.moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad,
+                              token_cnts_buffer, cumsum_buffer)
+
+
+def topk_softmax(topk_weights, topk_ids, token_expert_indices, gating_output) -> None:
+    """moe.py:26-34."""
+    _ops.topk_softmax(topk_weights, topk_ids, token_expert_indices, gating_output)
 
 
 def sgl_per_token_group_quant_fp8(input: torch.Tensor, output_q: torch.Tensor, output_s: torch.Tensor, group_size: int,

@@ -15,6 +15,8 @@ _SCHEMAS = {
     "awq_dequantize": "(Tensor qweight, Tensor scales, Tensor qzeros) -> Tensor",
     "fp8_scaled_mm": "(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype, Tensor? bias) -> Tensor",
     "fp8_blockwise_scaled_mm": "(Tensor mat_a, Tensor mat_b, Tensor scales_a, Tensor scales_b, ScalarType out_dtype) -> Tensor",
+    "moe_align_block_size": "(Tensor topk_ids, int num_experts, int block_size, Tensor! sorted_token_ids, Tensor! experts_ids, Tensor! num_tokens_post_pad, Tensor! token_cnts_buffer, Tensor! cumsum_buffer) -> ()",
+    "topk_softmax": "(Tensor! topk_weights, Tensor! topk_indices, Tensor! token_expert_indices, Tensor gating_output) -> ()",
     "sgl_per_token_quant_fp8": "(Tensor input, Tensor output_q, Tensor output_s) -> ()",
     "sgl_per_token_group_quant_fp8": "(Tensor input, Tensor output_q, Tensor output_s, int group_size, float eps, float fp8_min, float fp8_max) -> ()",
     "sgl_per_tensor_quant_fp8": "(Tensor input, Tensor output_q, Tensor output_s, bool is_static) -> ()",
@@ -51,6 +53,8 @@ _IMPLS = {
     "awq_dequantize": lambda qweight, scales, qzeros: _ops.awq_dequantize(qweight, scales, qzeros),
     "fp8_scaled_mm": lambda a, b, sa, sb, dt, bias: _ops.fp8_scaled_mm(a, b, sa, sb, dt, bias),
     "fp8_blockwise_scaled_mm": lambda a, b, sa, sb, dt: _ops.fp8_blockwise_scaled_mm(a, b, sa, sb, dt),
+    "moe_align_block_size": lambda ids, ne, bs, srt, ex, npp, cnt, cs: _ops.moe_align_block_size(ids, ne, bs, srt, ex, npp, cnt, cs),
+    "topk_softmax": lambda w, ids, src, g: _ops.topk_softmax(w, ids, src, g),
     "sgl_per_token_quant_fp8": lambda x, q, s: _ops.per_token_quant_fp8(x, q, s),
     "sgl_per_token_group_quant_fp8": lambda x, q, s, g, eps, lo, hi: _ops.per_token_group_quant_fp8(x, q, s, g, eps, lo, hi),
     "sgl_per_tensor_quant_fp8": lambda x, q, s, st: _ops.per_tensor_quant_fp8(x, q, s, st),

@@ -126,3 +126,37 @@ def test_per_token_quant_fp8():
     q, s = oracle.per_token_quant_fp8(g["x"])
     torch.testing.assert_close(s.reshape(-1), g["expect_scale"], rtol=1e-6, atol=0)
     torch.testing.assert_close(q.float(), g["expect_q"].float(), rtol=1e-3, atol=1e-3)
+
+
+def test_topk_softmax_oracle_vs_torch():
+    """The reference's own criterion for topk_softmax (sgl-kernel/tests/test_moe_topk_softmax.py:37-48)."""
+    import oracle
+
+    g = torch.Generator().manual_seed(3)
+    for T, E, k in [(1, 4, 1), (16, 64, 4), (128, 256, 8), (33, 384, 2)]:
+        gating = torch.randn(T, E, generator=g)
+        w, ids, src = oracle.topk_softmax(gating, k)
+        rw, ri = torch.topk(torch.softmax(gating, dim=-1), k, dim=-1)
+        assert torch.equal(ids, ri.int())
+        torch.testing.assert_close(w, rw, rtol=1e-5, atol=1e-7)
+        assert torch.equal(src, (torch.arange(k)[None, :] * T + torch.arange(T)[:, None]).int())
+
+
+def test_moe_align_oracle_properties():
+    """moe_align_kernel.cu:43-100: padded prefix sums, one expert per block, every slot placed once."""
+    import oracle
+
+    g = torch.Generator().manual_seed(5)
+    for T, k, E, bs in [(1, 2, 8, 16), (50, 8, 256, 64), (300, 4, 60, 16)]:
+        ids = torch.stack([torch.randperm(E, generator=g)[:k] for _ in range(T)])
+        srt, ex, tot = oracle.moe_align_block_size(ids, E, bs)
+        counts = torch.bincount(ids.flatten(), minlength=E)
+        assert tot == int(((counts + bs - 1) // bs * bs).sum())
+        flat = ids.flatten()
+        real = srt[:tot][srt[:tot] < flat.numel()]
+        assert torch.equal(torch.sort(real).values, torch.arange(flat.numel(), dtype=torch.int32))
+        for blk in range(tot // bs):
+            seg = srt[blk * bs:(blk + 1) * bs]
+            seg = seg[seg < flat.numel()]
+            assert (flat[seg.long()] == int(ex[blk])).all()
+            assert torch.equal(seg, torch.sort(seg).values)
