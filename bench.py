@@ -265,12 +265,15 @@ def main():
     agg = aggregate(B, args.steps, world, elapsed)
     roof = gemm_roofline(dec, cfg, B, stream) if cfg.quant == "awq" else None
 
+    wname = "AWQ int4" if cfg.quant == "awq" else "bf16"
+    wdesc = ("awq (int4 weights, G=128; bf16 activations and KV)" if cfg.quant == "awq"
+             else "bf16 (bf16 weights, activations and KV)")
     out = {
-        "metric": "decode tokens/s (whole job), Llama-3-8B AWQ int4, batch 64/GPU, 1024-token shared prefix",
+        "metric": f"decode tokens/s (whole job), Llama-3-8B {wname}, batch {B}/GPU, {args.prefix}-token shared prefix",
         "value": round(agg["value"], 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(agg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Llama-3-8B {cfg.quant} (int4 weights, G=128; bf16 activations and KV) decode, batch {B}/GPU, "
+        "config": {"workload": f"Llama-3-8B {wdesc} decode, batch {B}/GPU, "
                                f"prefix {args.prefix} shared + {args.suffix} private tokens, seq_len "
                                f"{args.prefix + args.suffix}+step, greedy, random-init weights",
                    "attention": attn_mode, "layer_fusion": bool(fused), "graph": graphed, "parallelism": f"replicas x{world}", "layers": cfg.layers},

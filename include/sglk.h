@@ -296,6 +296,14 @@ SGLK_API int sglk_decode_attention_shared_prefix_xs(
 SGLK_API int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N,
                                 int K, int64_t x_stride, int64_t w_stride, int64_t out_stride,
                                 int dtype, void* stream);
+/* The same product with a scratch buffer (sglk_dense_gemm_workspace_bytes(), contents don't matter): narrow
+ * outputs (the decoder-layer projections of the bf16 configuration) are split along K over enough blocks to fill
+ * the chip, fp32 partials summed in split order by a second launch.  Falls back to the form above when the
+ * workspace is missing or too small. */
+SGLK_API int64_t sglk_dense_gemm_workspace_bytes(int M, int N, int K);
+SGLK_API int sglk_dense_gemm_nt_ws(const void* x, const void* w, const void* bias, void* out, int M, int N,
+                                   int K, int64_t x_stride, int64_t w_stride, int64_t out_stride,
+                                   void* workspace, int64_t workspace_bytes, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ G2/G3: fp8 ---------------- */
 

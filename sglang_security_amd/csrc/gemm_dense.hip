@@ -4,6 +4,9 @@
 // cover 64 contiguous bytes, so one instruction touches one cache line per row; no LDS round trip
 // for the operand that is read once), while the activations, which every wave
 // re-reads, are staged through an XOR-swizzled LDS tile shared by the block.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sglk {
@@ -140,6 +143,54 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
   }
 }
 
+// out[m][n] = sum over splits (in split order) of partial[s][m][n] (+ bias), eight outputs per thread
+template <typename T>
+__global__ void __launch_bounds__(256) dense_reduce_kernel(const float* __restrict__ partial, const uint16_t* __restrict__ bias,
+                                                           uint16_t* __restrict__ out, int M, int Mpad, int N, int splits,
+                                                           int64_t out_stride) {
+  const int nv = N / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * nv) return;
+  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int s0 = 0; s0 < splits; s0 += 4) {  // four splits' loads in flight
+    float4v a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* pr = partial + ((int64_t)min(s0 + u, splits - 1) * Mpad + m) * N + n;
+      a[u] = *reinterpret_cast<const float4v*>(pr);
+      b[u] = *reinterpret_cast<const float4v*>(pr + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < splits) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] += a[u][j];
+          acc[4 + j] += b[u][j];
+        }
+      }
+  }
+  short8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (short)Conv<T>::from_f32(acc[j] + (bias ? Conv<T>::to_f32(bias[n + j]) : 0.f));
+  *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + n) = o;
+}
+
+// K-splits of the two-launch form: enough blocks to cover the chip about twice, at least 512 of k per block
+static int dense_splits(int M, int N, int K) {
+  const char* env = getenv("SGLK_DENSE_SPLITS");
+  const int kblocks = K / 128;
+  if (env && atoi(env) > 0) return std::min(atoi(env), kblocks);
+  if (N % 8 != 0) return 1;
+  const int blocks = (N + 63) / 64 * ((M + 63) / 64);
+  if (blocks >= 768) return 1;
+  int splits = std::min((1024 + blocks - 1) / blocks, std::max(kblocks / 4, 1));
+  return std::max(std::min(splits, 16), 1);
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -149,6 +200,43 @@ extern "C" {
 // Dense split-K needs scratch; this entry point keeps the weights' whole K in one block when N gives
 // enough blocks (lm_head: 1002 blocks of 128 rows) and otherwise runs unsplit as well: the strips are
 // 16 rows of W, so even N = 4096 yields 64 blocks x 4 waves.  (The AWQ path owns the split-K machinery.)
+int64_t sglk_dense_gemm_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0) return 0;
+  const int splits = dense_splits(M, N, K);
+  return splits > 1 ? (int64_t)splits * ((M + 63) / 64 * 64) * N * (int64_t)sizeof(float) : 0;
+}
+
+int sglk_dense_gemm_nt_ws(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
+                          int64_t x_stride, int64_t w_stride, int64_t out_stride, void* workspace,
+                          int64_t workspace_bytes, int dtype, void* stream) {
+  SGLK_CHECK(x && w && out, "dense_gemm_nt: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0, "dense_gemm_nt: bad shape");
+  SGLK_CHECK(K % 128 == 0, "dense_gemm_nt: K=%d must be a multiple of 128", K);
+  const int splits = dense_splits(M, N, K);
+  const int64_t need = sglk_dense_gemm_workspace_bytes(M, N, K);
+  if (splits <= 1 || !workspace || workspace_bytes < need || !aligned16(workspace) || !aligned16(out) ||
+      out_stride % 8 != 0)
+    return sglk_dense_gemm_nt(x, w, bias, out, M, N, K, x_stride, w_stride, out_stride, dtype, stream);
+  SGLK_CHECK(aligned16(x) && aligned16(w) && x_stride % 8 == 0 && w_stride % 8 == 0,
+             "dense_gemm_nt: rows must be 16-byte aligned");
+  const int mblocks = (M + 63) / 64, kblocks = K / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;  // every split non-empty
+  dim3 grid((N + 63) / 64, used, mblocks);
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_HALF(dtype, T, {
+    hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 1, 4>), grid, dim3(256), 0, s, (const uint16_t*)x, (const uint16_t*)w,
+                       (const uint16_t*)nullptr, (uint16_t*)nullptr, (float*)workspace, M, mblocks * 64, N, K, per,
+                       x_stride, w_stride, out_stride);
+    const int64_t vecs = (int64_t)M * (N / 8);
+    hipLaunchKernelGGL((dense_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
+                       (const float*)workspace, (const uint16_t*)bias, (uint16_t*)out, M, mblocks * 64, N, used,
+                       out_stride);
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
 int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
                        int64_t x_stride, int64_t w_stride, int64_t out_stride, int dtype, void* stream) {
   SGLK_CHECK(x && w && out, "dense_gemm_nt: null pointer");

@@ -129,6 +129,10 @@ class LlamaDecoder:
             for K, N in ((c.hidden, self.q_size + 2 * self.kv_size), (self.q_size, c.hidden), (c.hidden, 2 * c.inter),
                          (c.inter, c.hidden)):
                 ws = max(ws, ops.awq_gemm_workspace_bytes(B, N, K))
+        else:
+            for K, N in ((c.hidden, self.q_size + 2 * self.kv_size), (self.q_size, c.hidden), (c.hidden, 2 * c.inter),
+                         (c.inter, c.hidden)):
+                ws = max(ws, ops.dense_gemm_workspace_bytes(B, N, K))
         self.workspace = torch.zeros(max(ws, 256), dtype=torch.uint8, device=device)  # ticket words start at zero
         # layer fusion: block sums of every GEMM input come from its producer, split-K partials go to the consumer
         self.fused = False
@@ -183,7 +187,7 @@ class LlamaDecoder:
             if isinstance(w, _AwqLinear):
                 ops.awq_gemm(x, w.packed, w.scales, w.qzeros, None, out, self.workspace)
             else:
-                ops.dense_gemm_nt(x, w.weight, None, out)
+                ops.dense_gemm_nt(x, w.weight, None, out, self.workspace)
 
         if self.gemm_timer is not None:
             self.gemm_timer(name, run)

@@ -310,13 +310,23 @@ def awq_gemm(x, packed, scales, qzeros, bias=None, out=None, workspace=None):
     return out
 
 
-def dense_gemm_nt(x, w, bias=None, out=None):
-    """x:[M,K] @ w:[N,K]^T."""
+def dense_gemm_workspace_bytes(M, N, K) -> int:
+    return int(lib().sglk_dense_gemm_workspace_bytes(M, N, K))
+
+
+def dense_gemm_nt(x, w, bias=None, out=None, workspace=None):
+    """x:[M,K] @ w:[N,K]^T.  With a workspace (dense_gemm_workspace_bytes) narrow outputs are split along K."""
     _need_gpu(x, w)
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    if workspace is not None:
+        _need_gpu(workspace)
+        check(lib().sglk_dense_gemm_nt_ws(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x.stride(0), w.stride(0),
+                                          out.stride(0), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                          dtype_code(x.dtype), _stream(x)), "dense_gemm_nt")
+        return out
     check(lib().sglk_dense_gemm_nt(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x.stride(0), w.stride(0),
                                    out.stride(0), dtype_code(x.dtype), _stream(x)), "dense_gemm_nt")
     return out

@@ -139,6 +139,30 @@ def test_dense_gemm_nt(M, K, N, dtype, strips, monkeypatch):
     assert (out - want).abs().max().item() <= 1e-2 * scale
 
 
+@pytest.mark.parametrize("M,K,N,bias", [(64, 4096, 4096, False), (64, 14336, 4096, True), (7, 4096, 6144, False),
+                                        (130, 1024, 512, True), (64, 512, 28672, False)])
+def test_dense_gemm_nt_split_k(M, K, N, bias):
+    """Two-launch split-K form (workspace given) against the single-launch kernel and the oracle."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16) if bias else None
+    ws = torch.empty(max(ops.dense_gemm_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=DEV)
+    bd = b.to(DEV) if bias else None
+    got = ops.dense_gemm_nt(x.to(DEV), w.to(DEV), bd, None, ws).float().cpu()
+    one = ops.dense_gemm_nt(x.to(DEV), w.to(DEV), bd).float().cpu()
+    scale = one.abs().max().item()
+    assert (got - one).abs().max().item() <= 8e-3 * scale          # another summation order, one bf16 rounding
+    rows = torch.arange(0, M, max(M // 8, 1))
+    want = oracle.half_matmul(x[rows], w.t().contiguous()).float()
+    if bias:
+        want = (want + b.float()).to(torch.bfloat16).float()
+    assert (got[rows] - want).abs().max().item() <= 1e-2 * scale
+
+
 # ---------------------------------------------------------------------------------------------- norm / act / rope
 @pytest.mark.parametrize("name", ["norm_f16", "norm_bf16", "norm_odd"])
 def test_rmsnorm_golden(golden, name):
