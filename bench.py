@@ -35,7 +35,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--prefix", type=int, default=1024)
     ap.add_argument("--suffix", type=int, default=128)
-    ap.add_argument("--quant", default="awq", choices=["awq", "bf16"])
+    ap.add_argument("--quant", default="awq", choices=["awq", "bf16", "fp8"])
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8-rank"],
+                    help="llama3-70b-tp8-rank: one rank's shard of Llama-3-70B under TP=8 (no all-reduce on one GPU)")
     ap.add_argument("--attn", default="auto", choices=["auto", "per_request", "shared_prefix"])
     ap.add_argument("--tiny", action="store_true", help="2-layer toy model (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -249,7 +251,12 @@ def main():
     from sglang_security_amd.benchlib import aggregate
     from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
 
-    cfg = LlamaConfig.tiny(args.quant) if args.tiny else LlamaConfig.llama3_8b(args.quant)
+    if args.tiny:
+        cfg = LlamaConfig.tiny(args.quant)
+    elif args.model == "llama3-70b-tp8-rank":
+        cfg = LlamaConfig.llama3_70b_tp8_rank(args.quant)
+    else:
+        cfg = LlamaConfig.llama3_8b(args.quant)
     B = args.batch
     total_steps = args.steps + args.warmup + 8
     per_req = args.suffix + total_steps + 2
@@ -265,15 +272,17 @@ def main():
     agg = aggregate(B, args.steps, world, elapsed)
     roof = gemm_roofline(dec, cfg, B, stream) if cfg.quant == "awq" else None
 
-    wname = "AWQ int4" if cfg.quant == "awq" else "bf16"
-    wdesc = ("awq (int4 weights, G=128; bf16 activations and KV)" if cfg.quant == "awq"
-             else "bf16 (bf16 weights, activations and KV)")
+    wname = {"awq": "AWQ int4", "bf16": "bf16", "fp8": "fp8 w8a8"}[cfg.quant]
+    wdesc = {"awq": "awq (int4 weights, G=128; bf16 activations and KV)",
+             "bf16": "bf16 (bf16 weights, activations and KV)",
+             "fp8": "fp8 (e4m3 weights with per-channel scales, per-token e4m3 activations; bf16 KV)"}[cfg.quant]
+    mname = "Llama-3-8B" if args.model == "llama3-8b" else "Llama-3-70B TP=8 rank shard (no all-reduce)"
     out = {
-        "metric": f"decode tokens/s (whole job), Llama-3-8B {wname}, batch {B}/GPU, {args.prefix}-token shared prefix",
+        "metric": f"decode tokens/s (whole job), {mname} {wname}, batch {B}/GPU, {args.prefix}-token shared prefix",
         "value": round(agg["value"], 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(agg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Llama-3-8B {wdesc} decode, batch {B}/GPU, "
+        "config": {"workload": f"{mname} {wdesc} decode, batch {B}/GPU, "
                                f"prefix {args.prefix} shared + {args.suffix} private tokens, seq_len "
                                f"{args.prefix + args.suffix}+step, greedy, random-init weights",
                    "attention": attn_mode, "layer_fusion": bool(fused), "graph": graphed, "parallelism": f"replicas x{world}", "layers": cfg.layers},

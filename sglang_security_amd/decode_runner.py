@@ -32,11 +32,18 @@ class LlamaConfig:
     max_pos: int = 8192
     eps: float = 1e-5
     group_size: int = 128
-    quant: str = "awq"  # "awq" (int4) or "bf16"
+    quant: str = "awq"  # "awq" (int4), "bf16" or "fp8" (w8a8: per-channel weight scales, per-token activation scales)
 
     @staticmethod
     def llama3_8b(quant="awq"):
         return LlamaConfig(quant=quant)
+
+    @staticmethod
+    def llama3_70b_tp8_rank(quant="fp8"):
+        """One rank's shard of Llama-3-70B under TP=8 (llama.py:72-86,145-160: q/k/v and gate/up column-sharded,
+        o/down row-sharded, vocab-parallel lm_head): 8 of 64 query heads, 1 of 8 kv heads, 28672/8 MLP columns."""
+        return LlamaConfig(hidden=8192, layers=80, q_heads=8, kv_heads=1, head_dim=128, inter=3584, vocab=128256 // 8,
+                           quant=quant)
 
     @staticmethod
     def tiny(quant="awq"):
@@ -62,6 +69,21 @@ class _AwqLinear:
         return self.packed.numel() * 4 + self.qzeros.numel() * 4 + self.scales.numel() * 2
 
 
+class _Fp8Linear:
+    """w8a8 fp8 linear (layers/quantization/fp8.py / w8a8_fp8.py): e4m3 weight [N, K] with one scale per output
+    channel; activations are quantised per token right before the product."""
+
+    def __init__(self, K, N, dtype, device, gen):
+        self.K, self.N = K, N
+        w = torch.randn(N, K, device=device, generator=gen) / math.sqrt(K)
+        amax = w.abs().amax(dim=1, keepdim=True).clamp(min=1e-12)
+        self.scale = (amax / 448.0).float().reshape(N).contiguous()
+        self.weight = (w / (amax / 448.0)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+
+    def bytes(self):
+        return self.weight.numel() + self.scale.numel() * 4
+
+
 class _DenseLinear:
     def __init__(self, K, N, dtype, device, gen):
         self.K, self.N = K, N
@@ -83,6 +105,8 @@ class LlamaDecoder:
         def lin(K, N, keep=False):
             if c.quant == "awq":
                 return _AwqLinear(K, N, c.group_size, dtype, device, gen, keep_reference_layout or keep)
+            if c.quant == "fp8":
+                return _Fp8Linear(K, N, dtype, device, gen)
             return _DenseLinear(K, N, dtype, device, gen)
 
         self.embed = (torch.randn(c.vocab, c.hidden, device=device, generator=gen) * 0.5).to(dtype)
@@ -134,6 +158,10 @@ class LlamaDecoder:
                          (c.inter, c.hidden)):
                 ws = max(ws, ops.dense_gemm_workspace_bytes(B, N, K))
         self.workspace = torch.zeros(max(ws, 256), dtype=torch.uint8, device=device)  # ticket words start at zero
+        if c.quant == "fp8":
+            kmax = max(c.hidden, self.q_size, c.inter)
+            self.x_q = torch.empty(B, kmax, dtype=torch.float8_e4m3fn, device=device)
+            self.x_s = torch.empty(B, dtype=torch.float32, device=device)
         # layer fusion: block sums of every GEMM input come from its producer, split-K partials go to the consumer
         self.fused = False
         self.xs_hidden = torch.zeros(c.hidden // 128, B, dtype=torch.float32, device=device)
@@ -186,6 +214,10 @@ class LlamaDecoder:
         def run():
             if isinstance(w, _AwqLinear):
                 ops.awq_gemm(x, w.packed, w.scales, w.qzeros, None, out, self.workspace)
+            elif isinstance(w, _Fp8Linear):
+                xq = self.x_q.view(-1)[:x.shape[0] * w.K].view(x.shape[0], w.K)
+                ops.per_token_quant_fp8(x, xq, self.x_s)
+                ops.fp8_scaled_mm(xq, w.weight.t(), self.x_s, w.scale, self.dtype, None, out)
             else:
                 ops.dense_gemm_nt(x, w.weight, None, out, self.workspace)
 

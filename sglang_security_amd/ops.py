@@ -385,8 +385,9 @@ def _b_as_nk(mat_b, name):
     return mat_b.t()
 
 
-def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
-    """fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias) (sgl-kernel/python/sgl_kernel/gemm.py:48-57)."""
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, out=None):
+    """fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias) (sgl-kernel/python/sgl_kernel/gemm.py:48-57);
+    `out` (row-major [M, N] of out_dtype) is an addition for callers that own their buffers."""
     _need_gpu(mat_a, mat_b, scales_a, scales_b)
     if mat_a.dim() != 2 or mat_a.stride(1) != 1:
         raise SglkError("fp8_scaled_mm: mat_a must be a row-major 2-D tensor")
@@ -399,7 +400,10 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None):
         raise SglkError("fp8_scaled_mm: scales_a must have M and scales_b N elements")
     if bias is not None and (bias.numel() != N or bias.dtype != out_dtype):
         raise SglkError("fp8_scaled_mm: bias must have N elements of the output dtype")
-    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or out.stride(1) != 1:
+        raise SglkError(f"fp8_scaled_mm: out must be a row-major [{M}, {N}] tensor of the output dtype")
     check(lib().sglk_fp8_scaled_mm(_ptr(mat_a), _ptr(b), _ptr(scales_a.contiguous()), _ptr(scales_b.contiguous()),
                                    _ptr(bias), _ptr(out), M, N, K, mat_a.stride(0), b.stride(0), out.stride(0),
                                    dtype_code(out_dtype), _stream(mat_a)), "fp8_scaled_mm")

@@ -160,6 +160,38 @@ def test_fused_decode_step_matches_unfused():
     assert (k0 - k1).abs().max().item() < 0.05 * max(1.0, k0.abs().max().item())
 
 
+@pytest.mark.parametrize("quant", ["fp8", "bf16"])
+def test_decode_step_other_weight_formats(quant):
+    """The decode step on fp8 (w8a8: per-token activation quantisation + fp8_scaled_mm) and bf16 (dense, split-K
+    through the workspace) weights: every linear against the oracle on the step's own inputs."""
+    import oracle
+    from sglang_security_amd import ops
+    from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
+
+    cfg = LlamaConfig.tiny(quant)
+    dec = LlamaDecoder(cfg, batch=6, pool_slots=1 + 64 + 6 * 24, max_ctx=96, device=DEV, seed=0)
+    dec.setup_shared_prefix_batch(prefix_len=64, suffix_len=5)
+    dec.enable_shared_prefix(True)
+    assert not dec.enable_fusion(True)            # the layer fusion is the AWQ path's
+    for _ in range(2):
+        dec.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(dec.logits.float()).all()
+    x = torch.randn(6, cfg.hidden, device=DEV).to(torch.bfloat16)
+    w = dec.layers[1]["gate_up"]
+    out = torch.empty(6, 2 * cfg.inter, dtype=torch.bfloat16, device=DEV)
+    dec._linear("gate_up", w, x, out)
+    if quant == "fp8":
+        xq = torch.empty(6, cfg.hidden, dtype=torch.float8_e4m3fn, device=DEV)
+        xs = torch.empty(6, dtype=torch.float32, device=DEV)
+        ops.per_token_quant_fp8(x, xq, xs)
+        want = oracle.fp8_scaled_mm(xq.cpu(), w.weight.cpu().t(), xs.cpu(), w.scale.cpu(), torch.bfloat16).float()
+    else:
+        want = oracle.half_matmul(x.cpu(), w.weight.cpu().t().contiguous()).float()
+    got = out.float().cpu()
+    assert (got - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,K,inter", [(64, 1024, 512), (17, 512, 128), (64, 4096, 14336)])
 def test_gate_up_with_activation_epilogue(dtype, M, K, inter):

@@ -23,7 +23,7 @@ dev = "cuda"
 M = args.m
 shapes = [("qkv", 4096, 6144), ("o", 4096, 4096), ("gate_up", 4096, 28672), ("down", 14336, 4096)]
 if args.dense:
-    shapes = [("lm_head", 4096, 128256)]
+    shapes = shapes + [("lm_head", 4096, 128256)]
 gen = torch.Generator(device=dev).manual_seed(0)
 for name, K, N in shapes:
     wbytes = K * N // 2 + (K // 128) * N * 2 + (K // 128) * N // 2 if not args.dense else K * N * 2
@@ -40,12 +40,13 @@ for name, K, N in shapes:
             sc = (torch.rand(K // 128, N, device=dev, generator=gen) * 0.01).to(torch.bfloat16)
             ws.append((ops.awq_repack(qw), sc, qz))
             del qw
-    work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), 256), dtype=torch.uint8, device=dev)
+    work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), ops.dense_gemm_workspace_bytes(M, N, K) if args.dense else 0,
+                           256), dtype=torch.uint8, device=dev)
 
     def run(i):
         w = ws[i % copies]
         if args.dense:
-            ops.dense_gemm_nt(x, w[0], None, out)
+            ops.dense_gemm_nt(x, w[0], None, out, work)
         else:
             ops.awq_gemm(x, w[0], w[1], w[2], None, out, work)
 
