@@ -495,7 +495,9 @@ struct Wide {
 // XS_EXT: the block sums X[group][row] come from the kernel that produced x (xsum_in, row stride xs_stride) instead
 // of being computed here: one barrier per stage instead of two.  partial_mode: every split stores its fp32 tile
 // row-major to partial[split][M][N] and returns; the consumer kernel adds the splits up.
-template <typename T, bool XS_EXT>
+// MQ: 16-row tiles of the 64-row block that are multiplied (batches of up to 16 / 32 rows skip the matrix work of
+// the rows they do not have; staging, reduction and stores keep the 64-row shape, the skipped tiles are zeros).
+template <typename T, bool XS_EXT, int MQ = 4>
 __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     const uint16_t* __restrict__ x, const int32_t* __restrict__ packed, const uint16_t* __restrict__ scales,
     const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
@@ -713,14 +715,14 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
             const float ratio = s_cur[t] * __builtin_amdgcn_rcpf(sg[t]);
             s_cur[t] = sg[t];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) R[t][q] *= ratio;
+            for (int q = 0; q < MQ; ++q) R[t][q] *= ratio;
           }
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          int4v af[4];
+          int4v af[MQ];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) af[q] = *reinterpret_cast<const int4v*>(xt + q * 4096 + aoff[ks]);
+          for (int q = 0; q < MQ; ++q) af[q] = *reinterpret_cast<const int4v*>(xt + q * 4096 + aoff[ks]);
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
             const uint32_t w = (uint32_t)wreg[u][t][ks];
@@ -728,7 +730,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) bf[e] = (int)(((w >> (4 * e)) & msk[t]) | orc[t]);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
+            for (int q = 0; q < MQ; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
           }
           if (spread) {
             if (ks < 2) {
@@ -743,7 +745,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
         {
           const float* xp = xsumS + (XS_EXT ? (buf * 8 + wid) : (buf * 4 + kw)) * 64;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+          for (int q = 0; q < MQ; ++q) {
             const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 16 * q + 4 * g);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -1072,22 +1074,29 @@ static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* pac
                            int64_t xs_out_stride = 0) {
   static const int env_abl = getenv("SGLK_AWQ_ABL") ? atoi(getenv("SGLK_AWQ_ABL")) : 0;  // timing experiments only
   dim3 wgrid(N / 128, wp.splits, wp.mblocks);
-#define SGLK_WIDE_LAUNCH(XS)                                                                                       \
+#define SGLK_WIDE_LAUNCH(XS, MQ)                                                                                   \
   {                                                                                                                \
     static bool attr_set = false;                                                                                  \
     if (!attr_set) {                                                                                               \
-      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_wide_kernel<T, XS>),                    \
+      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_wide_kernel<T, XS, MQ>),                \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));                       \
       attr_set = true;                                                                                             \
     }                                                                                                              \
-    hipLaunchKernelGGL((awq_gemm_wide_kernel<T, XS>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x, packed, \
-                       (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial, tickets, M, N, \
-                       K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl, xsum, xs_stride,          \
-                       partial_mode, act_mode, xsum_out, xs_out_stride);                                           \
+    hipLaunchKernelGGL((awq_gemm_wide_kernel<T, XS, MQ>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x,     \
+                       packed, (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial,    \
+                       tickets, M, N, K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl, xsum,      \
+                       xs_stride, partial_mode, act_mode, xsum_out, xs_out_stride);                                \
+  }
+#define SGLK_WIDE_LAUNCH_MQ(XS)            \
+  {                                        \
+    if (M <= 16) SGLK_WIDE_LAUNCH(XS, 1)   \
+    else if (M <= 32) SGLK_WIDE_LAUNCH(XS, 2) \
+    else SGLK_WIDE_LAUNCH(XS, 4)           \
   }
   SGLK_DISPATCH_HALF(dtype, T, {
-    if (xsum) SGLK_WIDE_LAUNCH(true) else SGLK_WIDE_LAUNCH(false)
+    if (xsum) SGLK_WIDE_LAUNCH_MQ(true) else SGLK_WIDE_LAUNCH_MQ(false)
   });
+#undef SGLK_WIDE_LAUNCH_MQ
 #undef SGLK_WIDE_LAUNCH
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
