@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--quant", default="awq", choices=["awq", "bf16", "fp8"])
     ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8-rank"],
                     help="llama3-70b-tp8-rank: one rank's shard of Llama-3-70B under TP=8 (no all-reduce on one GPU)")
+    ap.add_argument("--tp", action="store_true",
+                    help="the ranks form ONE tensor-parallel group (use with --model llama3-70b-tp8-rank --gpus 8): "
+                         "peer-to-peer all-reduce after o / down, value = tokens/s of the one sharded model")
     ap.add_argument("--attn", default="auto", choices=["auto", "per_request", "shared_prefix"])
     ap.add_argument("--tiny", action="store_true", help="2-layer toy model (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -266,26 +269,36 @@ def main():
     max_ctx = args.prefix + per_req
     dec = LlamaDecoder(cfg, B, slots, max_ctx, device=dev, max_kv_splits=args.kv_splits)
     dec.cu_count = torch.cuda.get_device_properties(dev).multi_processor_count
-    fused = (not args.no_fusion) and dec.enable_fusion(True)
+    tp = args.tp and world > 1
+    fused = (not args.no_fusion) and not tp and dec.enable_fusion(True)
+    if tp:
+        import torch.distributed as dist
+        from sglang_security_amd.distributed.custom_all_reduce import CustomAllreduce
+
+        comm = CustomAllreduce(dist.new_group(backend="gloo"), dev)  # handles travel over a CPU group
+        if comm.disabled:
+            raise SystemExit(f"--tp: the peer-to-peer all-reduce does not support {world} ranks")
+        dec.enable_tp(comm)
 
     elapsed, graphed, attn_mode, stream = measure_decode(dec, args, dev, world, True, args.attn)
-    agg = aggregate(B, args.steps, world, elapsed)
+    agg = aggregate(B, args.steps, 1 if tp else world, elapsed)
     roof = gemm_roofline(dec, cfg, B, stream) if cfg.quant == "awq" else None
 
     wname = {"awq": "AWQ int4", "bf16": "bf16", "fp8": "fp8 w8a8"}[cfg.quant]
     wdesc = {"awq": "awq (int4 weights, G=128; bf16 activations and KV)",
              "bf16": "bf16 (bf16 weights, activations and KV)",
              "fp8": "fp8 (e4m3 weights with per-channel scales, per-token e4m3 activations; bf16 KV)"}[cfg.quant]
-    mname = "Llama-3-8B" if args.model == "llama3-8b" else "Llama-3-70B TP=8 rank shard (no all-reduce)"
+    mname = ("Llama-3-8B" if args.model == "llama3-8b"
+             else f"Llama-3-70B TP={world}" if tp else "Llama-3-70B TP=8 rank shard (no all-reduce)")
     out = {
         "metric": f"decode tokens/s (whole job), {mname} {wname}, batch {B}/GPU, {args.prefix}-token shared prefix",
         "value": round(agg["value"], 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(agg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(agg["ms_per_step"], 4), "higher_is_better": True, "scaling": "strong" if tp else "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{mname} {wdesc} decode, batch {B}/GPU, "
                                f"prefix {args.prefix} shared + {args.suffix} private tokens, seq_len "
                                f"{args.prefix + args.suffix}+step, greedy, random-init weights",
-                   "attention": attn_mode, "layer_fusion": bool(fused), "graph": graphed, "parallelism": f"replicas x{world}", "layers": cfg.layers},
+                   "attention": attn_mode, "layer_fusion": bool(fused), "graph": graphed, "parallelism": f"tp{world}" if tp else f"replicas x{world}", "layers": cfg.layers},
     }
     # fraction of the HBM roofline for the whole step (unique bytes: weights + lm_head + KV with the prefix once)
     if not args.tiny:

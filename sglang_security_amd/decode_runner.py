@@ -351,14 +351,55 @@ class LlamaDecoder:
             ops.rope_and_store_kv(self.qkv, self.cos_sin, self.positions, self.k_pool[li], self.v_pool[li],
                                   self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
             self.attention(li, q_view, o_view, sm_scale)
-            self._linear("o", L["o"], self.attn_out, self.hidden)
+            self._row_parallel("o", L["o"], self.attn_out)
             ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln2"], c.eps)
             self._linear("gate_up", L["gate_up"], self.hidden, self.gate_up)
             ops.act_and_mul(self.act, self.gate_up, 0)
-            self._linear("down", L["down"], self.act, self.hidden)
+            self._row_parallel("down", L["down"], self.act)
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)
         ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
-        torch.argmax(self.logits, dim=-1, out=self.next_ids)
+        self._sample()
+
+    def enable_tp(self, comm) -> None:
+        """Tensor parallelism over the ranks of `comm` (a distributed.CustomAllreduce): this decoder holds one rank's
+        shard (llama.py:72-86,145-160), the row-parallel projections (o, down) write their partial sums into a
+        registered buffer and the peer-to-peer all-reduce leaves the sum in `hidden`; the vocab-parallel lm_head
+        (vocab_parallel_embedding.py) is followed by an exchange of every rank's best (logit, token) pair.  Plain op
+        sequence only (the layer fusion hands split-K partials to the next kernel, not to a collective)."""
+        assert not self.fused, "tensor parallelism runs the plain op sequence"
+        self.tp_comm = comm
+        self.tp_rank, self.tp_world = comm.rank, comm.world_size
+        self.tp_buf = torch.empty_like(self.hidden)
+        comm.register_buffer(self.tp_buf)
+        # [B, world, 2] fp32: slot r holds rank r's best logit and its global token id; the other slots are zero
+        self.tp_best = torch.zeros(self.B, self.tp_world, 2, dtype=torch.float32, device=self.device)
+        comm.register_buffer(self.tp_best)
+        self.tp_best_all = torch.empty_like(self.tp_best)
+
+    def _row_parallel(self, name, w, x):
+        """o / down: the local product, then the sum over the TP ranks (linear.py RowParallelLinear)."""
+        comm = getattr(self, "tp_comm", None)
+        if comm is None:
+            self._linear(name, w, x, self.hidden)
+            return
+        self._linear(name, w, x, self.tp_buf)
+        comm.all_reduce_reg(self.tp_buf, self.hidden)
+
+    def _sample(self):
+        """Greedy token over the (vocab-parallel) logits."""
+        comm = getattr(self, "tp_comm", None)
+        if comm is None:
+            torch.argmax(self.logits, dim=-1, out=self.next_ids)
+        else:
+            val, idx = torch.max(self.logits.float(), dim=-1)
+            self.tp_best[:, self.tp_rank, 0] = val
+            self.tp_best[:, self.tp_rank, 1] = (idx + self.tp_rank * self.cfg.vocab).float()  # ids < 2^24: exact in fp32
+            comm.all_reduce_reg(self.tp_best, self.tp_best_all)
+            win = torch.argmax(self.tp_best_all[:, :, 0], dim=-1, keepdim=True)
+            self.next_ids.copy_(torch.gather(self.tp_best_all[:, :, 1], 1, win).squeeze(1).long())
+            # this rank's embedding shard stands in for the whole table (synthetic weights): fold the id into it
+            torch.remainder(self.next_ids, self.cfg.vocab, out=self.input_ids)
+            return
         self.input_ids.copy_(self.next_ids)
 
     def enable_shared_prefix(self, on: bool = True) -> bool:
