@@ -326,6 +326,15 @@ SGLK_API int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* sc
                                 const float* scales_b, const void* bias, void* out, int M, int N,
                                 int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
                                 int out_dtype, void* stream);
+/* The same product with a scratch buffer (sglk_fp8_mm_workspace_bytes(), contents don't matter): narrow outputs
+ * (N = 1280 of a TP = 8 qkv shard gives 40 blocks) are split along K, fp32 partials summed in split order and scaled
+ * by a second launch.  Falls back to the form above when the workspace is missing or too small. */
+SGLK_API int64_t sglk_fp8_mm_workspace_bytes(int M, int N, int K);
+SGLK_API int sglk_fp8_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a,
+                                   const float* scales_b, const void* bias, void* out, int M, int N,
+                                   int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
+                                   void* workspace, int64_t workspace_bytes, int out_dtype,
+                                   void* stream);
 /* DeepSeek block-scaled form: scales_a [M, K/128] (stride given, row- or M-major), scales_b
  * [N/128, K/128] or its transpose.  Replaces fp8_blockwise_scaled_mm,
  * sgl-kernel/csrc/gemm/fp8_blockwise_gemm_kernel.cu:345-423. */

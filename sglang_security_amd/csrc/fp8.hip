@@ -9,6 +9,9 @@
 // Quantisation is bit-exact integer-valued work (one correctly rounded f32 op per step, then the
 // hardware round-to-nearest-even f32 -> e4m3 conversion of a value already clamped to +-448).
 // The matmuls accumulate in fp32 on v_mfma_f32_16x16x32_fp8_fp8.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace sglk {
@@ -183,6 +186,8 @@ struct MmArgs {
   int64_t sa_m, sa_k, sb_n, sb_k;
   int64_t a_batch, b_batch, out_batch;  // element strides between the matrices of a batch (blockIdx.z)
   int scalar_scales;                    // one scale per operand for the whole batch (bmm_fp8)
+  float* partial;                       // split-K form: blockIdx.z is the K split, raw fp32 sums go to partial[z][M][N]
+  int kb_per_split;
 };
 
 // operand formats of the 16x16x32 MFMA: e4m3 x e4m3, e5m2 x e4m3, e4m3 x e5m2
@@ -233,8 +238,12 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int kblocks = (p.K + 127) / 128;
-  for (int kb = w; kb < kblocks; kb += 4) {
+  int kblocks = (p.K + 127) / 128, kb_first = w;
+  if (p.partial) {  // block-uniform: this block's K split
+    kb_first = blockIdx.z * p.kb_per_split + w;
+    kblocks = min(kblocks, (int)(blockIdx.z + 1) * p.kb_per_split);
+  }
+  for (int kb = kb_first; kb < kblocks; kb += 4) {
     const int k = kb * 128 + 32 * g;
     long af[MT][4], bf[2][4];
 #pragma unroll
@@ -279,6 +288,14 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
     }
     const int n = n0 + 16 * j + l16;
     if (n >= p.N) continue;
+    if (p.partial) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * i + 4 * g + r;
+        if (m < p.M) p.partial[((int64_t)blockIdx.z * p.M + m) * p.N + n] = s[r];
+      }
+      continue;
+    }
     float sbn = 1.f, bn = 0.f;
     if constexpr (!BLOCKWISE) {
       sbn = p.sb[p.scalar_scales ? 0 : n];
@@ -293,6 +310,45 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
       st<TO>(p.out, (int64_t)blockIdx.z * p.out_batch + (int64_t)m * p.out_stride + n, v);
     }
   }
+}
+
+// out[m][n] = (sum over splits, in split order, of partial[z][m][n]) * sa[m] * sb[n] (+ bias)
+template <typename TO>
+__global__ __launch_bounds__(256) void fp8_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
+                                                               const float* __restrict__ sa, const float* __restrict__ sb,
+                                                               const void* __restrict__ bias, void* __restrict__ out, int M,
+                                                               int N, int64_t out_stride) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nv = N / 4;
+  if (idx >= (int64_t)M * nv) return;
+  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int z0 = 0; z0 < splits; z0 += 4) {  // four splits' loads in flight
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = *reinterpret_cast<const f32x4*>(partial + ((int64_t)min(z0 + u, splits - 1) * M + m) * N + n);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (z0 + u < splits) acc += v[u];
+  }
+  const float am = sa[m];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float bn = bias ? ld<TO>(bias, n + j) : 0.f;
+    st<TO>(out, (int64_t)m * out_stride + n + j, acc[j] * am * sb[n + j] + bn);
+  }
+}
+
+// K splits of the two-launch form: narrow outputs leave most of the chip idle otherwise
+static int fp8_splits(int M, int N, int K) {
+  const char* env = getenv("SGLK_FP8_SPLITS");
+  const int kblocks = (K + 127) / 128;
+  if (env && atoi(env) > 0) return std::min(atoi(env), kblocks);
+  if (N % 4 != 0) return 1;
+  const int blocks = (N + 31) / 32 * ((M + 63) / 64);
+  if (blocks >= 200) return 1;
+  return std::max(1, std::min({(512 + blocks - 1) / blocks, kblocks / 8, 16}));
 }
 
 template <typename TO, bool BLOCKWISE, int FMT = 0>
@@ -391,6 +447,53 @@ int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* scales_a, c
   MmArgs p{(const uint8_t*)a, (const uint8_t*)b_nk, scales_a, scales_b, bias, out, M, N, K, a_stride, b_stride,
            out_stride,        0,                    0,        0,        0};
   SGLK_DISPATCH_HALF(out_dtype, TO, return (launch_mm<TO, false>(p, (hipStream_t)stream)));
+  return SGLK_OK;
+}
+
+int64_t sglk_fp8_mm_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int splits = fp8_splits(M, N, K);
+  return splits > 1 ? (int64_t)splits * M * N * (int64_t)sizeof(float) : 0;
+}
+
+int sglk_fp8_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a, const float* scales_b, const void* bias,
+                          void* out, int M, int N, int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
+                          void* workspace, int64_t workspace_bytes, int out_dtype, void* stream) {
+  const int splits = (M > 0 && N > 0 && K > 0) ? fp8_splits(M, N, K) : 1;
+  if (splits <= 1 || !workspace || workspace_bytes < sglk_fp8_mm_workspace_bytes(M, N, K) || !aligned16(workspace))
+    return sglk_fp8_scaled_mm(a, b_nk, scales_a, scales_b, bias, out, M, N, K, a_stride, b_stride, out_stride, out_dtype,
+                              stream);
+  SGLK_CHECK(a && b_nk && scales_a && scales_b && out, "fp8_scaled_mm: null pointer");
+  SGLK_CHECK(K % 16 == 0 && N % 16 == 0, "fp8_scaled_mm: N=%d and K=%d must be multiples of 16", N, K);
+  SGLK_CHECK(a_stride % 16 == 0 && b_stride % 16 == 0 && aligned16(a) && aligned16(b_nk),
+             "fp8_scaled_mm: operand rows must be 16-byte aligned");
+  SGLK_CHECK(a_stride >= K && b_stride >= K && out_stride >= N, "fp8_scaled_mm: stride smaller than the row");
+  const int kblocks = (K + 127) / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;
+  MmArgs p{};
+  p.a = (const uint8_t*)a;
+  p.b = (const uint8_t*)b_nk;
+  p.sa = scales_a;
+  p.sb = scales_b;
+  p.out = out;
+  p.M = M;
+  p.N = N;
+  p.K = K;
+  p.a_stride = a_stride;
+  p.b_stride = b_stride;
+  p.out_stride = out_stride;
+  p.partial = (float*)workspace;
+  p.kb_per_split = per;
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_HALF(out_dtype, TO, {
+    const int rc = launch_mm<TO, false>(p, s, used);
+    if (rc != SGLK_OK) return rc;
+    const int64_t vecs = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL((fp8_splitk_reduce_kernel<TO>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
+                       (const float*)workspace, used, scales_a, scales_b, bias, out, M, N, out_stride);
+  });
+  SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
 

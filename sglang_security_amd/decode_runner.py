@@ -154,9 +154,10 @@ class LlamaDecoder:
                          (c.inter, c.hidden)):
                 ws = max(ws, ops.awq_gemm_workspace_bytes(B, N, K))
         else:
+            need = ops.fp8_mm_workspace_bytes if c.quant == "fp8" else ops.dense_gemm_workspace_bytes
             for K, N in ((c.hidden, self.q_size + 2 * self.kv_size), (self.q_size, c.hidden), (c.hidden, 2 * c.inter),
                          (c.inter, c.hidden)):
-                ws = max(ws, ops.dense_gemm_workspace_bytes(B, N, K))
+                ws = max(ws, need(B, N, K))
         self.workspace = torch.zeros(max(ws, 256), dtype=torch.uint8, device=device)  # ticket words start at zero
         if c.quant == "fp8":
             kmax = max(c.hidden, self.q_size, c.inter)
@@ -217,7 +218,7 @@ class LlamaDecoder:
             elif isinstance(w, _Fp8Linear):
                 xq = self.x_q.view(-1)[:x.shape[0] * w.K].view(x.shape[0], w.K)
                 ops.per_token_quant_fp8(x, xq, self.x_s)
-                ops.fp8_scaled_mm(xq, w.weight.t(), self.x_s, w.scale, self.dtype, None, out)
+                ops.fp8_scaled_mm(xq, w.weight.t(), self.x_s, w.scale, self.dtype, None, out, self.workspace)
             else:
                 ops.dense_gemm_nt(x, w.weight, None, out, self.workspace)
 

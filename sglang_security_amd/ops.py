@@ -385,9 +385,14 @@ def _b_as_nk(mat_b, name):
     return mat_b.t()
 
 
-def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, out=None):
+def fp8_mm_workspace_bytes(M, N, K) -> int:
+    return int(lib().sglk_fp8_mm_workspace_bytes(M, N, K))
+
+
+def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, out=None, workspace=None):
     """fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias) (sgl-kernel/python/sgl_kernel/gemm.py:48-57);
-    `out` (row-major [M, N] of out_dtype) is an addition for callers that own their buffers."""
+    `out` (row-major [M, N] of out_dtype) and `workspace` (fp8_mm_workspace_bytes: narrow outputs are split along
+    K) are additions for callers that own their buffers."""
     _need_gpu(mat_a, mat_b, scales_a, scales_b)
     if mat_a.dim() != 2 or mat_a.stride(1) != 1:
         raise SglkError("fp8_scaled_mm: mat_a must be a row-major 2-D tensor")
@@ -404,6 +409,13 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, out=No
         out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
     elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or out.stride(1) != 1:
         raise SglkError(f"fp8_scaled_mm: out must be a row-major [{M}, {N}] tensor of the output dtype")
+    if workspace is not None:
+        _need_gpu(workspace)
+        check(lib().sglk_fp8_scaled_mm_ws(_ptr(mat_a), _ptr(b), _ptr(scales_a.contiguous()), _ptr(scales_b.contiguous()),
+                                          _ptr(bias), _ptr(out), M, N, K, mat_a.stride(0), b.stride(0), out.stride(0),
+                                          _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                          dtype_code(out_dtype), _stream(mat_a)), "fp8_scaled_mm")
+        return out
     check(lib().sglk_fp8_scaled_mm(_ptr(mat_a), _ptr(b), _ptr(scales_a.contiguous()), _ptr(scales_b.contiguous()),
                                    _ptr(bias), _ptr(out), M, N, K, mat_a.stride(0), b.stride(0), out.stride(0),
                                    dtype_code(out_dtype), _stream(mat_a)), "fp8_scaled_mm")

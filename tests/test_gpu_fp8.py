@@ -141,6 +141,26 @@ def test_fp8_scaled_mm_vs_oracle(M, N, K, out_dtype, with_bias):
     torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1280, 8192), (5, 128, 4096), (64, 512, 1040), (100, 256, 2048), (64, 8192, 1024)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_fp8_scaled_mm_split_k(M, N, K, with_bias):
+    """Two-launch split-K form (workspace given): narrow outputs, a ragged last k-block, a shape that is not split."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b_nk = _fp8_rand((M, K), g), _fp8_rand((N, K), g)
+    sa, sb = torch.rand(M, 1, generator=g) * 0.1, torch.rand(N, 1, generator=g) * 0.1
+    bias = torch.randn(N, generator=g).to(torch.bfloat16) if with_bias else None
+    ws = torch.empty(max(ops.fp8_mm_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=DEV)
+    args = (a.to(DEV), b_nk.to(DEV).t(), sa.to(DEV), sb.to(DEV), torch.bfloat16, None if bias is None else bias.to(DEV))
+    out = ops.fp8_scaled_mm(*args, None, ws)
+    one = ops.fp8_scaled_mm(*args)
+    want = oracle.fp8_scaled_mm(a, b_nk.t(), sa, sb, torch.bfloat16, bias)
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out.cpu().float(), one.cpu().float(), rtol=1e-2, atol=1e-2)
+
+
 def test_fp8_scaled_mm_rejects_bad_shapes():
     ops = _ops()
     from sglang_security_amd._lib import SglkError

@@ -25,7 +25,9 @@ for name, K, N, block in cases:
     else:
         sa = torch.rand(M, 1, device=dev, generator=gen)
         sb = torch.rand(N, 1, device=dev, generator=gen)
-        run = lambda i: ops.fp8_scaled_mm(a, ws[i % copies].t(), sa, sb, torch.bfloat16)
+        work = torch.empty(max(ops.fp8_mm_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=dev)
+        outb = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        run = lambda i: ops.fp8_scaled_mm(a, ws[i % copies].t(), sa, sb, torch.bfloat16, None, outb, work)
     for i in range(copies):
         run(i)
     torch.cuda.synchronize()
