@@ -326,6 +326,16 @@ SGLK_API int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* sc
                                 const float* scales_b, const void* bias, void* out, int M, int N,
                                 int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
                                 int out_dtype, void* stream);
+/* Producers of a w8a8 linear's input that quantise on the way out (for callers that own the whole decoder layer):
+ * fused_add_rmsnorm (residual += x when residual is given; sgl-kernel/csrc/elementwise: norm via
+ * python/sgl_kernel/elementwise.py:10-75) resp. silu_and_mul (elementwise.py:78-100, x = [gate | up] of width 2d)
+ * followed by sgl_per_token_quant_fp8 (gemm.py:131-136), with the roundings of that sequence; the 16-bit tensor
+ * in between is never written.  16-bit x, q e4m3 [rows, hidden] resp. [rows, d], scales fp32 [rows]. */
+SGLK_API int sglk_rmsnorm_quant_fp8(const void* x, void* residual, const void* weight, void* q,
+                                    float* scales, int64_t rows, int hidden, float eps, int gemma,
+                                    int dtype, void* stream);
+SGLK_API int sglk_silu_and_mul_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int d,
+                                         int dtype, void* stream);
 /* The same product with a scratch buffer (sglk_fp8_mm_workspace_bytes(), contents don't matter): narrow outputs
  * (N = 1280 of a TP = 8 qkv shard gives 40 blocks) are split along K, fp32 partials summed in split order and scaled
  * by a second launch.  Falls back to the form above when the workspace is missing or too small. */

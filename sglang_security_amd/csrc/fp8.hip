@@ -98,6 +98,140 @@ __global__ __launch_bounds__(256) void per_token_quant_kernel(const void* __rest
   }
 }
 
+// ---- producers that quantise on the way out: the 16-bit tensor the plain op sequence would write in between is
+// formed (and rounded) in registers only.  One block of 1024 threads per row, up to four 8-element vectors a thread.
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += red[w];
+  __syncthreads();
+  return t;
+}
+__device__ __forceinline__ float block_max_1024(float v, float* red) {
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) t = fmaxf(t, red[w]);
+  __syncthreads();
+  return t;
+}
+
+// residual += x (when given), y = round(rmsnorm(residual) * w), then per-token quantisation of y:
+// fused_add_rmsnorm (norm.cu) followed by sgl_per_token_quant_fp8 (per_token_quant_fp8.cu) with the same roundings
+template <typename T>
+__global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restrict__ xin, void* __restrict__ residual,
+                                                             const void* __restrict__ w, uint8_t* __restrict__ q,
+                                                             float* __restrict__ scales, int hidden, float eps, int gemma) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(xin) + row * hidden;
+  uint16_t* res = residual ? reinterpret_cast<uint16_t*>(residual) + row * hidden : nullptr;
+  const uint16_t* wr = reinterpret_cast<const uint16_t*>(w);
+  const int nvec = hidden >> 3;
+  constexpr int MAXV = 4;
+  float keep[MAXV][8];
+  float ss = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 1024;
+    if (v < nvec) {
+      const short8 xv = reinterpret_cast<const short8*>(x)[v];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) keep[it][j] = Conv<T>::to_f32((uint16_t)xv[j]);
+      if (res) {
+        const short8 rv = reinterpret_cast<const short8*>(res)[v];
+        short8 ro;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          keep[it][j] += Conv<T>::to_f32((uint16_t)rv[j]);
+          ro[j] = (short)Conv<T>::from_f32(keep[it][j]);
+        }
+        reinterpret_cast<short8*>(res)[v] = ro;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss += keep[it][j] * keep[it][j];
+    }
+  }
+  const float inv = rsqrtf(block_sum_1024(ss, red) / (float)hidden + eps);
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 1024;
+    if (v < nvec) {
+      const short8 wv = reinterpret_cast<const short8*>(wr)[v];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float wf = Conv<T>::to_f32((uint16_t)wv[j]);
+        if (gemma) wf += 1.0f;
+        keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32((keep[it][j] * inv) * wf));  // the value rmsnorm stores
+        amax = fmaxf(amax, fabsf(keep[it][j]));
+      }
+    }
+  }
+  amax = block_max_1024(amax, red);
+  const float scale = amax / kFp8Max;
+  if (threadIdx.x == 0) scales[row] = scale;
+  const float sinv = 1.0f / scale;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 1024;
+    if (v < nvec) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = clamp_sym(keep[it][j] * sinv, -kFp8Max, kFp8Max);
+      *reinterpret_cast<uint2*>(q + row * hidden + 8 * v) = cvt8(o);
+    }
+  }
+}
+
+// y = round(round(silu(gate)) * up) per element of x = [gate | up], then per-token quantisation of y:
+// silu_and_mul (activation.cu:22-50) followed by sgl_per_token_quant_fp8
+template <typename T>
+__global__ __launch_bounds__(1024) void silu_mul_quant_kernel(const void* __restrict__ xin, uint8_t* __restrict__ q,
+                                                              float* __restrict__ scales, int d) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(xin) + row * 2 * d;
+  const int nvec = d >> 3;
+  constexpr int MAXV = 4;
+  float keep[MAXV][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 1024;
+    if (v < nvec) {
+      const short8 a = reinterpret_cast<const short8*>(x)[v];
+      const short8 g = reinterpret_cast<const short8*>(x + d)[v];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float av = Conv<T>::to_f32((uint16_t)a[j]);
+        const float sv = Conv<T>::to_f32(Conv<T>::from_f32(av / (1.0f + __expf(-av))));
+        keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32(sv * Conv<T>::to_f32((uint16_t)g[j])));
+        amax = fmaxf(amax, fabsf(keep[it][j]));
+      }
+    }
+  }
+  amax = block_max_1024(amax, red);
+  const float scale = amax / kFp8Max;
+  if (threadIdx.x == 0) scales[row] = scale;
+  const float sinv = 1.0f / scale;
+#pragma unroll
+  for (int it = 0; it < MAXV; ++it) {
+    const int v = threadIdx.x + it * 1024;
+    if (v < nvec) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = clamp_sym(keep[it][j] * sinv, -kFp8Max, kFp8Max);
+      *reinterpret_cast<uint2*>(q + row * d + 8 * v) = cvt8(o);
+    }
+  }
+}
+
 // ---- per (token, group): 16 lanes per group ------------------------------------------------------------
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void per_group_quant_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
@@ -413,6 +547,35 @@ int sglk_per_token_group_quant_fp8(const void* x, void* q, float* scales, int64_
       hipLaunchKernelGGL((per_group_quant_kernel<T, false>), grid, dim3(256), 0, s, x, (uint8_t*)q, scales, rows, hidden,
                          group_size, eps, fp8_min, fp8_max, scale_col_major);
   });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_rmsnorm_quant_fp8(const void* x, void* residual, const void* weight, void* q, float* scales, int64_t rows,
+                           int hidden, float eps, int gemma, int dtype, void* stream) {
+  SGLK_CHECK(x && weight && q && scales, "rmsnorm_quant_fp8: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0, "rmsnorm_quant_fp8: bad shape");
+  SGLK_CHECK(hidden % 8 == 0 && hidden <= 4 * 1024 * 8, "rmsnorm_quant_fp8: hidden=%d must be a multiple of 8, at most 32768",
+             hidden);
+  SGLK_CHECK(aligned16(x) && aligned16(weight) && (!residual || aligned16(residual)) && ((uintptr_t)q & 7) == 0,
+             "rmsnorm_quant_fp8: tensors must be 16-byte aligned");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((rmsnorm_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                        x, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_silu_and_mul_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int d, int dtype, void* stream) {
+  SGLK_CHECK(x && q && scales, "silu_and_mul_quant_fp8: null pointer");
+  SGLK_CHECK(rows >= 0 && d > 0, "silu_and_mul_quant_fp8: bad shape");
+  SGLK_CHECK(d % 8 == 0 && d <= 4 * 1024 * 8, "silu_and_mul_quant_fp8: d=%d must be a multiple of 8, at most 32768", d);
+  SGLK_CHECK(aligned16(x) && ((uintptr_t)q & 7) == 0, "silu_and_mul_quant_fp8: tensors must be 16-byte aligned");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((silu_mul_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                        x, (uint8_t*)q, scales, d));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

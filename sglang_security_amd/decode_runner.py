@@ -331,9 +331,59 @@ class LlamaDecoder:
         torch.argmax(self.logits, dim=-1, out=self.next_ids)
         self.input_ids.copy_(self.next_ids)
 
+    def _xq(self, K):
+        return self.x_q.view(-1)[: self.B * K].view(self.B, K)
+
+    def _fp8_mm(self, name, w, out):
+        """The product on activations a producer has already quantised into x_q / x_s."""
+        run = lambda: ops.fp8_scaled_mm(self._xq(w.K), w.weight.t(), self.x_s, w.scale, self.dtype, None, out, self.workspace)
+        if self.gemm_timer is not None:
+            self.gemm_timer(name, run)
+        else:
+            run()
+
+    def step_fp8(self):
+        """w8a8 layer with the activation quantisation folded into its producers (norm, gated activation): 11 launches
+        per layer instead of 14; the attention output, whose row maximum spans blocks, is quantised on its own."""
+        c = self.cfg
+        self.prepare_for_decode()
+        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
+                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
+        sm_scale = 1.0 / math.sqrt(c.head_dim)
+        q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
+        o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
+        comm = getattr(self, "tp_comm", None)
+        row_out = self.hidden if comm is None else self.tp_buf
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                self.residual.copy_(self.hidden)
+                ops.rmsnorm_quant_fp8(self.hidden, None, L["ln1"], self._xq(c.hidden), self.x_s, c.eps)
+            else:
+                ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln1"], self._xq(c.hidden), self.x_s, c.eps)
+            self._fp8_mm("qkv", L["qkv"], self.qkv)
+            ops.rope_and_store_kv(self.qkv, self.cos_sin, self.positions, self.k_pool[li], self.v_pool[li],
+                                  self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
+            self.attention(li, q_view, o_view, sm_scale)
+            ops.per_token_quant_fp8(self.attn_out, self._xq(self.q_size), self.x_s)
+            self._fp8_mm("o", L["o"], row_out)
+            if comm is not None:
+                comm.all_reduce_reg(self.tp_buf, self.hidden)
+            ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln2"], self._xq(c.hidden), self.x_s, c.eps)
+            self._fp8_mm("gate_up", L["gate_up"], self.gate_up)
+            ops.silu_and_mul_quant_fp8(self.gate_up, self._xq(c.inter), self.x_s)
+            self._fp8_mm("down", L["down"], row_out)
+            if comm is not None:
+                comm.all_reduce_reg(self.tp_buf, self.hidden)
+        ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)
+        ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
+        self._sample()
+
     def step(self):
         if self.fused:
             return self.step_fused()
+        if self.cfg.quant == "fp8" and getattr(self, "fp8_fold_quant", True):
+            return self.step_fp8()
         c = self.cfg
         self.prepare_for_decode()
         ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,

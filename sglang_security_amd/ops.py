@@ -385,6 +385,30 @@ def _b_as_nk(mat_b, name):
     return mat_b.t()
 
 
+def rmsnorm_quant_fp8(x, residual, weight, out_q, out_s, eps, gemma=False):
+    """fused_add_rmsnorm (residual += x when given) + per-token fp8 quantisation of the normalised rows."""
+    _need_gpu(x, weight, out_q, out_s)
+    rows, hidden = x.shape
+    if not (x.is_contiguous() and out_q.is_contiguous() and (residual is None or residual.is_contiguous())):
+        raise SglkError("rmsnorm_quant_fp8: tensors must be contiguous")
+    if out_q.dtype != torch.float8_e4m3fn or out_s.dtype != torch.float32 or out_s.numel() < rows:
+        raise SglkError("rmsnorm_quant_fp8: out_q must be float8_e4m3fn and out_s float32 [rows]")
+    check(lib().sglk_rmsnorm_quant_fp8(_ptr(x), _ptr(residual), _ptr(weight), _ptr(out_q), _ptr(out_s), rows, hidden,
+                                       float(eps), 1 if gemma else 0, dtype_code(x.dtype), _stream(x)), "rmsnorm_quant_fp8")
+
+
+def silu_and_mul_quant_fp8(x, out_q, out_s):
+    """silu_and_mul over x = [gate | up] + per-token fp8 quantisation of the product rows."""
+    _need_gpu(x, out_q, out_s)
+    rows, two_d = x.shape
+    if not (x.is_contiguous() and out_q.is_contiguous()):
+        raise SglkError("silu_and_mul_quant_fp8: tensors must be contiguous")
+    if out_q.dtype != torch.float8_e4m3fn or out_s.dtype != torch.float32 or out_s.numel() < rows:
+        raise SglkError("silu_and_mul_quant_fp8: out_q must be float8_e4m3fn and out_s float32 [rows]")
+    check(lib().sglk_silu_and_mul_quant_fp8(_ptr(x), _ptr(out_q), _ptr(out_s), rows, two_d // 2, dtype_code(x.dtype),
+                                            _stream(x)), "silu_and_mul_quant_fp8")
+
+
 def fp8_mm_workspace_bytes(M, N, K) -> int:
     return int(lib().sglk_fp8_mm_workspace_bytes(M, N, K))
 

@@ -161,6 +161,57 @@ def test_fp8_scaled_mm_split_k(M, N, K, with_bias):
     torch.testing.assert_close(out.cpu().float(), one.cpu().float(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,hidden", [(64, 8192), (5, 512), (3, 14336), (1, 4096)])
+@pytest.mark.parametrize("with_residual", [True, False])
+def test_rmsnorm_quant_fp8(dtype, rows, hidden, with_residual):
+    """fused_add_rmsnorm + sgl_per_token_quant_fp8 in one launch against the oracle's two steps: the residual is
+    bit-exact; a normalised value may sit one 16-bit ulp away (another summation order of the squares), which can
+    move an fp8 code by one step."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + hidden)
+    x = torch.randn(rows, hidden, generator=g).to(dtype)
+    r = torch.randn(rows, hidden, generator=g).to(dtype) if with_residual else None
+    w = (1 + 0.1 * torch.randn(hidden, generator=g)).to(dtype)
+    if with_residual:
+        want_y, want_r = oracle.fused_add_rmsnorm(x, r, w, 1e-5)
+    else:
+        want_y, want_r = oracle.rmsnorm(x, w, 1e-5), None
+    want_q, want_s = oracle.per_token_quant_fp8(want_y)
+    q = torch.empty(rows, hidden, dtype=F8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    rd = r.to(DEV) if with_residual else None
+    ops.rmsnorm_quant_fp8(x.to(DEV), rd, w.to(DEV), q, sc, 1e-5)
+    if with_residual:
+        assert torch.equal(rd.cpu().view(torch.int16), want_r.view(torch.int16))
+    torch.testing.assert_close(sc.cpu(), want_s.flatten(), rtol=1e-2, atol=0)
+    deq = q.cpu().float() * sc.cpu()[:, None]
+    ref = want_q.float() * want_s.reshape(-1, 1)
+    assert (deq - ref).abs().max().item() <= 0.08 * ref.abs().max().item()   # one e4m3 step at the top of the range
+    assert (q.cpu().view(torch.uint8) != want_q.view(torch.uint8)).float().mean().item() < 0.02
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,d", [(64, 3584), (7, 14336), (2, 128)])
+def test_silu_and_mul_quant_fp8(dtype, rows, d):
+    """silu_and_mul + sgl_per_token_quant_fp8 in one launch, bit for bit the two-step result."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + d)
+    x = torch.randn(rows, 2 * d, generator=g).to(dtype).to(DEV)
+    y = torch.empty(rows, d, dtype=dtype, device=DEV)
+    ops.act_and_mul(y, x, 0)
+    q2 = torch.empty(rows, d, dtype=F8, device=DEV)
+    s2 = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.per_token_quant_fp8(y, q2, s2)
+    q = torch.empty(rows, d, dtype=F8, device=DEV)
+    sc = torch.empty(rows, dtype=torch.float32, device=DEV)
+    ops.silu_and_mul_quant_fp8(x, q, sc)
+    assert torch.equal(sc.cpu(), s2.cpu())
+    assert torch.equal(q.cpu().view(torch.uint8), q2.cpu().view(torch.uint8))
+
+
 def test_fp8_scaled_mm_rejects_bad_shapes():
     ops = _ops()
     from sglang_security_amd._lib import SglkError
