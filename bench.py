@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Decode-throughput benchmark of the sglk hot path.
 
-Workload (BASELINE.json configs[2] on the bench_in_batch_prefix shape): Llama-3-8B, AWQ int4 (G=128) weights,
+Workload (the bench_in_batch_prefix shape of the reference, benchmark/bench_in_batch_prefix): Llama-3-8B, AWQ int4 (G=128) weights,
 bf16 activations/KV, batch 64 per GPU, every request = 1024 shared prefix tokens (same KV-pool slots, a radix
 hit) + 128 private tokens, greedy decode.  One step = one full decode step of the whole batch: metadata, 32
 decoder layers (norm, fused AWQ GEMMs, RoPE + KV write, paged attention, gated MLP), final norm, bf16 lm_head,

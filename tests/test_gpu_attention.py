@@ -227,7 +227,7 @@ def test_decode_attention_noncontiguous_pool():
 
 
 def test_decode_attention_full_size_properties():
-    """BASELINE workload size (batch 64, 1024 shared + 128 private tokens, Llama-3-8B heads).  Too large
+    """The benchmark workload's size (batch 64, 1024 shared + 128 private tokens, Llama-3-8B heads).  Too large
     for the scalar oracle in seconds, so: (1) the result must not depend on the split count (8 vs 1 vs 16);
     (2) requests with identical slots and queries must give identical rows; (3) a sample of rows is checked
     against the oracle."""

@@ -101,7 +101,7 @@ def test_awq_gemm_exact_on_integers():
 
 @pytest.mark.parametrize("M,K,N", [(64, 4096, 6144), (64, 4096, 4096), (64, 14336, 4096), (64, 4096, 28672)])
 def test_awq_gemm_llama8b_shapes_linearity(M, K, N):
-    """Llama-3-8B projection shapes (BASELINE config).  Size-independent properties: (1) linearity in x on
+    """Llama-3-8B projection shapes (the benchmark's model).  Size-independent properties: (1) linearity in x on
     exactly representable inputs, (2) a sampled set of columns against the oracle."""
     import oracle
 
