@@ -663,8 +663,8 @@ int sglk_fp8_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a
 int sglk_bmm_fp8(const void* a, const void* b_nk, const float* scale_a, const float* scale_b, void* out, int batch, int M,
                  int N, int K, int64_t a_batch_stride, int64_t a_stride, int64_t b_batch_stride, int64_t b_stride,
                  int64_t out_batch_stride, int64_t out_stride, int a_e5m2, int b_e5m2, int out_dtype, void* stream) {
-  SGLK_CHECK(a && b_nk && scale_a && scale_b && out, "bmm_fp8: null pointer");
   SGLK_CHECK(batch >= 0 && M >= 0 && N > 0 && K > 0, "bmm_fp8: bad shape batch=%d M=%d N=%d K=%d", batch, M, N, K);
+  SGLK_CHECK(batch == 0 || M == 0 || (a && b_nk && scale_a && scale_b && out), "bmm_fp8: null pointer");
   SGLK_CHECK(!(a_e5m2 && b_e5m2), "bmm_fp8: both operands e5m2 is not a valid combination");
   SGLK_CHECK(K % 16 == 0, "bmm_fp8: K=%d must be a multiple of 16", K);
   SGLK_CHECK(a_stride % 16 == 0 && b_stride % 16 == 0 && a_batch_stride % 16 == 0 && b_batch_stride % 16 == 0 &&

@@ -144,7 +144,8 @@ extern "C" {
 int sglk_moe_align_block_size(const void* topk_ids, int ids_is64, int64_t numel, int num_experts, int block_size,
                               int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad,
                               int32_t* cumsum_buffer, void* stream) {
-  SGLK_CHECK(topk_ids && sorted_token_ids && expert_ids && num_tokens_post_pad, "moe_align_block_size: null pointer");
+  SGLK_CHECK((topk_ids || numel == 0) && sorted_token_ids && expert_ids && num_tokens_post_pad,
+             "moe_align_block_size: null pointer");
   SGLK_CHECK(numel >= 0 && numel < (1ll << 31), "moe_align_block_size: bad element count");
   SGLK_CHECK(num_experts > 0 && num_experts <= kMoeMaxExperts, "moe_align_block_size: num_experts=%d not in 1..%d",
              num_experts, kMoeMaxExperts);
@@ -163,8 +164,9 @@ int sglk_moe_align_block_size(const void* topk_ids, int ids_is64, int64_t numel,
 
 int sglk_topk_softmax(const void* gating_output, float* topk_weights, int32_t* topk_ids, int32_t* token_expert_indices,
                       int num_tokens, int num_experts, int topk, int64_t gating_stride, int dtype, void* stream) {
-  SGLK_CHECK(gating_output && topk_weights && topk_ids && token_expert_indices, "topk_softmax: null pointer");
   SGLK_CHECK(num_tokens >= 0 && num_experts > 0 && num_experts <= kTopkMaxExperts, "topk_softmax: bad shape");
+  SGLK_CHECK(num_tokens == 0 || (gating_output && topk_weights && topk_ids && token_expert_indices),
+             "topk_softmax: null pointer");
   SGLK_CHECK(topk > 0 && topk <= num_experts, "topk_softmax: topk=%d not in 1..%d", topk, num_experts);
   SGLK_CHECK(gating_stride >= num_experts, "topk_softmax: row stride smaller than the row");
   if (num_tokens == 0) return SGLK_OK;

@@ -152,3 +152,22 @@ def test_sgl_kernel_surface_moe_and_bmm():
     cs = torch.zeros(17, dtype=torch.int32, device=DEV)
     torch.ops.sgl_kernel.moe_align_block_size(ids, 16, 4, srt, ex, tot, cnt, cs)
     assert int(tot) % 4 == 0 and int(tot) >= 18
+
+
+def test_empty_inputs():
+    """Nothing to do: every entry point returns without touching its outputs' meaningful part."""
+    ops = _ops()
+    ids = torch.zeros(0, 2, dtype=torch.int32, device=DEV)
+    srt = torch.full((8 * 3,), 0, dtype=torch.int32, device=DEV)
+    ex = torch.full((8,), -1, dtype=torch.int32, device=DEV)
+    tot = torch.full((1,), 7, dtype=torch.int32, device=DEV)
+    ops.moe_align_block_size(ids, 8, 4, srt, ex, tot)
+    assert int(tot) == 0 and (ex == -1).all()
+    w = torch.empty(0, 2, dtype=torch.float32, device=DEV)
+    i = torch.empty(0, 2, dtype=torch.int32, device=DEV)
+    ops.topk_softmax(w, i, torch.empty_like(i), torch.empty(0, 16, device=DEV))
+    a = torch.empty(0, 4, 32, dtype=torch.float8_e4m3fn, device=DEV)
+    b = torch.empty(0, 16, 32, dtype=torch.float8_e4m3fn, device=DEV).transpose(-2, -1)
+    one = torch.ones(1, device=DEV)
+    assert ops.bmm_fp8(a, b, one, one, torch.bfloat16).shape == (0, 4, 16)
+    torch.cuda.synchronize()
