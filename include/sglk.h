@@ -382,6 +382,14 @@ SGLK_API int sglk_topk_softmax(const void* gating_output, float* topk_weights, i
                                int32_t* token_expert_indices, int num_tokens, int num_experts,
                                int topk, int64_t gating_stride, int dtype, void* stream);
 
+/* The block-scaled product with the same scratch buffer (sglk_fp8_mm_workspace_bytes()): K split over blocks for
+ * narrow outputs; the partials are already scaled, the second launch adds them up in split order. */
+SGLK_API int sglk_fp8_blockwise_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a,
+                                             const float* scales_b, void* out, int M, int N, int K,
+                                             int64_t sa_stride_m, int64_t sa_stride_k,
+                                             int64_t sb_stride_n, int64_t sb_stride_k, void* workspace,
+                                             int64_t workspace_bytes, int out_dtype, void* stream);
+
 /* ------------------------------------------------------------------ C1: custom all-reduce ----- */
 
 /* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.

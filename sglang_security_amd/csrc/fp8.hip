@@ -377,8 +377,26 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
     kb_first = blockIdx.z * p.kb_per_split + w;
     kblocks = min(kblocks, (int)(blockIdx.z + 1) * p.kb_per_split);
   }
-  for (int kb = kb_first; kb < kblocks; kb += 4) {
+  auto body = [&](int kb) {
     const int k = kb * 128 + 32 * g;
+    float sc[MT][2][4];
+    if constexpr (BLOCKWISE) {
+      // the block's scales are requested before the operands, one product per output element
+      float bs[2], as[MT][4];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bs[j] = p.sb[(int64_t)(ncol[j] / 128) * p.sb_n + (int64_t)kb * p.sb_k];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          as[i][r] = p.sa[(int64_t)min(m0 + 16 * i + 4 * g + r, p.M - 1) * p.sa_m + (int64_t)kb * p.sa_k];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[i][j][r] = as[i][r] * bs[j];
+    }
     long af[MT][4], bf[2][4];
 #pragma unroll
     for (int i = 0; i < MT; ++i) load32(arow[i], k, p.K, af[i]);
@@ -393,18 +411,14 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
         for (int s = 0; s < 4; ++s) acc = mma_f8<FMT>(af[i][s], bf[j][s], acc);
         if constexpr (BLOCKWISE) {
           // C layout: column = lane & 15, row = 4 * (lane >> 4) + r
-          const float bs = p.sb[(int64_t)(ncol[j] / 128) * p.sb_n + (int64_t)kb * p.sb_k];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = min(m0 + 16 * i + 4 * g + r, p.M - 1);
-            const float as = p.sa[(int64_t)m * p.sa_m + (int64_t)kb * p.sa_k];
-            tot[i][j][r] += acc[r] * as * bs;
-          }
+          for (int r = 0; r < 4; ++r) tot[i][j][r] += acc[r] * sc[i][j][r];
         } else {
           tot[i][j] = acc;
         }
       }
-  }
+  };
+  for (int kb = kb_first; kb < kblocks; kb += 4) body(kb);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -446,7 +460,7 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
   }
 }
 
-// out[m][n] = (sum over splits, in split order, of partial[z][m][n]) * sa[m] * sb[n] (+ bias)
+// out[m][n] = (sum over splits, in split order, of partial[z][m][n]) * sa[m] * sb[n] (+ bias); sa / sb optional
 template <typename TO>
 __global__ __launch_bounds__(256) void fp8_splitk_reduce_kernel(const float* __restrict__ partial, int splits,
                                                                const float* __restrict__ sa, const float* __restrict__ sb,
@@ -466,11 +480,11 @@ __global__ __launch_bounds__(256) void fp8_splitk_reduce_kernel(const float* __r
     for (int u = 0; u < 4; ++u)
       if (z0 + u < splits) acc += v[u];
   }
-  const float am = sa[m];
+  const float am = sa ? sa[m] : 1.f;  // no scales: the partials of the block-scaled form are final sums
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float bn = bias ? ld<TO>(bias, n + j) : 0.f;
-    st<TO>(out, (int64_t)m * out_stride + n + j, acc[j] * am * sb[n + j] + bn);
+    st<TO>(out, (int64_t)m * out_stride + n + j, acc[j] * am * (sb ? sb[n + j] : 1.f) + bn);
   }
 }
 
@@ -711,6 +725,37 @@ int sglk_fp8_blockwise_scaled_mm(const void* a, const void* b_nk, const float* s
   MmArgs p{(const uint8_t*)a, (const uint8_t*)b_nk, scales_a,    scales_b,    nullptr,     out,        M, N, K, K, K,
            N,                 sa_stride_m,          sa_stride_k, sb_stride_n, sb_stride_k};
   SGLK_DISPATCH_HALF(out_dtype, TO, return (launch_mm<TO, true>(p, (hipStream_t)stream)));
+  return SGLK_OK;
+}
+
+int sglk_fp8_blockwise_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a, const float* scales_b,
+                                    void* out, int M, int N, int K, int64_t sa_stride_m, int64_t sa_stride_k,
+                                    int64_t sb_stride_n, int64_t sb_stride_k, void* workspace, int64_t workspace_bytes,
+                                    int out_dtype, void* stream) {
+  const int splits = (M > 0 && N > 0 && K > 0) ? fp8_splits(M, N, K) : 1;
+  if (splits <= 1 || !workspace || workspace_bytes < sglk_fp8_mm_workspace_bytes(M, N, K) || !aligned16(workspace))
+    return sglk_fp8_blockwise_scaled_mm(a, b_nk, scales_a, scales_b, out, M, N, K, sa_stride_m, sa_stride_k, sb_stride_n,
+                                        sb_stride_k, out_dtype, stream);
+  SGLK_CHECK(a && b_nk && scales_a && scales_b && out, "fp8_blockwise_scaled_mm: null pointer");
+  SGLK_CHECK(K % 16 == 0 && N % 16 == 0, "fp8_blockwise_scaled_mm: N=%d and K=%d must be multiples of 16", N, K);
+  SGLK_CHECK(aligned16(a) && aligned16(b_nk), "fp8_blockwise_scaled_mm: operands must be 16-byte aligned");
+  const int kblocks = (K + 127) / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;
+  MmArgs p{(const uint8_t*)a, (const uint8_t*)b_nk, scales_a,    scales_b,    nullptr,     out,        M, N, K, K, K,
+           N,                 sa_stride_m,          sa_stride_k, sb_stride_n, sb_stride_k};
+  p.partial = (float*)workspace;
+  p.kb_per_split = per;
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_HALF(out_dtype, TO, {
+    const int rc = launch_mm<TO, true>(p, s, used);
+    if (rc != SGLK_OK) return rc;
+    const int64_t vecs = (int64_t)M * (N / 4);
+    hipLaunchKernelGGL((fp8_splitk_reduce_kernel<TO>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
+                       (const float*)workspace, used, (const float*)nullptr, (const float*)nullptr, (const void*)nullptr,
+                       out, M, N, (int64_t)N);
+  });
+  SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
 

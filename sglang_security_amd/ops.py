@@ -509,7 +509,7 @@ def topk_softmax(topk_weights, topk_ids, token_expert_indices, gating_output):
                                   _stream(gating_output)), "topk_softmax")
 
 
-def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
+def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, workspace=None):
     """fp8_blockwise_scaled_mm (sgl-kernel/python/sgl_kernel/gemm.py:36-45): scales_a [M, K/128] (any strides),
     scales_b [K/128, N/128] as the reference passes it (the transpose of the [N/128, K/128] checkpoint tensor)."""
     _need_gpu(mat_a, mat_b, scales_a, scales_b)
@@ -525,6 +525,14 @@ def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
     if tuple(scales_a.shape) != (M, kb) or tuple(scales_b.shape) != (kb, nb):
         raise SglkError(f"fp8_blockwise_scaled_mm: scales_a must be [{M},{kb}] and scales_b [{kb},{nb}]")
     out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    if workspace is not None:  # an addition: narrow outputs are split along K (fp8_mm_workspace_bytes)
+        _need_gpu(workspace)
+        check(lib().sglk_fp8_blockwise_scaled_mm_ws(_ptr(mat_a), _ptr(b), _ptr(scales_a), _ptr(scales_b), _ptr(out), M, N,
+                                                    K, scales_a.stride(0), scales_a.stride(1), scales_b.stride(1),
+                                                    scales_b.stride(0), _ptr(workspace),
+                                                    workspace.numel() * workspace.element_size(), dtype_code(out_dtype),
+                                                    _stream(mat_a)), "fp8_blockwise_scaled_mm")
+        return out
     check(lib().sglk_fp8_blockwise_scaled_mm(_ptr(mat_a), _ptr(b), _ptr(scales_a), _ptr(scales_b), _ptr(out), M, N, K,
                                              scales_a.stride(0), scales_a.stride(1), scales_b.stride(1),
                                              scales_b.stride(0), dtype_code(out_dtype), _stream(mat_a)),

@@ -212,6 +212,27 @@ def test_silu_and_mul_quant_fp8(dtype, rows, d):
     assert torch.equal(q.cpu().view(torch.uint8), q2.cpu().view(torch.uint8))
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 4608, 7168), (16, 512, 7168), (100, 1536, 1024), (64, 2112, 2048)])
+def test_fp8_blockwise_split_k(M, N, K):
+    """Block-scaled product with a workspace (K split over blocks) against the single-launch form and the oracle."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b_nk = _fp8_rand((M, K), g), _fp8_rand((N, K), g)
+    kb, nb = (K + 127) // 128, (N + 127) // 128
+    sa = torch.rand(M, kb, generator=g) * 0.1 + 0.01
+    sb = torch.rand(kb, nb, generator=g) * 0.1 + 0.01
+    ws = torch.empty(max(ops.fp8_mm_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=DEV)
+    args = (a.to(DEV), b_nk.to(DEV).t(), sa.to(DEV), sb.to(DEV), torch.bfloat16)
+    out = ops.fp8_blockwise_scaled_mm(*args, ws).float().cpu()
+    one = ops.fp8_blockwise_scaled_mm(*args).float().cpu()
+    want = oracle.fp8_blockwise_mm(a, b_nk, sa, sb.t().contiguous(), torch.bfloat16).float()
+    scale = want.abs().max().item()
+    assert (out - want).abs().max().item() <= 1e-2 * scale
+    assert (out - one).abs().max().item() <= 1e-2 * scale
+
+
 def test_fp8_scaled_mm_rejects_bad_shapes():
     ops = _ops()
     from sglang_security_amd._lib import SglkError

@@ -19,9 +19,11 @@ for name, K, N, block in cases:
     a = (torch.randn(M, K, device=dev, generator=gen) * 0.5).to(F8)
     ws = [(torch.randn(N, K, device=dev, generator=gen) * 0.5).to(F8) for _ in range(copies)]
     if block:
-        sa = torch.rand(M, K // 128, device=dev, generator=gen) + 0.1
+        # M-contiguous activation scales, as the reference's quantiser hands them to this product
+        sa = (torch.rand(M, K // 128, device=dev, generator=gen) + 0.1).t().contiguous().t()
         sb = torch.rand(K // 128, (N + 127) // 128, device=dev, generator=gen) + 0.1
-        run = lambda i: ops.fp8_blockwise_scaled_mm(a, ws[i % copies].t(), sa, sb, torch.bfloat16)
+        bwork = torch.empty(max(ops.fp8_mm_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=dev)
+        run = lambda i: ops.fp8_blockwise_scaled_mm(a, ws[i % copies].t(), sa, sb, torch.bfloat16, bwork)
     else:
         sa = torch.rand(M, 1, device=dev, generator=gen)
         sb = torch.rand(N, 1, device=dev, generator=gen)
