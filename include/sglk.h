@@ -101,6 +101,18 @@ SGLK_API int sglk_decode_attention_shared_prefix(
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
     int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* ScheduleBatch.prepare_for_decode on device-resident batch state (python/sglang/srt/managers/schedule_batch.py:
+ * 1464-1527): positions[b] = seq_lens[b]; out_cache_loc[b] = req_to_token[req_pool_indices[b], seq_lens[b]] (the
+ * slot the request table already holds for the next position); seq_lens[b] += 1.  One launch. */
+SGLK_API int sglk_prepare_for_decode(const int32_t* req_to_token, int64_t row_stride,
+                                     const void* req_pool_indices, int idx_is64, void* seq_lens,
+                                     int lens_is64, int64_t* positions, void* out_cache_loc,
+                                     int loc_is64, int bs, void* stream);
+/* Greedy sampling: out[r] = index of the first maximum of row r (torch.argmax(logits, -1),
+ * python/sglang/srt/layers/sampler.py greedy branch). */
+SGLK_API int sglk_argmax(const void* x, int64_t* out, int64_t rows, int cols, int64_t row_stride,
+                         int dtype, void* stream);
+
 /* Longest common prefix (in slots) of the batch's req_to_token rows, one group covering the whole
  * batch: out[0] = min over b of the first j with req_to_token[idx[b], j] != req_to_token[idx[0], j],
  * capped at min(seq_lens) - 1.  Device-side helper for the shared-prefix path when the scheduler

@@ -160,6 +160,63 @@ __global__ void __launch_bounds__(256) common_prefix_kernel(const int32_t* __res
 
 __global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
 
+// kv_indptr, num_kv_splits and kv_indices in one launch: block b finds its own offset (the sum of the lengths
+// before it) and gathers its row; block 0 also writes the offsets and the split counts.
+__global__ void __launch_bounds__(256) decode_metadata_kernel(const int32_t* __restrict__ req_to_token, int64_t row_stride,
+                                                              const void* req_pool_indices, int idx_is64,
+                                                              const void* seq_lens, int lens_is64,
+                                                              int32_t* __restrict__ kv_indptr,
+                                                              int32_t* __restrict__ kv_indices,
+                                                              int32_t* __restrict__ num_kv_splits, int bs, int num_head,
+                                                              int num_kv_head, int max_kv_splits, int device_core_count) {
+  __shared__ int red[256];
+  const int b = blockIdx.x;
+  int s = 0;
+  for (int i = threadIdx.x; i < b; i += 256) s += (int)ld_idx(seq_lens, lens_is64, i);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const int start = red[0];
+  __syncthreads();
+  const int64_t row = ld_idx(req_pool_indices, idx_is64, b);
+  const int64_t n = ld_idx(seq_lens, lens_is64, b);
+  const int32_t* src = req_to_token + row * row_stride;
+  int32_t* dst = kv_indices + start;
+  for (int64_t j = (int64_t)blockIdx.y * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.y * 256) dst[j] = src[j];
+  if (blockIdx.y == 0 && threadIdx.x == 0) {
+    kv_indptr[b + 1] = start + (int)n;
+    if (b == 0) kv_indptr[0] = 0;
+  }
+  if (b == 0 && blockIdx.y == 0)
+    num_kv_splits_body(num_kv_splits, seq_lens, lens_is64, bs, 1, num_head, num_kv_head, max_kv_splits, device_core_count,
+                       red);
+}
+
+// schedule_batch.py:1464-1527 (prepare_for_decode) on device state: the new token's position is the number of
+// tokens cached so far, seq_lens grows by one, out_cache_loc is the slot the request table holds for that position
+__global__ void __launch_bounds__(256) prepare_for_decode_kernel(const int32_t* __restrict__ req_to_token, int64_t row_stride,
+                                                                 const void* req_pool_indices, int idx_is64,
+                                                                 void* seq_lens, int lens_is64, int64_t* positions,
+                                                                 void* out_cache_loc, int loc_is64, int bs) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= bs) return;
+  const int64_t pos = ld_idx(seq_lens, lens_is64, b);
+  const int64_t row = ld_idx(req_pool_indices, idx_is64, b);
+  const int32_t slot = req_to_token[row * row_stride + pos];
+  positions[b] = pos;
+  if (lens_is64)
+    reinterpret_cast<int64_t*>(seq_lens)[b] = pos + 1;
+  else
+    reinterpret_cast<int32_t*>(seq_lens)[b] = (int32_t)(pos + 1);
+  if (loc_is64)
+    reinterpret_cast<int64_t*>(out_cache_loc)[b] = slot;
+  else
+    reinterpret_cast<int32_t*>(out_cache_loc)[b] = slot;
+}
+
 // ---------------------------------------------------------------------------------------------
 // generic stage 1: one wave per (request, query head, split); any head size, any float type
 // ---------------------------------------------------------------------------------------------
@@ -690,13 +747,27 @@ int sglk_decode_metadata(const int32_t* req_to_token, int64_t row_stride, const 
                          int32_t* num_kv_splits, int bs, int num_head, int num_kv_head, int max_kv_splits,
                          int device_core_count, void* stream) {
   SGLK_CHECK(bs > 0, "decode_metadata: empty batch");
-  int rc = sglk_kv_indptr_cumsum(seq_lens, lens_is64, kv_indptr, bs, stream);
-  if (rc) return rc;
-  rc = sglk_get_num_kv_splits(num_kv_splits, seq_lens, lens_is64, bs, 1, num_head, num_kv_head, max_kv_splits,
-                              device_core_count, stream);
-  if (rc) return rc;
-  return sglk_create_kv_indices(req_to_token, row_stride, req_pool_indices, idx_is64, seq_lens, lens_is64, kv_indptr,
-                                nullptr, 0, kv_indices, bs, stream);
+  SGLK_CHECK(req_to_token && req_pool_indices && seq_lens && kv_indptr && kv_indices && num_kv_splits,
+             "decode_metadata: null pointer");
+  SGLK_CHECK(num_head > 0 && num_kv_head > 0 && max_kv_splits > 0 && device_core_count > 0, "decode_metadata: bad argument");
+  const int ysl = bs >= 128 ? 1 : (bs >= 32 ? 4 : 8);  // slices per row: keep a few hundred blocks in flight
+  hipLaunchKernelGGL(decode_metadata_kernel, dim3(bs, ysl), dim3(256), 0, (hipStream_t)stream, req_to_token, row_stride,
+                     req_pool_indices, idx_is64, seq_lens, lens_is64, kv_indptr, kv_indices, num_kv_splits, bs, num_head,
+                     num_kv_head, max_kv_splits, device_core_count);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_prepare_for_decode(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,
+                            void* seq_lens, int lens_is64, int64_t* positions, void* out_cache_loc, int loc_is64, int bs,
+                            void* stream) {
+  SGLK_CHECK(bs >= 0, "prepare_for_decode: negative batch");
+  if (bs == 0) return SGLK_OK;
+  SGLK_CHECK(req_to_token && req_pool_indices && seq_lens && positions && out_cache_loc, "prepare_for_decode: null pointer");
+  hipLaunchKernelGGL(prepare_for_decode_kernel, dim3((bs + 255) / 256), dim3(256), 0, (hipStream_t)stream, req_to_token,
+                     row_stride, req_pool_indices, idx_is64, seq_lens, lens_is64, positions, out_cache_loc, loc_is64, bs);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
 }
 
 int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,

@@ -241,35 +241,21 @@ struct WaveAttn {
   }
 
   int4v kreg[8], vreg[8];  // one tile in flight: instruction i covers rows 4i + g
-  // pool slots of this lane's eight rows of the tile starting at token t0
-  __device__ __forceinline__ void load_slots(const int32_t* idx, int t0, int s0, int s1, int32_t (&slot)[8]) const {
-    const int g = (threadIdx.x & 63) >> 4;
+  __device__ __forceinline__ void fetch(const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                        int64_t v_stride_n, const int32_t* idx, int t0, int s0, int s1) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, chunk = lane & 15;  // chunk: 16-byte piece of the row this lane fetches
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       int tok = t0 + 4 * i + g;
       tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
-      slot[i] = idx[tok];
+      const int64_t slot = idx[tok];
+      kreg[i] = *reinterpret_cast<const int4v*>(kbase + slot * k_stride_n + chunk * 8);
+      vreg[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
     }
-  }
-  __device__ __forceinline__ void fetch_rows(const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
-                                             int64_t v_stride_n, const int32_t (&slot)[8]) {
-    const int chunk = threadIdx.x & 15;  // 16-byte piece of the row this lane fetches
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      kreg[i] = *reinterpret_cast<const int4v*>(kbase + (int64_t)slot[i] * k_stride_n + chunk * 8);
-      vreg[i] = *reinterpret_cast<const int4v*>(vbase + (int64_t)slot[i] * v_stride_n + chunk * 8);
-    }
-  }
-  __device__ __forceinline__ void fetch(const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
-                                        int64_t v_stride_n, const int32_t* idx, int t0, int s0, int s1) {
-    int32_t slot[8];
-    load_slots(idx, t0, s0, s1, slot);
-    fetch_rows(kbase, vbase, k_stride_n, v_stride_n, slot);
   }
 
-  // Stream tokens [s0, s1) of the slot list idx (wave-uniform range, may be empty).  PREFETCHED: the caller has
-  // already requested the rows of the tile at s0 (fetch / fetch_rows) for a non-empty range.
-  template <bool PREFETCHED = false>
+  // Stream tokens [s0, s1) of the slot list idx (wave-uniform range, may be empty).
   __device__ __forceinline__ void run(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
                                       int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
                                       float sm_scale, float logit_cap) {
@@ -288,7 +274,7 @@ struct WaveAttn {
       }
     };
 
-    if (!PREFETCHED && s1 > s0) fetch(kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
+    if (s1 > s0) fetch(kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
     for (int t0 = s0; t0 < s1; t0 += kTile) {
       park();
       if (t0 + kTile < s1)  // next tile's rows fly while this one is multiplied

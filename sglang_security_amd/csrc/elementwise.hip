@@ -525,6 +525,51 @@ __global__ void __launch_bounds__(256) act_and_mul_xs_kernel(void* __restrict__ 
   }
 }
 
+// Greedy token: index of the first maximum of every row (torch.argmax, sampler.py greedy path).  One block per row,
+// eight elements per load for 16-bit rows.
+template <typename T>
+__global__ void __launch_bounds__(1024) argmax_rows_kernel(const void* __restrict__ x, int64_t* __restrict__ out, int cols,
+                                                           int64_t row_stride) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int64_t row = blockIdx.x;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  auto take = [&](float v, int i) {
+    if (v > best || (v == best && i < idx) || (v != v && !(best != best))) {  // a NaN wins, as in torch
+      best = v;
+      idx = i;
+    }
+  };
+  if constexpr (sizeof(typename Raw<T>::type) == 2) {
+    const uint16_t* r = reinterpret_cast<const uint16_t*>(x) + row * row_stride;
+    const int nv = ((row_stride % 8) == 0 && aligned16(x)) ? cols / 8 : 0;
+    for (int v = threadIdx.x; v < nv; v += 1024) {
+      const short8 q = reinterpret_cast<const short8*>(r)[v];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) take(Conv<T>::to_f32((uint16_t)q[j]), 8 * v + j);
+    }
+    for (int i = nv * 8 + threadIdx.x; i < cols; i += 1024) take(Conv<T>::to_f32(r[i]), i);
+  } else {
+    for (int i = threadIdx.x; i < cols; i += 1024) take(ld<T>(x, row * row_stride + i), i);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    take(ov, oi);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    bv[threadIdx.x >> 6] = best;
+    bi[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) take(bv[w], bi[w]);
+    out[row] = idx == 0x7fffffff ? 0 : idx;
+  }
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -717,6 +762,17 @@ int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits,
                                         (size_t)row_len * 2, (hipStream_t)stream, qkv, partials, splits, part_stride, bias,
                                         cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, q_heads, kv_heads,
                                         head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_argmax(const void* x, int64_t* out, int64_t rows, int cols, int64_t row_stride, int dtype, void* stream) {
+  SGLK_CHECK(rows >= 0 && cols > 0 && row_stride >= cols, "argmax: bad shape");
+  if (rows == 0) return SGLK_OK;
+  SGLK_CHECK(x && out, "argmax: null pointer");
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((argmax_rows_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                         x, out, cols, row_stride));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -231,10 +231,8 @@ class LlamaDecoder:
     def prepare_for_decode(self):
         """schedule_batch.py:1464-1527: seq_lens += 1; out_cache_loc = the request's next free slot;
         req_to_token[req, seq_len - 1] = out_cache_loc.  All on device."""
-        self.positions.copy_(self.seq_lens)  # the new token's position = tokens cached so far
-        self.seq_lens.add_(1)
-        loc = self.req_to_token[self.req_pool_indices, self.positions]  # private slots are pre-assigned per request
-        self.out_cache_loc.copy_(loc)
+        # the new token's position = tokens cached so far; private slots are pre-assigned per request
+        ops.prepare_for_decode(self.req_to_token, self.req_pool_indices, self.seq_lens, self.positions, self.out_cache_loc)
 
     def enable_fusion(self, on: bool = True) -> bool:
         """Decoder-layer fusion (AWQ, 16-bit, head size 128, shapes the partial GEMM covers)."""
@@ -328,8 +326,7 @@ class LlamaDecoder:
             self._timed("down", lambda: ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, P, self.xs_act))
         ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])
         ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
-        torch.argmax(self.logits, dim=-1, out=self.next_ids)
-        self.input_ids.copy_(self.next_ids)
+        self._sample()
 
     def _xq(self, K):
         return self.x_q.view(-1)[: self.B * K].view(self.B, K)
@@ -440,7 +437,7 @@ class LlamaDecoder:
         """Greedy token over the (vocab-parallel) logits."""
         comm = getattr(self, "tp_comm", None)
         if comm is None:
-            torch.argmax(self.logits, dim=-1, out=self.next_ids)
+            ops.argmax(self.logits, self.next_ids)
         else:
             val, idx = torch.max(self.logits.float(), dim=-1)
             self.tp_best[:, self.tp_rank, 0] = val

@@ -76,6 +76,26 @@ def decode_metadata(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indi
         "decode_metadata")
 
 
+def prepare_for_decode(req_to_token, req_pool_indices, seq_lens, positions, out_cache_loc):
+    """positions = seq_lens; out_cache_loc = req_to_token[req_pool_indices, seq_lens]; seq_lens += 1 (one launch)."""
+    _need_gpu(req_to_token, req_pool_indices, seq_lens, positions, out_cache_loc)
+    if positions.dtype != torch.int64:
+        raise SglkError("prepare_for_decode: positions must be int64")
+    check(lib().sglk_prepare_for_decode(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices),
+                                        _is64(req_pool_indices), _ptr(seq_lens), _is64(seq_lens), _ptr(positions),
+                                        _ptr(out_cache_loc), _is64(out_cache_loc), seq_lens.shape[0], _stream(seq_lens)),
+          "prepare_for_decode")
+
+
+def argmax(x, out):
+    """out[r] = argmax(x[r]) (first maximum), int64."""
+    _need_gpu(x, out)
+    if x.dim() != 2 or x.stride(1) != 1 or out.dtype != torch.int64 or not out.is_contiguous():
+        raise SglkError("argmax: x must be [rows, cols] with unit inner stride, out contiguous int64")
+    check(lib().sglk_argmax(_ptr(x), _ptr(out), x.shape[0], x.shape[1], x.stride(0), dtype_code(x.dtype), _stream(x)),
+          "argmax")
+
+
 def common_prefix_len(req_to_token, req_pool_indices, seq_lens, out):
     _need_gpu(req_to_token, req_pool_indices, seq_lens, out)
     check(lib().sglk_common_prefix_len(_ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices),

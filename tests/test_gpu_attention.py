@@ -74,6 +74,59 @@ def test_num_kv_splits_golden():
         assert out.cpu().tolist() == c["expect"], c
 
 
+@pytest.mark.parametrize("bs,ctx", [(1, 7), (5, 300), (64, 1200), (200, 40)])
+@pytest.mark.parametrize("ldt", [torch.int64, torch.int32])
+def test_decode_metadata_one_launch_and_prepare(bs, ctx, ldt):
+    """sglk_decode_metadata (one launch) against the three separate entry points, bit for bit; prepare_for_decode
+    against the torch sequence of schedule_batch.py:1464-1527."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(bs + ctx)
+    lens = torch.randint(1, ctx + 1, (bs,), generator=g).to(ldt)
+    r2t = torch.randint(1, 1 << 20, (bs + 3, ctx + 8), generator=g, dtype=torch.int32).to(DEV)
+    pool_idx = torch.randperm(bs + 3, generator=g)[:bs].to(DEV)
+    lens_d = lens.to(DEV)
+    total = int(lens.sum())
+    ptr = torch.full((bs + 1,), -1, dtype=torch.int32, device=DEV)
+    ind = torch.full((total + 5,), -1, dtype=torch.int32, device=DEV)
+    ns = torch.full((bs,), -1, dtype=torch.int32, device=DEV)
+    ops.decode_metadata(r2t, pool_idx, lens_d, ptr, ind, ns, 32, 8, 8, 256)
+    ptr2 = torch.zeros_like(ptr)
+    ind2 = torch.full_like(ind, -1)
+    ns2 = torch.zeros_like(ns)
+    ops.kv_indptr_cumsum(lens_d, ptr2)
+    ops.get_num_kv_splits(ns2, lens_d, 32, 8, 8, 256)
+    ops.create_kv_indices(r2t, pool_idx, lens_d, ptr2, None, ind2)
+    assert torch.equal(ptr, ptr2) and torch.equal(ns, ns2) and torch.equal(ind, ind2)
+    # prepare_for_decode
+    pos = torch.empty(bs, dtype=torch.int64, device=DEV)
+    loc = torch.empty(bs, dtype=torch.int64, device=DEV)
+    want_loc = r2t[pool_idx, lens_d.long()].long()
+    lens_before = lens_d.clone()
+    ops.prepare_for_decode(r2t, pool_idx, lens_d, pos, loc)
+    assert torch.equal(pos, lens_before.long()) and torch.equal(lens_d, lens_before + 1) and torch.equal(loc, want_loc)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(64, 128256), (3, 1001), (1, 8), (7, 4096)])
+def test_argmax_rows(dtype, rows, cols):
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows + cols)
+    x = torch.randn(rows, cols, generator=g).to(dtype).to(DEV)
+    x[0, cols // 2] = 100.0
+    if cols > 4:
+        x[rows - 1, 3] = 50.0
+        x[rows - 1, cols - 1] = 50.0          # a tie: the first one wins
+    out = torch.empty(rows, dtype=torch.int64, device=DEV)
+    ops.argmax(x, out)
+    assert torch.equal(out, torch.argmax(x, dim=-1))
+    if cols > 4 and rows > 1:
+        assert int(out[rows - 1]) == 3
+    view = x[:, : cols - 1] if cols > 8 else x  # a row stride that is not the row length
+    out2 = torch.empty(rows, dtype=torch.int64, device=DEV)
+    ops.argmax(view, out2)
+    assert torch.equal(out2, torch.argmax(view, dim=-1))
+
+
 def _run_decode(ops, g, dtype, max_splits=8, splits=None):
     q = g["q"].to(dtype).to(DEV)
     kb, vb = g["k_buffer"].to(dtype).to(DEV), g["v_buffer"].to(dtype).to(DEV)
