@@ -548,7 +548,8 @@ ORACLE_API void oracle_allreduce_sum(const float* const* bufs, int world, float*
 /* ------------------------------------------------------------------------------------------------
  * MoE routing helpers.
  * moe_align_block_size: sgl-kernel/csrc/moe/moe_align_kernel.cu:43-100 (counts, padded prefix sums, expert id per
- * block) with the placement of :27-41 made deterministic: slots of one expert in order of appearance.
+ * block) with the placement of :27-41 made deterministic: slots of one expert in order of appearance (parity
+ * unpinned for that order: the reference's is whatever its atomics produce).
  * ------------------------------------------------------------------------------------------------ */
 void oracle_moe_align_block_size(const int64_t* topk_ids, int64_t numel, int num_experts, int block_size,
                                  int32_t* sorted_token_ids, int32_t* expert_ids, int32_t* num_tokens_post_pad) {
