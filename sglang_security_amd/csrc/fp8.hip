@@ -346,9 +346,11 @@ __device__ __forceinline__ void load32(const uint8_t* row, int k, int K, long (&
   r[3] = (long)(uint32_t)hi.z | ((long)hi.w << 32);
 }
 
-template <typename TO, int MT, bool BLOCKWISE, int FMT = 0>
-__global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
-  __shared__ float red[4][MT * 2][64][4];
+// NW waves split the block's K range (4, or 8 where the grid leaves CUs without a block)
+template <typename TO, int MT, bool BLOCKWISE, int FMT = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void fp8_mm_kernel(MmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float red_raw[];
+  float(*red)[MT * 2][64][4] = reinterpret_cast<float(*)[MT * 2][64][4]>(red_raw);  // [NW][MT * 2][64][4]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 16 * MT;
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
         }
       }
   };
-  for (int kb = kb_first; kb < kblocks; kb += 4) body(kb);
+  for (int kb = kb_first; kb < kblocks; kb += NW) body(kb);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -426,11 +428,11 @@ __global__ __launch_bounds__(256) void fp8_mm_kernel(MmArgs p) {
       *reinterpret_cast<f32x4*>(&red[w][i * 2 + j][lane][0]) = tot[i][j];
   __syncthreads();
   // wave w finishes tiles w, w+4, ...
-  for (int t = w; t < MT * 2; t += 4) {
+  for (int t = w; t < MT * 2; t += NW) {
     const int i = t >> 1, j = t & 1;
     f32x4 s = *reinterpret_cast<f32x4*>(&red[0][t][lane][0]);
 #pragma unroll
-    for (int ww = 1; ww < 4; ++ww) {
+    for (int ww = 1; ww < NW; ++ww) {
       const f32x4 o = *reinterpret_cast<f32x4*>(&red[ww][t][lane][0]);
       s += o;
     }
@@ -503,12 +505,20 @@ template <typename TO, bool BLOCKWISE, int FMT = 0>
 int launch_mm(const MmArgs& p, hipStream_t s, int batch = 1) {
   const dim3 block(256);
   const unsigned nb = (p.N + 31) / 32, z = (unsigned)batch;
+  auto lds = [](int mt, int nw) { return (size_t)nw * mt * 2 * 64 * 4 * sizeof(float); };
   if (p.M <= 16) {
-    hipLaunchKernelGGL((fp8_mm_kernel<TO, 1, BLOCKWISE, FMT>), dim3(nb, (p.M + 15) / 16, z), block, 0, s, p);
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 1, BLOCKWISE, FMT>), dim3(nb, (p.M + 15) / 16, z), block, lds(1, 4), s, p);
   } else if (p.M <= 32) {
-    hipLaunchKernelGGL((fp8_mm_kernel<TO, 2, BLOCKWISE, FMT>), dim3(nb, (p.M + 31) / 32, z), block, 0, s, p);
+    hipLaunchKernelGGL((fp8_mm_kernel<TO, 2, BLOCKWISE, FMT>), dim3(nb, (p.M + 31) / 32, z), block, lds(2, 4), s, p);
   } else {
-    hipLaunchKernelGGL((fp8_mm_kernel<TO, 4, BLOCKWISE, FMT>), dim3(nb, (p.M + 63) / 64, z), block, 0, s, p);
+    const unsigned mb = (p.M + 63) / 64;
+    const char* env = getenv("SGLK_FP8_WAVES");  // 4 / 8: forces the K-waves per block (tests, timing)
+    const int kblocks = (p.K + 127) / 128;
+    const bool eight = env ? atoi(env) == 8 : (nb * mb * z <= 256 && kblocks >= 32);
+    if (eight && FMT == 0)
+      hipLaunchKernelGGL((fp8_mm_kernel<TO, 4, BLOCKWISE, 0, 8>), dim3(nb, mb, z), dim3(512), lds(4, 8), s, p);
+    else
+      hipLaunchKernelGGL((fp8_mm_kernel<TO, 4, BLOCKWISE, FMT>), dim3(nb, mb, z), block, lds(4, 4), s, p);
   }
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
