@@ -16,8 +16,9 @@ cases = [("qkv", 8192, 1280, False), ("o", 1024, 8192, False), ("gate_up", 8192,
          ("block 7168x4608", 7168, 4608, True)]
 for name, K, N, block in cases:
     copies = max(2, int(600e6 // (K * N)) + 1)
-    a = (torch.randn(M, K, device=dev, generator=gen) * 0.5).to(F8)
-    ws = [(torch.randn(N, K, device=dev, generator=gen) * 0.5).to(F8) for _ in range(copies)]
+    pad_a, pad_b = int(os.environ.get("PAD_A", "0")), int(os.environ.get("PAD_B", "0"))  # row pitch experiments
+    a = (torch.randn(M, K + pad_a, device=dev, generator=gen) * 0.5).to(F8)[:, :K]
+    ws = [(torch.randn(N, K + pad_b, device=dev, generator=gen) * 0.5).to(F8)[:, :K] for _ in range(copies)]
     if block:
         # M-contiguous activation scales, as the reference's quantiser hands them to this product
         sa = (torch.rand(M, K // 128, device=dev, generator=gen) + 0.1).t().contiguous().t()
