@@ -114,26 +114,31 @@ struct BlockAttn {
         vr[i] = *reinterpret_cast<const int4v*>(vbase + row * v_stride_n + chunk * 8);
       }
     };
+    // One K / V fragment read from LDS feeds all NC column tiles of the wave.
     auto compute = [&](int t0, const char* kl, const char* vl) {
+      float4v sacc[NC][2];
+#pragma unroll
+      for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) sacc[c][hh] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
+#pragma unroll
+          for (int c = 0; c < NC; ++c) sacc[c][hh] = Mfma16<T>::mma(kf, qf[c][ks], sacc[c][hh]);
+        }
+      short8 pf[NC];  // P^T operands: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
-        float4v sacc[2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
-            sacc[hh] = Mfma16<T>::mma(kf, qf[c][ks], sacc[hh]);
-          }
-        }
         float sv[8];
         float tmax = -INFINITY;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            float s = sacc[hh][r] * qk_scale;
+            float s = sacc[c][hh][r] * qk_scale;
             if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
             const int tok = t0 + 16 * hh + 4 * g + r;
             bool ok = tok < t_end;
@@ -149,24 +154,24 @@ struct BlockAttn {
         const float alpha = exp2f(m[c] - m_use);
         m[c] = m_new;
         float psum = 0.f;
-        short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float p = exp2f(sv[j] - m_use);
           psum += p;
-          pf[j] = (short)Conv<T>::from_f32(p);
+          pf[c][j] = (short)Conv<T>::from_f32(p);
         }
         lsum[c] = lsum[c] * alpha + psum;
 #pragma unroll
         for (int n = 0; n < 8; ++n) oacc[c][n] *= alpha;
+      }
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          const int byte_in_row = 32 * n + 8 * (hl & 3);
-          const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
-          const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
-          const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          oacc[c][n] = Mfma16<T>::mma(vf, pf, oacc[c][n]);
-        }
+      for (int n = 0; n < 8; ++n) {
+        const int byte_in_row = 32 * n + 8 * (hl & 3);
+        const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
+        const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
+        const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) oacc[c][n] = Mfma16<T>::mma(vf, pf[c], oacc[c][n]);
       }
     };
 
