@@ -219,7 +219,18 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                     mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && mult8(k_stride_n) &&
                     mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h) && o_stride_t % 4 == 0 &&
                     o_stride_h % 4 == 0;
-  if (fast) {
+  // One column tile per wave (64 query rows per block) keeps the kernel at two blocks per CU; two tiles per wave
+  // halve the K/V re-reads but run at one wave per SIMD and measured 25 % slower (SGLK_EXTEND_NC=2 selects them).
+  const char* env_nc = getenv("SGLK_EXTEND_NC");
+  if (fast && !(env_nc && atoi(env_nc) == 2)) {
+    dim3 grid((max_extend_len + 63) / 64, Hq, B);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((extend_attention_mfma128<T, 1>), grid, dim3(256), kBlockAttnLds, s,
+                                          q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
+                                          kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h, ke_stride_t,
+                                          ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal));
+  } else if (fast) {
     dim3 grid((max_extend_len + 64 * kNC - 1) / (64 * kNC), Hq, B);
     SGLK_DISPATCH_HALF(dtype, T,
                        hipLaunchKernelGGL((extend_attention_mfma128<T, kNC>), grid, dim3(256), kBlockAttnLds, s,
