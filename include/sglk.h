@@ -402,6 +402,30 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm_ws(const void* a, const void* b_nk, co
                                              int64_t sb_stride_n, int64_t sb_stride_k, void* workspace,
                                              int64_t workspace_bytes, int out_dtype, void* stream);
 
+/* ------------------------------------------------------------------ sampling filters ---------- */
+
+/* probs fp32 [batch, vocab] (rows sum to 1).  Keep the top_k largest entries of every row (ties with the k-th kept)
+ * and renormalise: top_k_renorm_probs, sgl-kernel/python/sgl_kernel/sampling.py:21-52.  top_k_arr (int32 [batch]) or,
+ * when null, top_k_val for every row. */
+SGLK_API int sglk_top_k_renorm_probs(const float* probs, float* out, const int32_t* top_k_arr,
+                                     int top_k_val, int batch, int vocab, int64_t in_stride,
+                                     int64_t out_stride, void* stream);
+/* Drop the longest ascending run of entries whose cumulative mass stays below 1 - top_p, renormalise the rest:
+ * top_p_renorm_probs, sampling.py:69-102. */
+SGLK_API int sglk_top_p_renorm_probs(const float* probs, float* out, const float* top_p_arr,
+                                     float top_p_val, int batch, int vocab, int64_t in_stride,
+                                     int64_t out_stride, void* stream);
+/* One token per row from the filtered distribution by inverse CDF in index order with the caller's uniform numbers
+ * (fp32 [batch] in [0, 1)): top_p_sampling_from_probs / top_k_top_p_sampling_from_probs / min_p_sampling_from_probs,
+ * sampling.py:131-330.  A filter is off when its value is out of range (top_k <= 0 or >= vocab, top_p >= 1,
+ * min_p <= 0); joint != 0 applies top-k and top-p to the original distribution ("joint"), 0 applies top-p to the
+ * top-k-renormalised one ("top_k_first").  out int32 [batch]. */
+SGLK_API int sglk_sampling_from_probs(const float* probs, const float* uniform, int32_t* out,
+                                      const int32_t* top_k_arr, int top_k_val,
+                                      const float* top_p_arr, float top_p_val,
+                                      const float* min_p_arr, float min_p_val, int joint, int batch,
+                                      int vocab, int64_t in_stride, void* stream);
+
 /* ------------------------------------------------------------------ C1: custom all-reduce ----- */
 
 /* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.

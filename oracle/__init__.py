@@ -282,3 +282,40 @@ def bmm_fp8(A, B, A_scale, B_scale, dtype):
     b = B.detach().cpu().to(torch.float32)
     out = torch.bmm(a, b) * float(A_scale) * float(B_scale)
     return out.to(dtype)
+
+
+# ---------------------------------------------------------------------------------------------- sampling filters
+def top_k_mask(probs, k):
+    """Entries >= the k-th largest of their row (sgl-kernel/tests/test_sampling.py:85-88)."""
+    p = probs.detach().cpu().double()
+    pivot = torch.sort(p, descending=True).values[:, k - 1]
+    return p >= pivot.unsqueeze(-1)
+
+
+def top_p_mask(probs, top_p, eps=0.0):
+    """Entries whose ascending cumulative sum reaches 1 - top_p (test_sampling.py:55-60; eps as in :23-27)."""
+    p = probs.detach().cpu().double()
+    sp, idx = torch.sort(p, descending=False)
+    cdf = torch.cumsum(sp, dim=-1)
+    mask = torch.zeros_like(p, dtype=torch.bool)
+    mask.scatter_(1, idx, cdf >= (1 - top_p) - eps)
+    return mask
+
+
+def min_p_mask(probs, min_p):
+    """Entries >= min_p * the row maximum (test_sampling.py:108-116)."""
+    p = probs.detach().cpu().float()
+    return p >= (min_p * p.max(dim=-1, keepdim=True).values)
+
+
+def renorm(probs, mask):
+    p = probs.detach().cpu().double() * mask
+    return (p / p.sum(dim=-1, keepdim=True)).float()
+
+
+def sample_from_mask(probs, mask, uniform):
+    """First kept index (in index order) whose running sum exceeds u * total, in float64."""
+    p = probs.detach().cpu().double() * mask
+    cum = torch.cumsum(p, dim=-1)
+    target = uniform.detach().cpu().double().unsqueeze(-1) * cum[:, -1:]
+    return (cum > target).float().argmax(dim=-1).int()

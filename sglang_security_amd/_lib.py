@@ -28,6 +28,9 @@ _SIGS = {
     "sglk_decode_metadata": (i32, [p, i64, p, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, p]),
     "sglk_decode_attention": (i32, [p, p, p, p, p, p, p, p, p, i32, i32, i32, i32, i32, i32,
                                     i64, i64, i64, i64, i64, i64, i64, i64, f32, f32, i32, p]),
+    "sglk_top_k_renorm_probs": (i32, [p, p, p, i32, i32, i32, i64, i64, p]),
+    "sglk_top_p_renorm_probs": (i32, [p, p, p, f32, i32, i32, i64, i64, p]),
+    "sglk_sampling_from_probs": (i32, [p, p, p, p, i32, p, f32, p, f32, i32, i32, i32, i64, p]),
     "sglk_prepare_for_decode": (i32, [p, i64, p, i32, p, i32, p, p, i32, i32, p]),
     "sglk_argmax": (i32, [p, p, i64, i32, i64, i32, p]),
     "sglk_decode_shared_workspace_bytes": (i64, [i32, i32, i32, i32]),

@@ -694,3 +694,56 @@ def prefill_attention_paged(q, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_i
         q.stride(0), q.stride(1), o.stride(0), o.stride(1), kb.stride(0), kb.stride(1), vb.stride(0), vb.stride(1),
         int(max_q_len), float(sm_scale), float(logit_cap), 1 if causal else 0, dtype_code(q.dtype), _stream(q)),
         "prefill_attention_paged")
+
+
+# ---- sampling filters ---------------------------------------------------------------------------------------
+def _probs2d(probs, name):
+    _need_gpu(probs)
+    if probs.dim() != 2 or probs.dtype != torch.float32 or probs.stride(1) != 1:
+        raise SglkError(f"{name}: probs must be float32 [batch, vocab] with unit inner stride")
+    return probs.shape
+
+
+def _per_row(v, batch, dtype, name):
+    """(tensor or None, scalar): a per-row tensor of the right dtype on the device, or the scalar for every row."""
+    if isinstance(v, torch.Tensor):
+        _need_gpu(v)
+        t = v.to(dtype).contiguous()
+        if t.numel() != batch:
+            raise SglkError(f"{name}: per-row values must have batch elements")
+        return t, 0
+    return None, v
+
+
+def top_k_renorm_probs(probs, top_k):
+    B, V = _probs2d(probs, "top_k_renorm_probs")
+    arr, val = _per_row(top_k, B, torch.int32, "top_k_renorm_probs")
+    out = torch.empty_like(probs)
+    check(lib().sglk_top_k_renorm_probs(_ptr(probs), _ptr(out), _ptr(arr), int(val), B, V, probs.stride(0), out.stride(0),
+                                        _stream(probs)), "top_k_renorm_probs")
+    return out
+
+
+def top_p_renorm_probs(probs, top_p):
+    B, V = _probs2d(probs, "top_p_renorm_probs")
+    arr, val = _per_row(top_p, B, torch.float32, "top_p_renorm_probs")
+    out = torch.empty_like(probs)
+    check(lib().sglk_top_p_renorm_probs(_ptr(probs), _ptr(out), _ptr(arr), float(val), B, V, probs.stride(0),
+                                        out.stride(0), _stream(probs)), "top_p_renorm_probs")
+    return out
+
+
+def sampling_from_probs(probs, uniform, top_k=0, top_p=1.0, min_p=0.0, joint=True):
+    """int32 [batch] samples; uniform float32 [batch] in [0, 1)."""
+    B, V = _probs2d(probs, "sampling_from_probs")
+    _need_gpu(uniform)
+    if uniform.dtype != torch.float32 or uniform.numel() != B or not uniform.is_contiguous():
+        raise SglkError("sampling_from_probs: uniform must be contiguous float32 [batch]")
+    ka, kv = _per_row(top_k, B, torch.int32, "sampling_from_probs")
+    pa, pv = _per_row(top_p, B, torch.float32, "sampling_from_probs")
+    ma, mv = _per_row(min_p, B, torch.float32, "sampling_from_probs")
+    out = torch.empty(B, dtype=torch.int32, device=probs.device)
+    check(lib().sglk_sampling_from_probs(_ptr(probs), _ptr(uniform), _ptr(out), _ptr(ka), int(kv), _ptr(pa), float(pv),
+                                         _ptr(ma), float(mv), 1 if joint else 0, B, V, probs.stride(0), _stream(probs)),
+          "sampling_from_probs")
+    return out

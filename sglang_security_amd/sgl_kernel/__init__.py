@@ -22,7 +22,9 @@ __all__ = [
     "rmsnorm", "fused_add_rmsnorm", "gemma_rmsnorm", "gemma_fused_add_rmsnorm", "silu_and_mul", "gelu_tanh_and_mul",
     "gelu_and_mul", "apply_rope_with_cos_sin_cache_inplace", "awq_dequantize", "fp8_scaled_mm",
     "fp8_blockwise_scaled_mm", "bmm_fp8", "sgl_per_token_quant_fp8", "sgl_per_token_group_quant_fp8",
-    "sgl_per_tensor_quant_fp8", "moe_align_block_size", "topk_softmax", "merge_state", "merge_state_v2", "install",
+    "sgl_per_tensor_quant_fp8", "moe_align_block_size", "topk_softmax", "top_k_renorm_probs", "top_k_renorm_prob",
+    "top_p_renorm_probs", "top_p_renorm_prob", "top_p_sampling_from_probs", "top_k_top_p_sampling_from_probs",
+    "min_p_sampling_from_probs", "merge_state", "merge_state_v2", "install",
 ]
 
 
@@ -118,6 +120,55 @@ def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype):
 def bmm_fp8(A, B, A_scale, B_scale, dtype, out=None):
     """gemm.py:66-82."""
     return _ops.bmm_fp8(A, B, A_scale, B_scale, dtype, out)
+
+
+# ---- sampling.py ----------------------------------------------------------------------------------------------
+def top_k_renorm_probs(probs: torch.Tensor, top_k) -> torch.Tensor:
+    """sampling.py:21-52."""
+    return _ops.top_k_renorm_probs(probs, top_k)
+
+
+top_k_renorm_prob = top_k_renorm_probs  # sampling.py:52
+
+
+def top_p_renorm_probs(probs: torch.Tensor, top_p) -> torch.Tensor:
+    """sampling.py:69-102."""
+    return _ops.top_p_renorm_probs(probs, top_p)
+
+
+top_p_renorm_prob = top_p_renorm_probs  # sampling.py:102
+
+
+def _uniform(probs, generator):
+    return torch.rand(probs.shape[0], dtype=torch.float32, device=probs.device, generator=generator)
+
+
+def top_p_sampling_from_probs(probs, top_p, indices=None, deterministic=True, generator=None, check_nan=False):
+    """sampling.py:131-185 (indices: rows of probs to sample from, one per output)."""
+    if check_nan and torch.any(torch.isnan(probs)):
+        raise ValueError("Input probs contains NaN.")
+    src = probs if indices is None else probs[indices.long()]
+    return _ops.sampling_from_probs(src, _uniform(src, generator), 0, top_p, 0.0, True)
+
+
+def top_k_top_p_sampling_from_probs(probs, top_k, top_p, indices=None, filter_apply_order="top_k_first",
+                                    deterministic=True, generator=None, check_nan=False):
+    """sampling.py:219-300: "top_k_first" renormalises after top-k and then cuts by top-p, "joint" applies both
+    filters to the original distribution."""
+    if filter_apply_order not in ("top_k_first", "joint"):
+        raise ValueError(f"Invalid filter_apply_order: {filter_apply_order}")
+    if check_nan and torch.any(torch.isnan(probs)):
+        raise ValueError("Input probs contains NaN.")
+    src = probs if indices is None else probs[indices.long()]
+    return _ops.sampling_from_probs(src, _uniform(src, generator), top_k, top_p, 0.0, filter_apply_order == "joint")
+
+
+def min_p_sampling_from_probs(probs, min_p, indices=None, deterministic=True, generator=None, check_nan=False):
+    """sampling.py:303-360."""
+    if check_nan and torch.any(torch.isnan(probs)):
+        raise ValueError("Input probs contains NaN.")
+    src = probs if indices is None else probs[indices.long()]
+    return _ops.sampling_from_probs(src, _uniform(src, generator), 0, 1.0, min_p, True)
 
 
 # ---- moe.py -------------------------------------------------------------------------------------------------
