@@ -426,6 +426,44 @@ SGLK_API int sglk_sampling_from_probs(const float* probs, const float* uniform, 
                                       const float* min_p_arr, float min_p_val, int joint, int batch,
                                       int vocab, int64_t in_stride, void* stream);
 
+/* ------------------------------------------------------------------ draft-tree helpers -------- */
+
+/* Layout of the draft trees of a batch: build_tree_kernel_efficient,
+ * sgl-kernel/csrc/speculative/eagle_utils.cu:32-147.  parent_list int64 [bs, topk * (depth - 1) + 1],
+ * selected_index int64 [bs, n - 1] (n = draft_token_num), verified_seq_len int32 [bs]; outputs: tree_mask bool
+ * (1 byte) [sum(seq_len) * n + bs * n * n] (caller-filled with true; the tree part of every row is rewritten),
+ * positions int64 [bs * n], retrive_index / retrive_next_token / retrive_next_sibling int64 [bs, n] (caller-filled
+ * with -1; entries without a child / sibling are left untouched).  A token whose parent is not among the selected
+ * ones (the reference prints a warning and skips it) gets no links and masks only itself.  tree_mask_len = entries
+ * of tree_mask; a request whose rows would not fit writes nothing. */
+SGLK_API int sglk_build_tree_efficient(const int64_t* parent_list, const int64_t* selected_index,
+                                       const int32_t* verified_seq_len, uint8_t* tree_mask,
+                                       int64_t* positions, int64_t* retrive_index,
+                                       int64_t* retrive_next_token, int64_t* retrive_next_sibling,
+                                       int topk, int depth, int draft_token_num, int bs,
+                                       int64_t tree_mask_len, void* stream);
+/* Greedy verification of the trees against the target model's picks: verify_tree_greedy, eagle_utils.cu:150-286.
+ * All int32; predicts [total draft tokens], accept_index [bs, num_spec_step], accept_token_num [bs],
+ * candidates / retrive_* / target_predict [bs, num_draft_tokens] (target_predict addressed by flat retrive index);
+ * total_draft_tokens = entries of predicts (= of target_predict).  Link or index values outside their range end the
+ * walk of that request (the reference reads through them). */
+SGLK_API int sglk_verify_tree_greedy(int32_t* predicts, int32_t* accept_index, int32_t* accept_token_num,
+                                     const int32_t* candidates, const int32_t* retrive_index,
+                                     const int32_t* retrive_next_token,
+                                     const int32_t* retrive_next_sibling, const int32_t* target_predict,
+                                     int bs, int num_spec_step, int num_draft_tokens,
+                                     int total_draft_tokens, void* stream);
+/* Target-only speculative sampling over the trees: tree_speculative_sampling_target_only,
+ * sgl-kernel/csrc/speculative/speculative_sampling.cuh:38-157 (threshold_acc is floored at 1e-9 as at :185).
+ * uniform_samples fp32 [bs, num_draft_tokens], target_probs / draft_probs fp32 [bs, num_draft_tokens, vocab];
+ * draft_probs receives the target probability of every rejected candidate. */
+SGLK_API int sglk_tree_speculative_sampling_target_only(
+    int32_t* predicts, int32_t* accept_index, int32_t* accept_token_num, const int32_t* candidates,
+    const int32_t* retrive_index, const int32_t* retrive_next_token, const int32_t* retrive_next_sibling,
+    const float* uniform_samples, const float* target_probs, float* draft_probs, int bs, int num_spec_step,
+    int num_draft_tokens, int total_draft_tokens, int vocab, float threshold_single, float threshold_acc,
+    void* stream);
+
 /* ------------------------------------------------------------------ C1: custom all-reduce ----- */
 
 /* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.

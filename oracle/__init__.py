@@ -319,3 +319,154 @@ def sample_from_mask(probs, mask, uniform):
     cum = torch.cumsum(p, dim=-1)
     target = uniform.detach().cpu().double().unsqueeze(-1) * cum[:, -1:]
     return (cum > target).float().argmax(dim=-1).int()
+
+
+# ---------------------------------------------------------------------------------------------- draft-tree helpers
+def build_tree_preprocess(verified_id, score_list, token_list, parents_list, num_verify_tokens):
+    """Selection of the draft tokens from the per-step scores (speculative/build_eagle_tree.py:15-40)."""
+    scores = torch.cat(score_list, dim=1).flatten(1)
+    tokens = torch.cat(token_list, dim=1)
+    top = torch.sort(torch.topk(scores, num_verify_tokens - 1, dim=-1).indices).values
+    draft = torch.cat((verified_id.unsqueeze(1), torch.gather(tokens, index=top, dim=1)), dim=1).flatten()
+    if len(parents_list) > 1:
+        parent_list = torch.cat(parents_list[:-1], dim=1)
+    else:
+        parent_list = torch.empty(parents_list[0].shape[0], 0, dtype=torch.int64)
+    return parent_list, top, draft
+
+
+def build_tree_efficient(parent_list, selected_index, verified_seq_len, topk, depth, n):
+    """Serial restatement of build_tree_efficient (sgl-kernel/csrc/speculative/eagle_utils.cu:32-114) on lists.
+    Returns tree_mask (flat list of bool, initialised True as the caller does, build_eagle_tree.py:70-77), positions,
+    retrive_index, retrive_next_token, retrive_next_sibling (the latter three initialised -1, :78-86).  A token without
+    a selected parent is skipped for the links (:79-84) and masks only itself."""
+    pl = parent_list.tolist()
+    si = selected_index.tolist()
+    sl = [int(v) for v in verified_seq_len.tolist()]
+    bs = len(si)
+    mask = [True] * (sum(sl) * n + n * n * bs)
+    positions = [0] * (bs * n)
+    ridx = [[-1] * n for _ in range(bs)]
+    nxt = [[-1] * n for _ in range(bs)]
+    sib = [[-1] * n for _ in range(bs)]
+    for b in range(bs):
+        base = n * n * b + sum(sl[:b]) * n
+        seq = sl[b]
+
+        def parent_slot(i):                       # slot (1-based token) of the parent of token i, 0 = root, None = orphan
+            row = si[b][i - 1] // topk
+            if row == 0:
+                return 0
+            want = pl[b][row]
+            for j in range(n - 1):
+                if si[b][j] == want:
+                    return j + 1
+            return None
+
+        for t in range(n):
+            off = base + (seq + n) * t + seq + 1
+            for i in range(n - 1):
+                mask[off + i] = False
+            level, cur = 0, t
+            while cur:
+                mask[off + cur - 1] = True
+                level += 1
+                cur = parent_slot(cur)
+                if cur is None:
+                    break
+            positions[b * n + t] = seq + level
+        for i in range(n - 1, 0, -1):
+            ridx[b][i] = b * n + i
+            p = parent_slot(i)
+            if p is None:
+                continue
+            if nxt[b][p] == -1:
+                nxt[b][p] = i
+            else:
+                sib[b][i] = nxt[b][p]
+                nxt[b][p] = i
+        ridx[b][0] = b * n
+    return mask, positions, ridx, nxt, sib
+
+
+def verify_tree_greedy(candidates, retrive_index, retrive_next_token, retrive_next_sibling, target_predict, num_spec):
+    """VerifyTreeGreedy (eagle_utils.cu:150-191) on lists; predicts / accept_index start at -1 as in the reference's
+    test (sgl-kernel/tests/speculative/test_eagle_utils.py:59-65)."""
+    cand, ridx = candidates.tolist(), retrive_index.tolist()
+    nxt, sib = retrive_next_token.tolist(), retrive_next_sibling.tolist()
+    tp = target_predict.flatten().tolist()
+    bs, n = len(cand), len(cand[0])
+    predicts = [-1] * (bs * n)
+    accept_index = [[-1] * num_spec for _ in range(bs)]
+    accept_num = [0] * bs
+    for b in range(bs):
+        last = ridx[b][0]
+        accept_index[b][0] = last
+        acc, cur = 0, 0
+        for _ in range(1, num_spec):
+            cur = nxt[b][cur]
+            while cur != -1:
+                if cand[b][cur] == tp[last]:
+                    predicts[last] = tp[last]
+                    acc += 1
+                    accept_index[b][acc] = ridx[b][cur]
+                    last = ridx[b][cur]
+                    break
+                cur = sib[b][cur]
+            if cur == -1:
+                break
+        accept_num[b] = acc
+        predicts[last] = tp[last]
+    return predicts, accept_index, accept_num
+
+
+def tree_speculative_sampling_target_only(candidates, retrive_index, retrive_next_token, retrive_next_sibling, coins,
+                                          target_probs, draft_probs, num_spec, threshold_single=1.0, threshold_acc=1.0):
+    """TreeSpeculativeSamplingTargetOnly (sgl-kernel/csrc/speculative/speculative_sampling.cuh:38-157), float32 for the
+    acceptance test as the kernel, float64 running sum for the final inverse-CDF draw.  draft_probs is updated in place."""
+    import numpy as np
+    cand, ridx = candidates.tolist(), retrive_index.tolist()
+    nxt, sib = retrive_next_token.tolist(), retrive_next_sibling.tolist()
+    bs, n = len(cand), len(cand[0])
+    d = target_probs.shape[-1]
+    q = target_probs.reshape(bs * n, d).numpy()
+    p = draft_probs.reshape(bs * n, d).numpy()
+    u = coins.numpy().astype(np.float32)
+    t_acc = np.float32(max(threshold_acc, 1e-9))
+    t_single = np.float32(threshold_single)
+    predicts = [-1] * (bs * n)
+    accept_index = [[-1] * num_spec for _ in range(bs)]
+    accept_num = [0] * bs
+    for b in range(bs):
+        acc = np.float32(0)
+        rowq = b * n
+        coin = u[b, 0]
+        last = ridx[b][0]
+        accept_index[b][0] = last
+        k, cur = 0, 0
+        for _ in range(1, num_spec):
+            cur = nxt[b][cur]
+            while cur != -1:
+                tok = cand[b][cur]
+                pt = q[rowq, tok]
+                acc = np.float32(acc + pt)
+                if coin <= np.float32(acc / t_acc) or pt >= t_single:
+                    acc = np.float32(0)
+                    rowq = b * n + cur
+                    coin = u[b, cur]
+                    predicts[last] = tok
+                    k += 1
+                    accept_index[b][k] = ridx[b][cur]
+                    last = ridx[b][cur]
+                    break
+                p[rowq, tok] = pt
+                cur = sib[b][cur]
+            if cur == -1:
+                break
+        accept_num[b] = k
+        rest = q[rowq].astype(np.float64) - (0 if k == num_spec - 1 else p[rowq].astype(np.float64))
+        rest = np.maximum(rest, 0)
+        cum = np.cumsum(rest)
+        hit = np.nonzero((cum > np.float64(coin) * cum[-1]) & (rest > 0))[0]
+        predicts[last] = int(hit[0]) if hit.size else d - 1
+    return predicts, accept_index, accept_num

@@ -747,3 +747,93 @@ def sampling_from_probs(probs, uniform, top_k=0, top_p=1.0, min_p=0.0, joint=Tru
                                          _ptr(ma), float(mv), 1 if joint else 0, B, V, probs.stride(0), _stream(probs)),
           "sampling_from_probs")
     return out
+
+
+# ------------------------------------------------------------------------------------------ draft-tree helpers
+def _typed(t, dtype, shape_len, name, what):
+    _need_gpu(t)
+    if t.dtype != dtype or t.dim() != shape_len or not t.is_contiguous():
+        raise SglkError(f"{name}: {what} must be a contiguous {dtype} tensor of {shape_len} dimension(s)")
+
+
+def build_tree_kernel_efficient(parent_list, selected_index, verified_seq_len, tree_mask, positions, retrive_index,
+                                retrive_next_token, retrive_next_sibling, topk, depth, draft_token_num):
+    """In place, arguments as sgl_kernel.build_tree_kernel_efficient (sgl-kernel/python/sgl_kernel/speculative.py:61-86)."""
+    name = "build_tree_kernel_efficient"
+    bs = selected_index.shape[0]
+    n = int(draft_token_num)
+    _typed(selected_index, torch.int64, 2, name, "selected_index")
+    _typed(verified_seq_len, torch.int32, 1, name, "verified_seq_len")
+    _typed(tree_mask, torch.bool, 1, name, "tree_mask")
+    _typed(positions, torch.int64, 1, name, "positions")
+    for t, what in ((retrive_index, "retrive_index"), (retrive_next_token, "retrive_next_token"),
+                    (retrive_next_sibling, "retrive_next_sibling")):
+        _typed(t, torch.int64, 2, name, what)
+        if tuple(t.shape) != (bs, n):
+            raise SglkError(f"{name}: {what} must be [bs, draft_token_num]")
+    if selected_index.shape[1] != n - 1 or verified_seq_len.numel() != bs or positions.numel() != bs * n:
+        raise SglkError(f"{name}: selected_index [bs, n - 1], verified_seq_len [bs], positions [bs * n] expected")
+    pitch = int(topk) * (int(depth) - 1) + 1
+    if int(depth) > 1:
+        _typed(parent_list, torch.int64, 2, name, "parent_list")
+        if tuple(parent_list.shape) != (bs, pitch):
+            raise SglkError(f"{name}: parent_list must be [bs, topk * (depth - 1) + 1]")
+    if tree_mask.numel() < bs * n * n:
+        raise SglkError(f"{name}: tree_mask holds {tree_mask.numel()} entries, at least bs * n * n needed")
+    check(lib().sglk_build_tree_efficient(_ptr(parent_list) if int(depth) > 1 else None, _ptr(selected_index),
+                                          _ptr(verified_seq_len), _ptr(tree_mask), _ptr(positions), _ptr(retrive_index),
+                                          _ptr(retrive_next_token), _ptr(retrive_next_sibling), int(topk), int(depth), n,
+                                          bs, tree_mask.numel(), _stream(selected_index)), name)
+
+
+def _tree_walk_args(name, predicts, accept_index, accept_token_num, candidates, retrive_index, retrive_next_token,
+                    retrive_next_sibling):
+    _typed(predicts, torch.int32, 1, name, "predicts")
+    _typed(accept_index, torch.int32, 2, name, "accept_index")
+    _typed(accept_token_num, torch.int32, 1, name, "accept_token_num")
+    _typed(candidates, torch.int32, 2, name, "candidates")
+    bs, n = candidates.shape
+    for t, what in ((retrive_index, "retrive_index"), (retrive_next_token, "retrive_next_token"),
+                    (retrive_next_sibling, "retrive_next_sibling")):
+        _typed(t, torch.int32, 2, name, what)
+        if tuple(t.shape) != (bs, n):
+            raise SglkError(f"{name}: {what} must match candidates [bs, num_draft_tokens]")
+    if accept_index.shape[0] != bs or accept_token_num.shape[0] != bs:
+        raise SglkError(f"{name}: accept_index / accept_token_num must have bs rows")
+    return bs, n, accept_index.shape[1]
+
+
+def verify_tree_greedy(predicts, accept_index, accept_token_num, candidates, retrive_index, retrive_next_token,
+                       retrive_next_sibling, target_predict):
+    """In place, arguments as sgl_kernel.verify_tree_greedy (speculative.py:38-58)."""
+    name = "verify_tree_greedy"
+    bs, n, steps = _tree_walk_args(name, predicts, accept_index, accept_token_num, candidates, retrive_index,
+                                   retrive_next_token, retrive_next_sibling)
+    _typed(target_predict, torch.int32, 2, name, "target_predict")
+    if tuple(target_predict.shape) != (bs, n) or predicts.numel() != bs * n:
+        raise SglkError(f"{name}: target_predict must be [bs, num_draft_tokens] and predicts hold bs * num_draft_tokens")
+    check(lib().sglk_verify_tree_greedy(_ptr(predicts), _ptr(accept_index), _ptr(accept_token_num), _ptr(candidates),
+                                        _ptr(retrive_index), _ptr(retrive_next_token), _ptr(retrive_next_sibling),
+                                        _ptr(target_predict), bs, steps, n, predicts.numel(), _stream(candidates)), name)
+
+
+def tree_speculative_sampling_target_only(predicts, accept_index, accept_token_num, candidates, retrive_index,
+                                          retrive_next_token, retrive_next_sibling, uniform_samples, target_probs,
+                                          draft_probs, threshold_single=1.0, threshold_acc=1.0, deterministic=True):
+    """In place, arguments as sgl_kernel.tree_speculative_sampling_target_only (speculative.py:5-35); the kernel is
+    deterministic in its inputs either way."""
+    name = "tree_speculative_sampling_target_only"
+    bs, n, steps = _tree_walk_args(name, predicts, accept_index, accept_token_num, candidates, retrive_index,
+                                   retrive_next_token, retrive_next_sibling)
+    _typed(uniform_samples, torch.float32, 2, name, "uniform_samples")
+    _typed(target_probs, torch.float32, 3, name, "target_probs")
+    _typed(draft_probs, torch.float32, 3, name, "draft_probs")
+    if tuple(uniform_samples.shape) != (bs, n) or target_probs.shape[:2] != (bs, n) or draft_probs.shape != target_probs.shape:
+        raise SglkError(f"{name}: uniform_samples [bs, n], target_probs / draft_probs [bs, n, vocab] expected")
+    vocab = target_probs.shape[2]
+    if predicts.numel() != bs * n:
+        raise SglkError(f"{name}: predicts must hold bs * num_draft_tokens entries")
+    check(lib().sglk_tree_speculative_sampling_target_only(
+        _ptr(predicts), _ptr(accept_index), _ptr(accept_token_num), _ptr(candidates), _ptr(retrive_index),
+        _ptr(retrive_next_token), _ptr(retrive_next_sibling), _ptr(uniform_samples), _ptr(target_probs), _ptr(draft_probs),
+        bs, steps, n, predicts.numel(), vocab, float(threshold_single), float(threshold_acc), _stream(candidates)), name)

@@ -24,7 +24,8 @@ __all__ = [
     "fp8_blockwise_scaled_mm", "bmm_fp8", "sgl_per_token_quant_fp8", "sgl_per_token_group_quant_fp8",
     "sgl_per_tensor_quant_fp8", "moe_align_block_size", "topk_softmax", "top_k_renorm_probs", "top_k_renorm_prob",
     "top_p_renorm_probs", "top_p_renorm_prob", "top_p_sampling_from_probs", "top_k_top_p_sampling_from_probs",
-    "min_p_sampling_from_probs", "merge_state", "merge_state_v2", "install",
+    "min_p_sampling_from_probs", "build_tree_kernel_efficient", "verify_tree_greedy",
+    "tree_speculative_sampling_target_only", "merge_state", "merge_state_v2", "install",
 ]
 
 
@@ -169,6 +170,31 @@ def min_p_sampling_from_probs(probs, min_p, indices=None, deterministic=True, ge
         raise ValueError("Input probs contains NaN.")
     src = probs if indices is None else probs[indices.long()]
     return _ops.sampling_from_probs(src, _uniform(src, generator), 0, 1.0, min_p, True)
+
+
+# ---- speculative.py ------------------------------------------------------------------------------------------
+def build_tree_kernel_efficient(parent_list, selected_index, verified_seq_len, tree_mask, positions, retrive_index,
+                                retrive_next_token, retrive_next_sibling, topk, depth, draft_token_num) -> None:
+    """speculative.py:61-86."""
+    _ops.build_tree_kernel_efficient(parent_list, selected_index, verified_seq_len, tree_mask, positions, retrive_index,
+                                     retrive_next_token, retrive_next_sibling, topk, depth, draft_token_num)
+
+
+def verify_tree_greedy(predicts, accept_index, accept_token_num, candidates, retrive_index, retrive_next_token,
+                       retrive_next_sibling, target_predict) -> None:
+    """speculative.py:38-58."""
+    _ops.verify_tree_greedy(predicts, accept_index, accept_token_num, candidates, retrive_index, retrive_next_token,
+                            retrive_next_sibling, target_predict)
+
+
+def tree_speculative_sampling_target_only(predicts, accept_index, accept_token_num, candidates, retrive_index,
+                                          retrive_next_token, retrive_next_sibling, uniform_samples, target_probs,
+                                          draft_probs, threshold_single: float = 1.0, threshold_acc: float = 1.0,
+                                          deterministic: bool = True) -> None:
+    """speculative.py:5-35."""
+    _ops.tree_speculative_sampling_target_only(predicts, accept_index, accept_token_num, candidates, retrive_index,
+                                               retrive_next_token, retrive_next_sibling, uniform_samples, target_probs,
+                                               draft_probs, threshold_single, threshold_acc, deterministic)
 
 
 # ---- moe.py -------------------------------------------------------------------------------------------------

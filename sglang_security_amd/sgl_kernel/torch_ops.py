@@ -1,5 +1,5 @@
 """`torch.ops.sgl_kernel.*` registrations for the hot-path ops, with the reference's schemas
-(sgl-kernel/csrc/common_extension.cc:48-121; the reference registers them from C++ with TORCH_LIBRARY_FRAGMENT,
+(sgl-kernel/csrc/common_extension.cc:48-121, torch_extension_rocm.cc:60-84; the reference registers them from C++ with TORCH_LIBRARY_FRAGMENT,
 here torch.library does the same from Python and the implementations call libsglk through its C ABI).
 
     from sglang_security_amd.sgl_kernel.torch_ops import register_torch_ops
@@ -30,6 +30,9 @@ _SCHEMAS = {
     "gelu_tanh_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
     "gelu_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
     "apply_rope_pos_ids_cos_sin_cache": "(Tensor q, Tensor k, Tensor! q_rope, Tensor! k_rope, Tensor cos_sin_cache, Tensor pos_ids, bool interleave, int cuda_stream) -> ()",
+    "verify_tree_greedy": "(Tensor! predicts, Tensor! accept_index, Tensor! accept_token_num, Tensor candidates, Tensor retrive_index, Tensor retrive_next_token, Tensor retrive_next_sibling, Tensor target_predict, int cuda_stream) -> ()",
+    "build_tree_kernel_efficient": "(Tensor parent_list, Tensor selected_index, Tensor verified_seq_len, Tensor! tree_mask, Tensor! positions, Tensor! retrive_index, Tensor! retrive_next_token, Tensor! retrive_next_sibling, int topk, int depth, int draft_token_num) -> ()",
+    "tree_speculative_sampling_target_only": "(Tensor! predicts, Tensor! accept_index, Tensor! accept_token_num, Tensor candidates, Tensor retrive_index, Tensor retrive_next_token, Tensor retrive_next_sibling, Tensor uniform_samples, Tensor target_probs, Tensor! draft_probs, float threshold_single, float threshold_acc, bool deterministic, int cuda_stream) -> ()",
     # the fast path the reference does not have: fused dequantise + GEMM on the re-laid-out weight
     "awq_gemm": "(Tensor x, Tensor packed, Tensor scales, Tensor qzeros, Tensor? bias, Tensor workspace) -> Tensor",
 }
@@ -68,6 +71,9 @@ _IMPLS = {
     "gelu_tanh_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 1),
     "gelu_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 2),
     "apply_rope_pos_ids_cos_sin_cache": _rope,
+    "verify_tree_greedy": lambda pr, ai, an, c, ri, nt, ns, tp, stream: _ops.verify_tree_greedy(pr, ai, an, c, ri, nt, ns, tp),
+    "build_tree_kernel_efficient": lambda pl, si, sl, m, pos, ri, nt, ns, topk, depth, n: _ops.build_tree_kernel_efficient(pl, si, sl, m, pos, ri, nt, ns, topk, depth, n),
+    "tree_speculative_sampling_target_only": lambda pr, ai, an, c, ri, nt, ns, u, tp, dp, ts, ta, det, stream: _ops.tree_speculative_sampling_target_only(pr, ai, an, c, ri, nt, ns, u, tp, dp, ts, ta, det),
     "awq_gemm": lambda x, packed, scales, qzeros, bias, ws: _ops.awq_gemm(x, packed, scales, qzeros, bias, None, ws),
 }
 

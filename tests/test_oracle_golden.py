@@ -160,3 +160,62 @@ def test_moe_align_oracle_properties():
             seg = seg[seg < flat.numel()]
             assert (flat[seg.long()] == int(ex[blk])).all()
             assert torch.equal(seg, torch.sort(seg).values)
+
+
+# ---------------------------------------------------------------------------------------------- draft-tree helpers
+def _tree_golden():
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "eagle_tree.json")))
+    t = lambda e: torch.tensor(e["data"], dtype=getattr(torch, e["dtype"]))
+    return g, t
+
+
+def test_oracle_build_tree_golden():
+    """The serial restatement reproduces the expected outputs of build_eagle_tree.py:354-384."""
+    import oracle
+    g, t = _tree_golden()
+    n = g["num_draft_token"]
+    parent_list, top, draft = oracle.build_tree_preprocess(
+        t(g["verified_id"]), [t(x) for x in g["score_list"]], [t(x) for x in g["token_list"]],
+        [t(x) for x in g["parents_list"]], n)
+    _, pos, ridx, nxt, sib = oracle.build_tree_efficient(parent_list, top, t(g["seq_lens"]), g["topk"], g["depth"], n)
+    e = g["expected"]
+    assert draft.tolist() == e["draft_tokens"]
+    assert pos == e["position"] and ridx == e["retrive_index"]
+    assert nxt == e["retrive_next_token"] and sib == e["retrive_next_sibling"]
+
+
+def _walk_golden():
+    cand = torch.tensor([[0, 1, 2, 3, 4, 5], [7, 8, 9, 10, 11, 12]], dtype=torch.int32)
+    ridx = torch.tensor([[0, 1, 2, 3, 4, 5], [6, 7, 8, 9, 10, 11]], dtype=torch.int32)
+    nxt = torch.tensor([[1, 2, -1, 4, 5, -1], [4, 2, 3, -1, 5, -1]], dtype=torch.int32)
+    sib = torch.tensor([[-1, 3, -1, -1, -1, -1], [-1, -1, -1, -1, 1, -1]], dtype=torch.int32)
+    logits = torch.full((2, 6, 20), 1, dtype=torch.float32)
+    for i, j, k in ((0, 0, 3), (0, 3, 4), (0, 4, 5), (1, 0, 11), (1, 4, 12)):
+        logits[i, j, k] = 10
+    for i in range(2):
+        for j in range(6):
+            if torch.max(logits[i, j]) < 10:
+                logits[i, j, 18] = 10
+    return cand, ridx, nxt, sib, logits
+
+
+def test_oracle_verify_tree_greedy_golden():
+    """sgl-kernel/tests/speculative/test_eagle_utils.py:78-84."""
+    import oracle
+    cand, ridx, nxt, sib, logits = _walk_golden()
+    got = oracle.verify_tree_greedy(cand, ridx, nxt, sib, torch.argmax(logits, -1).to(torch.int32), 4)
+    assert got == ([3, -1, -1, 4, 5, 18, 11, -1, -1, -1, 12, 18], [[0, 3, 4, 5], [6, 10, 11, -1]], [3, 2])
+
+
+def test_oracle_tree_speculative_sampling_golden():
+    """sgl-kernel/tests/speculative/test_speculative_sampling.py:6-21."""
+    import oracle
+    cand, ridx, nxt, sib, logits = _walk_golden()
+    probs = torch.softmax(logits / 0.01, dim=-1)
+    coins = torch.rand(2, 6, generator=torch.Generator().manual_seed(0))
+    got = oracle.tree_speculative_sampling_target_only(cand, ridx, nxt, sib, coins, probs, torch.zeros_like(probs), 4, 1, 1)
+    assert got == ([3, -1, -1, 4, 5, 18, 11, -1, -1, -1, 12, 18], [[0, 3, 4, 5], [6, 10, 11, -1]], [3, 2])
+    got = oracle.tree_speculative_sampling_target_only(cand, ridx, nxt, sib, coins, probs, torch.zeros_like(probs), 4, 0, 0)
+    assert got == ([1, 2, 18, -1, -1, -1, 11, -1, -1, -1, 12, 18], [[0, 1, 2, -1], [6, 10, 11, -1]], [2, 2])
