@@ -318,6 +318,15 @@ def main():
             hit.update(extend_ttft(cfg, B, args.prefix, args.suffix, dev))
         except Exception as e:  # the headline number must survive a failure here
             hit["extend_error"] = str(e)[:200]
+        if cfg.quant in ("awq", "bf16"):
+            # whole-model time to first token through the radix cache: cold, prefix cached by another user (public
+            # nodes), and the same with SafeKV holding the nodes private (the fork's timing side-channel experiment)
+            try:
+                from sglang_security_amd.prefill_runner import ttft_experiment
+
+                hit["ttft"] = ttft_experiment(dec, args.prefix, args.suffix)
+            except Exception as e:
+                hit["ttft_error"] = str(e)[:200]
         out["prefix_hit"] = hit
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.tiny:
         try:

@@ -1,0 +1,236 @@
+"""Extend (prefill-with-prefix) step of a Llama-family model on the sglk kernels, and the prefix-cache harness that
+times it the way the fork's timing experiment does.
+
+Per layer this is the reference's extend forward (python/sglang/srt/models/llama.py:245-267;
+model_executor/model_runner.py:1151-1164 forward_extend): norm, qkv projection, rotary + KV-pool write, extend
+attention over the cached prefix (through kv_indices) and the new tokens (causal), o projection, norm, gated MLP.
+The AWQ projections follow the reference's own switch (layers/quantization/awq.py: 256 tokens or more are
+multiplied by the dequantised weight with a plain GEMM, fewer go through the fused int4 kernel).
+
+`PrefixCacheHarness` is the scheduler's part around it, reduced to one request at a time: match_prefix with the
+sender's user id, slot allocation, req_to_token row, extend of the unmatched tail, cache_finished_req
+(managers/schedule_batch.py:1072-1200 prepare_for_extend; mem_cache/radix_cache.py:160-197).  The time to the first
+token of a request whose prefix is cached by another user is what the fork's experiment measures
+(ndss_scripts/timing_side_channel_attacker.py): short when the nodes are public, as long as a cold request when
+SafeKV has marked them private.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from . import ops
+from .decode_runner import LlamaDecoder, _AwqLinear, _DenseLinear, _Fp8Linear
+from .mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
+from .mem_cache.radix_cache import RadixCache
+
+DEQUANT_GEMM_MIN_TOKENS = 256  # awq.py FP16_MATMUL_HEURISTIC_CONDITION
+
+
+class LlamaPrefill:
+    """Extend forward over the weights of a LlamaDecoder and the buffers of an MHATokenToKVPool."""
+
+    def __init__(self, dec: LlamaDecoder, kv_pool: MHATokenToKVPool, max_tokens: int):
+        c = dec.cfg
+        self.dec, self.cfg, self.kv = dec, c, kv_pool
+        self.max_tokens = max_tokens
+        dev, dt = dec.device, dec.dtype
+        self.q_size, self.kv_size = dec.q_size, dec.kv_size
+        T = max_tokens
+        self.hidden = torch.empty(T, c.hidden, dtype=dt, device=dev)
+        self.residual = torch.empty(T, c.hidden, dtype=dt, device=dev)
+        self.qkv = torch.empty(T, self.q_size + 2 * self.kv_size, dtype=dt, device=dev)
+        self.attn_out = torch.empty(T, self.q_size, dtype=dt, device=dev)
+        self.gate_up = torch.empty(T, 2 * c.inter, dtype=dt, device=dev)
+        self.act = torch.empty(T, c.inter, dtype=dt, device=dev)
+        ws = 256
+        if c.quant == "awq":
+            m = min(T, DEQUANT_GEMM_MIN_TOKENS)
+            for K, N in ((c.hidden, self.q_size + 2 * self.kv_size), (self.q_size, c.hidden), (c.hidden, 2 * c.inter),
+                         (c.inter, c.hidden)):
+                ws = max(ws, ops.awq_gemm_workspace_bytes(m, N, K))
+        self.workspace = torch.zeros(ws, dtype=torch.uint8, device=dev)
+        self.logits = torch.empty(1, c.vocab, dtype=dt, device=dev)
+        self.next_id = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def _linear(self, w, x, out):
+        T = x.shape[0]
+        if isinstance(w, _AwqLinear):
+            if T >= DEQUANT_GEMM_MIN_TOKENS:
+                torch.matmul(x, ops.awq_dequantize_packed(w.packed, w.scales, w.qzeros), out=out)
+            else:
+                ops.awq_gemm(x, w.packed, w.scales, w.qzeros, None, out, self.workspace)
+        elif isinstance(w, _DenseLinear):
+            torch.matmul(x, w.weight.t(), out=out)
+        else:
+            raise NotImplementedError("prefill runner: awq and bf16 weights")
+        return out
+
+    def extend(self, input_ids: torch.Tensor, positions: torch.Tensor, out_cache_loc: torch.Tensor,
+               qo_indptr: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, max_extend_len: int):
+        """One extend forward over T = len(input_ids) new tokens of the requests described by the indptr arrays
+        (ForwardMetadata of the attention backend); returns the hidden states [T, hidden] after the last layer's MLP
+        (before the final residual add and norm)."""
+        c = self.cfg
+        T = input_ids.shape[0]
+        if T > self.max_tokens:
+            raise ValueError(f"extend of {T} tokens, buffers hold {self.max_tokens}")
+        hidden, residual = self.hidden[:T], self.residual[:T]
+        qkv, attn_out = self.qkv[:T], self.attn_out[:T]
+        gate_up, act = self.gate_up[:T], self.act[:T]
+        torch.index_select(self.dec.embed, 0, input_ids, out=hidden)
+        sm_scale = 1.0 / math.sqrt(c.head_dim)
+        q = qkv[:, : self.q_size].view(T, c.q_heads, c.head_dim)
+        k = qkv[:, self.q_size: self.q_size + self.kv_size].view(T, c.kv_heads, c.head_dim)
+        v = qkv[:, self.q_size + self.kv_size:].view(T, c.kv_heads, c.head_dim)
+        o = attn_out.view(T, c.q_heads, c.head_dim)
+        for li, L in enumerate(self.dec.layers):
+            if li == 0:
+                residual.copy_(hidden)
+                ops.rmsnorm(hidden, hidden, L["ln1"], c.eps)
+            else:
+                ops.fused_add_rmsnorm(hidden, residual, L["ln1"], c.eps)
+            self._linear(L["qkv"], hidden, qkv)
+            kb, vb = self.kv.get_kv_buffer(li)
+            ops.rope_and_store_kv(qkv, self.dec.cos_sin, positions, kb, vb, out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
+            ops.extend_attention_fwd(q, k, v, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None, max_extend_len,
+                                     sm_scale)
+            self._linear(L["o"], attn_out, hidden)
+            ops.fused_add_rmsnorm(hidden, residual, L["ln2"], c.eps)
+            self._linear(L["gate_up"], hidden, gate_up)
+            ops.act_and_mul(act, gate_up, 0)
+            self._linear(L["down"], act, hidden)
+        return hidden, residual
+
+    def first_token(self, hidden: torch.Tensor, residual: torch.Tensor, last_row: int) -> torch.Tensor:
+        """Greedy next token of the request whose last new token is row `last_row` (logits_processor.py: only the last
+        position of an extend is projected)."""
+        c = self.cfg
+        h = hidden[last_row: last_row + 1].clone()
+        r = residual[last_row: last_row + 1].clone()
+        ops.fused_add_rmsnorm(h, r, self.dec.final_norm, c.eps)
+        torch.matmul(h, self.dec.lm_head.weight.t(), out=self.logits)
+        ops.argmax(self.logits, self.next_id)
+        return self.next_id
+
+
+class _Req:
+    """The fields of managers/schedule_batch.py Req that the prefix cache reads."""
+
+    def __init__(self, token_ids: List[int], user_id, text: str = ""):
+        self.origin_input_ids = list(token_ids)
+        self.output_ids: List[int] = []
+        self.user_id = user_id
+        self.origin_input_text = text
+        self.req_pool_idx: Optional[int] = None
+        self.prefix_indices = None
+        self.last_node = None
+        self.fill_ids = list(token_ids)
+
+
+class PrefixCacheHarness:
+    """One request at a time through match_prefix -> alloc -> extend -> first token -> cache_finished_req."""
+
+    def __init__(self, dec: LlamaDecoder, pool_tokens: int, max_ctx: int, judge=None, compat_fork: bool = True):
+        c = dec.cfg
+        dev = dec.device
+        self.dec = dec
+        self.kv = MHATokenToKVPool(pool_tokens, 1, dec.dtype, c.kv_heads, c.head_dim, c.layers, dev)
+        self.alloc = TokenToKVPoolAllocator(pool_tokens, dec.dtype, dev, self.kv)
+        self.req_pool = ReqToTokenPool(8, max_ctx, dev)
+        self.tree = RadixCache(self.req_pool, self.alloc, 1, judge, compat_fork=compat_fork)
+        self.model = LlamaPrefill(dec, self.kv, max_ctx)
+        self.dev = dev
+
+    def serve_first_token(self, token_ids: List[int], user_id, text: str = "", finish: bool = True):
+        """Returns (first token id tensor, number of prefix tokens served from the cache, the request)."""
+        req = _Req(token_ids, user_id, text)
+        n = len(token_ids)
+        # the last token is always computed (schedule_batch.py init_next_round_input matches fill_ids[:-1])
+        prefix, last_node = self.tree.match_prefix(token_ids[:-1], user_id=user_id)
+        pre = int(prefix.numel())
+        req.prefix_indices, req.last_node = prefix, last_node
+        self.tree.inc_lock_ref(last_node)
+        req.req_pool_idx = self.req_pool.alloc(1)[0]
+        ext = n - pre
+        loc = self.alloc.alloc(ext)
+        if loc is None:
+            self.tree.evict(ext)
+            loc = self.alloc.alloc(ext)
+            if loc is None:
+                raise RuntimeError("KV pool exhausted")
+        row = self.req_pool.req_to_token[req.req_pool_idx]
+        if pre:
+            row[:pre] = prefix.to(torch.int32)
+        row[pre:n] = loc.to(torch.int32)
+        ids = torch.tensor(token_ids[pre:], dtype=torch.int64, device=self.dev)
+        positions = torch.arange(pre, n, dtype=torch.int64, device=self.dev)
+        qo_indptr = torch.tensor([0, ext], dtype=torch.int32, device=self.dev)
+        kv_indptr = torch.tensor([0, pre], dtype=torch.int32, device=self.dev)
+        kv_indices = row[:pre].contiguous() if pre else torch.zeros(1, dtype=torch.int32, device=self.dev)
+        hidden, residual = self.model.extend(ids, positions, loc, qo_indptr, kv_indptr, kv_indices, ext)
+        tok = self.model.first_token(hidden, residual, ext - 1)
+        if finish:
+            self.finish(req, int(tok.item()))
+        return tok, pre, req
+
+    def finish(self, req: _Req, first_token: int):
+        req.output_ids = [first_token]
+        self.tree.cache_finished_req(req)
+
+
+def ttft_experiment(dec: LlamaDecoder, prefix_len: int, suffix_len: int, pool_tokens: int = 16384, seed: int = 0,
+                    repeats: int = 3) -> dict:
+    """Time to first token of a request whose first `prefix_len` tokens another user has just sent, with the cached
+    nodes public and with SafeKV holding them private, next to the cold request and to the owner's own re-use.
+    Wall-clock per request, host work included (match_prefix, allocation, metadata), device synchronised on both
+    sides; the median of `repeats` rounds, each on a freshly reset tree."""
+    import statistics
+    import time
+
+    from .private_service.private_client import PrivateJudgeClient
+
+    g = torch.Generator().manual_seed(seed)
+    vocab = dec.cfg.vocab
+    rand = lambda n: torch.randint(0, vocab, (n,), generator=g).tolist()
+    out = {}
+    for mode, is_private in (("public", False), ("private", True)):
+        judge = PrivateJudgeClient(lambda text, p=is_private: p, num_workers=1)
+        h = PrefixCacheHarness(dec, pool_tokens, prefix_len + suffix_len + 8, judge)
+        cold, other, owner, hits = [], [], [], []
+        for r in range(repeats + 1):                     # round 0 warms kernels, GEMM heuristics and the allocator
+            h.tree.reset()
+            h.alloc.clear()
+            h.req_pool.clear()
+            shared = rand(prefix_len)
+
+            def timed(tokens, user):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, pre, _ = h.serve_first_token(tokens, user, "context line\nUser: question")
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) * 1e3, pre
+
+            t_cold, pre_cold = timed(shared + rand(suffix_len), "victim")
+            judge.drain()
+            t_owner, pre_owner = timed(shared + rand(suffix_len), "victim")
+            judge.drain()
+            t_other, pre_other = timed(shared + rand(suffix_len), "attacker")
+            judge.drain()
+            if r:
+                cold.append(t_cold)
+                other.append(t_other)
+                owner.append(t_owner)
+                hits.append((pre_cold, pre_other, pre_owner))
+        judge.close()
+        med = statistics.median
+        out[mode] = {"ttft_ms_cold": round(med(cold), 3), "ttft_ms_other_user": round(med(other), 3),
+                     "ttft_ms_owner": round(med(owner), 3), "cached_prefix_tokens_cold_other_owner": list(hits[-1])}
+        del h
+    pub, prv = out["public"], out["private"]
+    out["ttft_speedup_prefix_hit"] = round(pub["ttft_ms_cold"] / pub["ttft_ms_other_user"], 2)
+    out["side_channel_gap_ms_public"] = round(pub["ttft_ms_cold"] - pub["ttft_ms_other_user"], 3)
+    out["side_channel_gap_ms_safekv_private"] = round(prv["ttft_ms_cold"] - prv["ttft_ms_other_user"], 3)
+    return out
