@@ -113,6 +113,67 @@ __global__ void __launch_bounds__(256) awq_dequant_packed_kernel(const int32_t* 
   }
 }
 
+// The same over whole tiles, with row-contiguous stores: a wave takes one 128-k group of 64 columns (four 1-KiB strip
+// tiles), parks the packed words in LDS with the eight column words of every (k-octet, 8-column half) side by side,
+// and each lane then builds 8 neighbouring columns of one row per step: two 16-byte LDS reads, one 16-byte store, a
+// row's 128 bytes from eight adjacent lanes.  Needs N % 64 == 0 and group_size % 128 == 0.
+template <typename T>
+__global__ void __launch_bounds__(256) awq_dequant_packed_tile_kernel(const int32_t* __restrict__ packed,
+                                                                      const uint16_t* __restrict__ scales,
+                                                                      const int32_t* __restrict__ qzeros,
+                                                                      uint16_t* __restrict__ out, int K, int N,
+                                                                      int group_size) {
+  __shared__ __attribute__((aligned(16))) uint32_t words[4][4 * 256];  // per wave: [strip][(g * 4 + d) * 16 + i]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nchunks = N / 64, nstrips = N / 16, qcols = N / 8;
+  const int64_t ntiles = (int64_t)(K / 128) * nchunks;
+  const int i16 = lane & 15, g4 = lane >> 4;
+  const int cg = lane & 7, r = lane >> 3;  // output role: 8 columns 8 * cg .. + 7 of the chunk, rows r + 8 * it
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wid; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    const int kb = (int)(tile / nchunks), chunk = (int)(tile % nchunks);
+    uint32_t* w = words[wid];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int4v v = *reinterpret_cast<const int4v*>(packed + (((int64_t)kb * nstrips + chunk * 4 + t) * 64 + lane) * 4);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) w[t * 256 + (g4 * 4 + d) * 16 + i16] = (uint32_t)v[d];
+    }
+    const int gq = (128 * kb) / group_size;
+    const int n0 = chunk * 64 + 8 * cg;
+    const int4v sv = *reinterpret_cast<const int4v*>(scales + (int64_t)gq * N + n0);
+    const uint32_t zw = (uint32_t)qzeros[(int64_t)gq * qcols + (n0 >> 3)];
+    float s[8];
+    int z[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s[j] = Conv<T>::to_f32((uint16_t)(((uint32_t)sv[j >> 1]) >> (16 * (j & 1))));
+      z[j] = (int)((zw >> (4 * ((j >> 1) + 4 * (j & 1)))) & 0xF);  // AWQ nibble order {0, 4, 1, 5, 2, 6, 3, 7}
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int pos = (r & 1) ? (r >> 1) + 4 : (r >> 1);  // nibble of row e = r inside a word
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int g = it & 3, d = it >> 2;
+      const uint32_t* src = w + (cg >> 1) * 256 + (g * 4 + d) * 16 + 8 * (cg & 1);
+      const int4v a = *reinterpret_cast<const int4v*>(src);
+      const int4v b = *reinterpret_cast<const int4v*>(src + 4);
+      int4v o;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const uint32_t w0 = (uint32_t)(j < 4 ? a[j] : b[j - 4]), w1 = (uint32_t)(j < 4 ? a[j + 1] : b[j - 3]);
+        const float v0 = (float)((int)((w0 >> (4 * pos)) & 0xF) - z[j]) * s[j];
+        const float v1 = (float)((int)((w1 >> (4 * pos)) & 0xF) - z[j + 1]) * s[j + 1];
+        o[j >> 1] = (int)((uint32_t)Conv<T>::from_f32(v0) | ((uint32_t)Conv<T>::from_f32(v1) << 16));
+      }
+      const int k = 128 * kb + 32 * d + 8 * g + r;
+      *reinterpret_cast<int4v*>(out + (int64_t)k * N + n0) = o;
+    }
+    __builtin_amdgcn_wave_barrier();  // the next tile's words overwrite this wave's LDS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 template <typename T>
 struct AwqMagic;
 template <>
@@ -1037,6 +1098,17 @@ int sglk_awq_dequantize_packed(const int32_t* packed, const void* scales, const 
   SGLK_CHECK(packed && scales && qzeros && out, "awq_dequantize_packed: null pointer");
   SGLK_CHECK(K > 0 && N > 0 && K % 128 == 0 && N % 16 == 0, "awq_dequantize_packed: K %% 128 and N %% 16 must be 0");
   SGLK_CHECK(group_size > 0 && K % group_size == 0 && group_size % 8 == 0, "awq_dequantize_packed: bad group size");
+  if (N % 64 == 0 && group_size % 128 == 0) {  // whole tiles, row-contiguous stores
+    int64_t tiles = (int64_t)(K / 128) * (N / 64);
+    int blocks = (int)((tiles + 3) / 4);
+    if (blocks > 8192) blocks = 8192;
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((awq_dequant_packed_tile_kernel<T>), dim3(blocks), dim3(256), 0,
+                                          (hipStream_t)stream, packed, (const uint16_t*)scales, qzeros, (uint16_t*)out, K,
+                                          N, group_size));
+    SGLK_LAUNCH_CHECK();
+    return SGLK_OK;
+  }
   int blocks = (int)(((int64_t)K * (N / 8) + 255) / 256);
   if (blocks > 16384) blocks = 16384;
   SGLK_DISPATCH_HALF(dtype, T,

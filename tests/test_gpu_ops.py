@@ -328,3 +328,20 @@ def test_awq_gemm_full_size_shapes():
         got = ops.awq_gemm(x.to(DEV), ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV)).float().cpu()
         assert (got - want).abs().max().item() <= 1e-2 * max(want.abs().max().item(), 1.0)
 
+
+
+@pytest.mark.parametrize("K,N,group", [(128, 64, 128), (512, 256, 128), (4096, 6144, 128), (256, 48, 128), (256, 128, 64),
+                                       (1024, 192, 256)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_awq_dequantize_packed_matches_reference_layout(K, N, group, dtype):
+    """Dequantising the re-laid-out copy gives the bits of awq_dequantize on the reference layout (both the
+    whole-tile kernel, N % 64 == 0 and group % 128 == 0, and the word-per-thread one)."""
+    from sglang_security_amd import ops
+
+    g = torch.Generator().manual_seed(K + N)
+    qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, generator=g).to("cuda")
+    qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // group, N // 8), dtype=torch.int32, generator=g).to("cuda")
+    sc = (torch.rand(K // group, N, generator=g) * 0.02).to(dtype).to("cuda")
+    want = ops.awq_dequantize(qw, sc, qz)
+    got = ops.awq_dequantize_packed(ops.awq_repack(qw), sc, qz)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
