@@ -212,6 +212,16 @@ SGLK_API int sglk_awq_dequantize(const int32_t* qweight, const void* scales, con
 SGLK_API int sglk_awq_repack(const int32_t* qweight, int32_t* packed, int rows, int qcols,
                              void* stream);
 
+/* GPTQ int4 checkpoint tensors into the layouts of sglk_awq_repack / the AWQ zero words, so that every sglk_awq_*
+ * product runs on them unchanged.  qweight int32 [K/8, N] and qzeros int32 [K/G, N/8] as GPTQLinearMethod registers
+ * them (python/sglang/srt/layers/quantization/gptq.py:18-31 takes it from vllm 0.8.4, absent from the reference
+ * tree); zero_offset 1 for v1 checkpoints (zero points stored minus one), 0 for v2.  packed int32 [K, N/8],
+ * qzeros_out int32 [K/G, N/8]; *overflow (device int, caller-zeroed) becomes non-zero if a zero point does not fit
+ * four bits.  Activation reordering (desc_act with a non-trivial g_idx) is not supported. */
+SGLK_API int sglk_gptq_repack(const int32_t* qweight, const int32_t* qzeros, int32_t* packed,
+                              int32_t* qzeros_out, int* overflow, int K, int N, int group_size,
+                              int zero_offset, void* stream);
+
 /* awq_dequantize from the re-laid-out copy: the same values as sglk_awq_dequantize on the original tensor
  * (for the prefill path once the reference-layout qweight has been dropped).  K % 128 == 0, N % 16 == 0. */
 SGLK_API int sglk_awq_dequantize_packed(const int32_t* packed, const void* scales, const int32_t* qzeros,

@@ -113,6 +113,50 @@ __global__ void __launch_bounds__(256) awq_dequant_packed_kernel(const int32_t* 
   }
 }
 
+// GPTQ int4 checkpoints (qweight int32 [K/8, N]: eight consecutive k of one column per word, nibble e = k % 8;
+// qzeros int32 [K/G, N/8]: eight consecutive columns per word in plain order, stored minus one in the v1 format) into
+// the layouts the kernels above stream: the packed weight word of (k-octet, column) is the GPTQ word of the same
+// octet with its nibbles reordered, and the zero words take the AWQ nibble order with the stored offset added back.
+// A zero point of 16 (stored nibble 15 in the v1 format) does not fit four bits: *overflow is set instead.
+__global__ void __launch_bounds__(256) gptq_repack_kernel(const int32_t* __restrict__ qweight,
+                                                          const int32_t* __restrict__ qzeros,
+                                                          int32_t* __restrict__ packed, int32_t* __restrict__ zeros_out,
+                                                          int* __restrict__ overflow, int K, int N, int groups,
+                                                          int zero_offset) {
+  const int qcols = N / 8, nstrips = N / 16;
+  const int64_t total = (int64_t)K * qcols;
+  const int64_t zwords = (int64_t)groups * qcols;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int d = (int)(idx & 3);
+    const int lane = (int)((idx >> 2) & 63);
+    const int64_t tile = idx >> 8;
+    const int nb = (int)(tile % nstrips), kb = (int)(tile / nstrips);
+    const int n = 16 * nb + (lane & 15);
+    const int k0 = 128 * kb + 32 * d + 8 * (lane >> 4);
+    const uint32_t src = (uint32_t)qweight[(int64_t)(k0 >> 3) * N + n];
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int pos = (e & 1) ? (e >> 1) + 4 : (e >> 1);
+      w |= ((src >> (4 * e)) & 0xF) << (4 * pos);
+    }
+    packed[idx] = (int32_t)w;
+    if (idx < zwords) {
+      const uint32_t zsrc = (uint32_t)qzeros[idx];
+      uint32_t z = 0;
+      bool over = false;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t v = ((zsrc >> (4 * j)) & 0xF) + (uint32_t)zero_offset;
+        over |= v > 15u;
+        z |= (v & 0xF) << (4 * ((j >> 1) + 4 * (j & 1)));
+      }
+      zeros_out[idx] = (int32_t)z;
+      if (over) atomicOr(overflow, 1);
+    }
+  }
+}
+
 // The same over whole tiles, with row-contiguous stores: a wave takes one 128-k group of 64 columns (four 1-KiB strip
 // tiles), parks the packed words in LDS with the eight column words of every (k-octet, 8-column half) side by side,
 // and each lane then builds 8 neighbouring columns of one row per step: two 16-byte LDS reads, one 16-byte store, a
@@ -1114,6 +1158,21 @@ int sglk_awq_dequantize_packed(const int32_t* packed, const void* scales, const 
   SGLK_DISPATCH_HALF(dtype, T,
                      hipLaunchKernelGGL((awq_dequant_packed_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                                         packed, (const uint16_t*)scales, qzeros, (uint16_t*)out, K, N, group_size));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_gptq_repack(const int32_t* qweight, const int32_t* qzeros, int32_t* packed, int32_t* qzeros_out, int* overflow,
+                     int K, int N, int group_size, int zero_offset, void* stream) {
+  SGLK_CHECK(qweight && qzeros && packed && qzeros_out && overflow, "gptq_repack: null pointer");
+  SGLK_CHECK(K > 0 && N > 0 && K % 128 == 0 && N % 16 == 0, "gptq_repack: K %% 128 and N %% 16 must be 0");
+  SGLK_CHECK(group_size > 0 && K % group_size == 0 && group_size % 8 == 0, "gptq_repack: bad group size");
+  SGLK_CHECK(zero_offset == 0 || zero_offset == 1, "gptq_repack: zero_offset is 1 (v1 checkpoints) or 0 (v2)");
+  SGLK_CHECK((int64_t)K * (N / 8) >= (int64_t)(K / group_size) * (N / 8), "gptq_repack: bad shape");
+  int blocks = (int)(((int64_t)K * (N / 8) + 255) / 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(gptq_repack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, qweight, qzeros, packed,
+                     qzeros_out, overflow, K, N, K / group_size, zero_offset);
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

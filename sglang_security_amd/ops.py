@@ -293,6 +293,25 @@ def awq_repack(qweight):
     return packed
 
 
+def gptq_repack(qweight, qzeros, group_size, zero_offset=1):
+    """GPTQ qweight int32 [K/8, N] / qzeros int32 [K/G, N/8] -> (packed [K, N/8], AWQ-order zero words): the operands
+    of awq_gemm / awq_dequantize_packed.  Raises if a zero point does not fit four bits."""
+    _need_gpu(qweight, qzeros)
+    if qweight.dtype != torch.int32 or qzeros.dtype != torch.int32 or not (qweight.is_contiguous() and qzeros.is_contiguous()):
+        raise SglkError("gptq_repack: qweight / qzeros must be contiguous int32")
+    K, N = qweight.shape[0] * 8, qweight.shape[1]
+    if tuple(qzeros.shape) != (K // group_size, N // 8):
+        raise SglkError("gptq_repack: qzeros must be [K / group_size, N / 8]")
+    packed = torch.empty((K, N // 8), dtype=torch.int32, device=qweight.device)
+    zeros = torch.empty_like(qzeros)
+    flag = torch.zeros(1, dtype=torch.int32, device=qweight.device)
+    check(lib().sglk_gptq_repack(_ptr(qweight), _ptr(qzeros), _ptr(packed), _ptr(zeros), _ptr(flag), K, N, int(group_size),
+                                 int(zero_offset), _stream(qweight)), "gptq_repack")
+    if int(flag.item()):
+        raise SglkError("gptq_repack: a zero point of 16 does not fit the 4-bit zero words (asymmetric v1 checkpoint)")
+    return packed, zeros
+
+
 def awq_dequantize_packed(packed, scales, qzeros):
     """awq_dequantize from the re-laid-out copy: [K, N] in the scale dtype."""
     _need_gpu(packed, scales, qzeros)

@@ -1,1 +1,2 @@
 from .awq import AWQConfig, AWQLinearMethod  # noqa: F401
+from .gptq import GPTQConfig, GPTQLinearMethod  # noqa: F401

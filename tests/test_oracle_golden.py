@@ -219,3 +219,16 @@ def test_oracle_tree_speculative_sampling_golden():
     assert got == ([3, -1, -1, 4, 5, 18, 11, -1, -1, -1, 12, 18], [[0, 3, 4, 5], [6, 10, 11, -1]], [3, 2])
     got = oracle.tree_speculative_sampling_target_only(cand, ridx, nxt, sib, coins, probs, torch.zeros_like(probs), 4, 0, 0)
     assert got == ([1, 2, 18, -1, -1, -1, 11, -1, -1, -1, 12, 18], [[0, 1, 2, -1], [6, 10, 11, -1]], [2, 2])
+
+
+def test_oracle_gptq_dequantize_known_answer():
+    """The format by hand: word 0x76543210 holds rows 0..7 of a column, zero nibbles are stored minus one (v1)."""
+    import oracle
+    qw = torch.full((1, 8), 0x76543210, dtype=torch.int32)                 # K = 8, N = 8
+    qz = torch.tensor([[0x01234567]], dtype=torch.int32)                   # column j stores 7 - j -> zero point 8 - j
+    sc = torch.full((1, 8), 0.5, dtype=torch.float16)
+    w = oracle.gptq_dequantize(qw, qz, sc, 8)
+    k = torch.arange(8).view(8, 1).float()
+    z = (8 - torch.arange(8)).view(1, 8).float()
+    assert torch.equal(w.float(), (k - z) * 0.5)
+    assert torch.equal(oracle.gptq_dequantize(qw, qz, sc, 8, zero_offset=0).float(), (k - z + 1) * 0.5)
