@@ -126,7 +126,8 @@ SGLK_API int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_str
 /* Prefill with a cached prefix: stage 1 over the prefix through kv_indices, stage 2 causal over the
  * contiguous new tokens.  Replaces extend_attention_fwd,
  * python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438
- * (== extend_attention_cpu, sgl-kernel/csrc/cpu/extend.cpp:481-621).  custom_mask unsupported. */
+ * (== extend_attention_cpu, sgl-kernel/csrc/cpu/extend.cpp:481-621).  For a custom mask see
+ * sglk_extend_attention_masked. */
 SGLK_API int sglk_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend,
                                    void* o_extend, const void* k_buffer, const void* v_buffer,
                                    const int32_t* qo_indptr, const int32_t* kv_indptr,
@@ -137,6 +138,23 @@ SGLK_API int sglk_extend_attention(const void* q_extend, const void* k_extend, c
                                    int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
                                    int max_extend_len, float sm_scale, float logit_cap, int causal,
                                    int dtype, void* stream);
+
+/* sglk_extend_attention under a custom mask (draft-tree verification): custom_mask uint8, for request b the
+ * [extend_len, prefix_len + extend_len] row-major block at mask_indptr[b] (int64 [B + 1]); a new token j is visible
+ * to row i iff its byte is non-zero, prefix tokens are all visible when skip_prefix_custom_mask, else by their bytes
+ * (extend_attention.py:93-94,167-178,245-257).  Mask bytes above the diagonal are honoured as given (the reference,
+ * when is_causal, drops those beyond its row tile); a row that sees nothing is written as zeros (reference: NaN). */
+SGLK_API int sglk_extend_attention_masked(const void* q_extend, const void* k_extend, const void* v_extend,
+                                          void* o_extend, const void* k_buffer, const void* v_buffer,
+                                          const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                          const int32_t* kv_indices, const uint8_t* custom_mask,
+                                          const int64_t* mask_indptr, int skip_prefix_custom_mask, int B,
+                                          int Hq, int Hkv, int D, int Dv, int64_t q_stride_t,
+                                          int64_t q_stride_h, int64_t ke_stride_t, int64_t ke_stride_h,
+                                          int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
+                                          int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                          int64_t v_stride_n, int64_t v_stride_h, int max_extend_len,
+                                          float sm_scale, float logit_cap, int dtype, void* stream);
 
 /* Paged prefill: like sglk_extend_attention, but the new tokens are already in the pool and kv_indices lists
  * every token of each sequence (prefix + new); with causal != 0 query row i of a sequence with q_len rows and

@@ -487,3 +487,35 @@ def gptq_dequantize(qweight, qzeros, scales, group_size, zero_offset=1):
     g = torch.arange(q.shape[0]) // group_size
     w = (q - z[g]).float() * scales.cpu().float()[g]
     return w.to(scales.dtype)
+
+
+# ---------------------------------------------------------------------------------------------- masked extend
+def extend_attention_masked(q_ext, k_ext, v_ext, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask,
+                            mask_indptr, skip_prefix_custom_mask, sm_scale, logit_cap=0.0):
+    """extend_attention_fwd with USE_CUSTOM_MASK (triton_ops/extend_attention.py:93-94,167-178,245-257): per request a
+    uint8 [extend_len, prefix_len + extend_len] block; the prefix is fully visible when skip_prefix_custom_mask.
+    fp32 torch, one request and head at a time (small cases)."""
+    q, ke, ve = q_ext.float().cpu(), k_ext.float().cpu(), v_ext.float().cpu()
+    kb, vb = k_buffer.float().cpu(), v_buffer.float().cpu()
+    T, Hq, D = q.shape
+    Hkv, Dv = ve.shape[1], ve.shape[2]
+    o = torch.zeros(T, Hq, Dv)
+    qo, kp = qo_indptr.tolist(), kv_indptr.tolist()
+    ki, mp = kv_indices.long().cpu(), mask_indptr.tolist()
+    m8 = custom_mask.cpu()
+    for b in range(len(qo) - 1):
+        ext, pre = qo[b + 1] - qo[b], kp[b + 1] - kp[b]
+        allow = m8[mp[b]: mp[b] + ext * (pre + ext)].reshape(ext, pre + ext) != 0
+        if skip_prefix_custom_mask:
+            allow[:, :pre] = True
+        loc = ki[kp[b]: kp[b + 1]]
+        for h in range(Hq):
+            g = h // (Hq // Hkv)
+            K = torch.cat([kb[loc, g], ke[qo[b]: qo[b + 1], g]])
+            V = torch.cat([vb[loc, g], ve[qo[b]: qo[b + 1], g]])
+            s = (q[qo[b]: qo[b + 1], h] @ K.t()) * sm_scale
+            if logit_cap > 0:
+                s = logit_cap * torch.tanh(s / logit_cap)
+            s = s.masked_fill(~allow, float("-inf"))
+            o[qo[b]: qo[b + 1], h] = torch.softmax(s, -1) @ V
+    return o

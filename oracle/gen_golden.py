@@ -211,6 +211,45 @@ def gen_extend(tri, ops):
         save(f"extend_{tag}", d)
 
 
+def gen_extend_masked(tri):
+    """extend_attention_fwd with a custom mask (the draft-tree verification path): bits below or on the diagonal of the
+    new tokens chosen at random with the diagonal always set, prefix fully visible (skip_prefix_custom_mask=True) or
+    masked at random with its first token kept."""
+    torch.manual_seed(7)
+    cases = [("tree", 2, 8, 2, 128, 128, [40, 9], [16, 8], True), ("prefix_masked", 2, 4, 4, 64, 64, [17, 5], [12, 6], False)]
+    for tag, B, Hq, Hkv, D, Dv, pre, ext, skip in cases:
+        n = sum(pre) + sum(ext) + 5
+        kb, vb = _mk_pool(n, Hkv, D, Dv, torch.bfloat16)
+        T = sum(ext)
+        q = torch.randn(T, Hq, D).to(torch.bfloat16)
+        ke, ve = torch.randn(T, Hkv, D).to(torch.bfloat16), torch.randn(T, Hkv, Dv).to(torch.bfloat16)
+        perm = torch.randperm(n - 1) + 1
+        qo = torch.zeros(B + 1, dtype=torch.int32)
+        qo[1:] = torch.cumsum(torch.tensor(ext), 0)
+        kp = torch.zeros(B + 1, dtype=torch.int32)
+        kp[1:] = torch.cumsum(torch.tensor(pre), 0)
+        ki = perm[: sum(pre)].to(torch.int32)
+        masks, mptr = [], [0]
+        for b in range(B):
+            m = torch.zeros(ext[b], pre[b] + ext[b], dtype=torch.bool)
+            m[:, : pre[b]] = True if skip else (torch.rand(ext[b], pre[b]) < 0.6)
+            m[:, 0] = True
+            tri_part = torch.tril(torch.rand(ext[b], ext[b]) < 0.5) | torch.eye(ext[b], dtype=torch.bool)
+            m[:, pre[b]:] = tri_part
+            masks.append(m.flatten())
+            mptr.append(mptr[-1] + m.numel())
+        mask = torch.cat(masks).to(torch.uint8)
+        mask_indptr = torch.tensor(mptr, dtype=torch.int64)
+        sm = 1.0 / math.sqrt(D)
+        o_t = torch.zeros(T, Hq, Dv)
+        tri.extend_attention_fwd(q.float(), ke.float(), ve.float(), o_t, kb.float(), vb.float(), qo, kp, ki,
+                                 mask, True, mask_indptr, max(ext), sm, 0.0, skip_prefix_custom_mask=skip)
+        save(f"extend_masked_{tag}", dict(
+            q_extend=q, k_extend=ke, v_extend=ve, k_buffer=kb, v_buffer=vb, qo_indptr=qo, kv_indptr=kp, kv_indices=ki,
+            custom_mask=mask, mask_indptr=mask_indptr, skip_prefix_custom_mask=int(skip), sm_scale=sm,
+            expect_triton_f32=o_t))
+
+
 def gen_merge_state(tri):
     torch.manual_seed(42)
     m = load_test_module("sgl-kernel/tests/test_merge_state_v2.py", "ref_test_merge_state_v2") \
@@ -561,6 +600,8 @@ def main():
         gen_decode(tri, ops)
     if want("extend"):
         gen_extend(tri, ops)
+    if want("extend_masked"):
+        gen_extend_masked(tri)
     if want("merge"):
         gen_merge_state(tri)
     if want("awq"):

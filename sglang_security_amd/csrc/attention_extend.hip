@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
     const int32_t* __restrict__ kv_indices, int Hq, int Hkv, int D, int Dv, int64_t q_stride_t, int64_t q_stride_h,
     int64_t ke_stride_t, int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
     int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
-    float logit_cap, int causal) {
+    float logit_cap, int causal, const uint8_t* __restrict__ custom_mask, const int64_t* __restrict__ mask_indptr,
+    int skip_prefix_mask) {
   extern __shared__ float qs[];  // D floats
   const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x;
   const int q0 = qo_indptr[b];
@@ -128,7 +129,10 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
   for (int d = lane; d < D; d += 64) qs[d] = ld<T>(q_extend, (int64_t)(q0 + qi) * q_stride_t + (int64_t)h * q_stride_h + d);
   __syncthreads();
   const bool paged = k_extend == nullptr;   // kv_indices lists every token; row qi sees plen - ext_len + qi + 1 of them
-  const int vis = paged ? 0 : (causal ? qi + 1 : ext_len);  // visible new tokens
+  // with a custom mask (row qi of the request: plen + ext_len bytes, prefix columns first) the mask decides which new
+  // tokens are visible, and, unless skip_prefix_mask, which prefix tokens
+  const uint8_t* mrow = (custom_mask && !paged) ? custom_mask + mask_indptr[b] + (int64_t)qi * (plen + ext_len) : nullptr;
+  const int vis = paged ? 0 : (mrow ? ext_len : (causal ? qi + 1 : ext_len));  // visible new tokens
   const int total = paged ? (causal ? plen - ext_len + qi + 1 : plen) : plen + vis;
   float m = -INFINITY, l = 0.f;
   float acc[DV_PER_LANE];
@@ -154,15 +158,17 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
       }
     }
     float s = -INFINITY;
-    if (valid) {
+    const bool shown = valid && (!mrow || (in_prefix && skip_prefix_mask) || mrow[tok] != 0);
+    if (shown) {
       s = 0.f;
       for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(kp, kb + d);
       s *= sm_scale;
       if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
     }
     const float m_new = fmaxf(m, wave_max(s));
+    if (m_new == -INFINITY) continue;  // nothing visible so far (only possible under a custom mask)
     const float alpha = expf(m - m_new);
-    const float p = valid ? expf(s - m_new) : 0.f;
+    const float p = shown ? expf(s - m_new) : 0.f;
     l = l * alpha + wave_sum(p);
     m = m_new;
 #pragma unroll
@@ -183,7 +189,7 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
 #pragma unroll
   for (int i = 0; i < DV_PER_LANE; ++i) {
     const int d = lane + 64 * i;
-    if (d < Dv) st<T>(o_extend, (int64_t)(q0 + qi) * o_stride_t + (int64_t)h * o_stride_h + d, acc[i] / l);
+    if (d < Dv) st<T>(o_extend, (int64_t)(q0 + qi) * o_stride_t + (int64_t)h * o_stride_h + d, l > 0.f ? acc[i] / l : 0.f);
   }
 }
 
@@ -199,7 +205,9 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                                  int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h,
                                  int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
                                  int max_extend_len, float sm_scale, float logit_cap, int causal, int dtype, void* stream,
-                                 bool paged) {
+                                 bool paged, const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
+                                 int skip_prefix_mask = 1) {
+  SGLK_CHECK(!custom_mask || (mask_indptr && !paged), "extend_attention: a custom mask needs mask_indptr and new K/V");
   SGLK_CHECK(q_extend && o_extend && qo_indptr && kv_indptr && (paged || (k_extend && v_extend)),
              "extend_attention: null pointer");
   SGLK_CHECK(B >= 0 && Hq > 0 && Hkv > 0 && D > 0 && Dv > 0, "extend_attention: bad shape");
@@ -213,7 +221,7 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
   if (paged) k_extend = v_extend = nullptr;  // the kernels take a null k_extend as "every token is in the pool"
   hipStream_t s = (hipStream_t)stream;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
-  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
+  const bool fast = !custom_mask && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
                     (paged || (aligned16(k_extend) && aligned16(v_extend))) && aligned16(k_buffer) && aligned16(v_buffer) &&
                     ((uintptr_t)o_extend % 8 == 0) && mult8(q_stride_t) && mult8(q_stride_h) && mult8(ke_stride_t) &&
                     mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && mult8(k_stride_n) &&
@@ -246,7 +254,8 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
   hipLaunchKernelGGL((extend_attention_generic<T, N>), grid, dim3(64), lds, s, q_extend, k_extend, v_extend, o_extend, \
                      k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, D, Dv, q_stride_t, q_stride_h,     \
                      ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,           \
-                     k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal)
+                     k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, custom_mask, mask_indptr,        \
+                     skip_prefix_mask)
     SGLK_DISPATCH_FLOAT(dtype, T, {
       if (per_lane <= 1) {
         SGLK_GEN(1);
@@ -278,6 +287,24 @@ extern "C" int sglk_extend_attention(const void* q_extend, const void* k_extend,
                                B, Hq, Hkv, D, Dv, q_stride_t, q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h,
                                o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
                                sm_scale, logit_cap, causal, dtype, stream, false);
+}
+
+extern "C" int sglk_extend_attention_masked(const void* q_extend, const void* k_extend, const void* v_extend,
+                                            void* o_extend, const void* k_buffer, const void* v_buffer,
+                                            const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                            const uint8_t* custom_mask, const int64_t* mask_indptr,
+                                            int skip_prefix_custom_mask, int B, int Hq, int Hkv, int D, int Dv,
+                                            int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                            int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h,
+                                            int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                            int64_t v_stride_n, int64_t v_stride_h, int max_extend_len, float sm_scale,
+                                            float logit_cap, int dtype, void* stream) {
+  SGLK_CHECK(custom_mask && mask_indptr, "extend_attention_masked: null mask");
+  return extend_attention_impl(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                               B, Hq, Hkv, D, Dv, q_stride_t, q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h,
+                               o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
+                               sm_scale, logit_cap, 1, dtype, stream, false, custom_mask, mask_indptr,
+                               skip_prefix_custom_mask ? 1 : 0);
 }
 
 extern "C" int sglk_prefill_attention_paged(const void* q, void* o, const void* k_buffer, const void* v_buffer,

@@ -297,3 +297,67 @@ def test_aiter_shim_prefill_and_decode(dtype, D, causal):
                                     None, 256)
         last = torch.stack([want[int(qo[b + 1]) - 1] for b in range(B)])
         assert (od.float().cpu() - last).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("case", ["tree", "prefix_masked"])
+def test_extend_masked_golden(golden, case):
+    """Custom-mask extend (draft-tree verification) against the reference Triton kernel's output."""
+    from sglang_security_amd import ops
+
+    g = golden("extend_masked_" + case)
+    dev = "cuda"
+    q = g["q_extend"].to(dev)
+    o = torch.empty(q.shape[0], q.shape[1], g["v_extend"].shape[2], dtype=q.dtype, device=dev)
+    ext = (g["qo_indptr"][1:] - g["qo_indptr"][:-1]).max().item()
+    ops.extend_attention_fwd(q, g["k_extend"].to(dev), g["v_extend"].to(dev), o, g["k_buffer"].to(dev), g["v_buffer"].to(dev),
+                             g["qo_indptr"].to(dev), g["kv_indptr"].to(dev), g["kv_indices"].to(dev),
+                             g["custom_mask"].to(dev), True, g["mask_indptr"].to(dev), ext, g["sm_scale"], 0.0,
+                             skip_prefix_custom_mask=bool(g["skip_prefix_custom_mask"]))
+    torch.testing.assert_close(o.float().cpu(), g["expect_triton_f32"], rtol=2e-2, atol=2e-2)   # bf16 output
+
+
+def test_extend_masked_tree_from_builder():
+    """The mask laid out by build_tree_kernel_efficient drives the extend: every draft token attends the prefix and
+    its own ancestors only, which the restatement reproduces from the same bytes."""
+    import oracle
+    from sglang_security_amd import ops
+    import sglang_security_amd.sgl_kernel as sk
+
+    dev = "cuda"
+    bs, topk, depth, n, Hq, Hkv, D = 3, 4, 3, 8, 8, 2, 128
+    gen = torch.Generator().manual_seed(3)
+    score = [torch.rand(bs, 1, topk, generator=gen)]
+    parents = [torch.arange(-1, topk).unsqueeze(0).repeat(bs, 1)]
+    prev = score[0].squeeze(1)
+    for step in range(1, depth):
+        child = prev.unsqueeze(2) * torch.rand(bs, topk, topk, generator=gen)
+        score.append(child)
+        top = torch.topk(child.flatten(1), topk, dim=-1)
+        parents.append(top.indices + (topk * topk * (step - 1) + topk))
+        prev = top.values
+    tokens = [torch.randint(0, 100, (bs, s.shape[1] * s.shape[2]), generator=gen) for s in score]
+    parent_list, sel, _ = oracle.build_tree_preprocess(torch.zeros(bs, dtype=torch.long), score, tokens, parents, n)
+    seq = torch.tensor([20, 7, 33], dtype=torch.int32)
+    mask = torch.full((int(seq.sum()) * n + n * n * bs,), True, device=dev)
+    pos = torch.empty(bs * n, dtype=torch.long, device=dev)
+    ri, nt, ns = (torch.full((bs, n), -1, dtype=torch.long, device=dev) for _ in range(3))
+    sk.build_tree_kernel_efficient(parent_list.to(dev), sel.to(dev), seq.to(dev), mask, pos, ri, nt, ns, topk, depth, n)
+    total = int(seq.sum())
+    kb = torch.randn(total + 1, Hkv, D, generator=gen).to(torch.bfloat16)
+    vb = torch.randn(total + 1, Hkv, D, generator=gen).to(torch.bfloat16)
+    q = torch.randn(bs * n, Hq, D, generator=gen).to(torch.bfloat16)
+    ke = torch.randn(bs * n, Hkv, D, generator=gen).to(torch.bfloat16)
+    ve = torch.randn(bs * n, Hkv, D, generator=gen).to(torch.bfloat16)
+    qo = (torch.arange(bs + 1) * n).int()
+    kp = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seq, 0).int()])
+    ki = (torch.randperm(total, generator=gen) + 1).int()
+    mptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum((seq.long() + n) * n, 0)])
+    o = torch.empty(bs * n, Hq, D, dtype=torch.bfloat16, device=dev)
+    ops.extend_attention_fwd(q.to(dev), ke.to(dev), ve.to(dev), o, kb.to(dev), vb.to(dev), qo.to(dev), kp.to(dev),
+                             ki.to(dev), mask, True, mptr.to(dev), n, 1.0 / math.sqrt(D))
+    want = oracle.extend_attention_masked(q, ke, ve, kb, vb, qo, kp, ki, mask.cpu().to(torch.uint8), mptr, True,
+                                          1.0 / math.sqrt(D))
+    torch.testing.assert_close(o.float().cpu(), want, rtol=2e-2, atol=2e-2)
+    # the root of every tree sees the prefix and itself only: equal to plain causal extend of one token
+    m = mask.cpu().view(-1)
+    assert m[mptr[0] + 20] and not m[mptr[0] + 21: mptr[0] + 20 + n].any()

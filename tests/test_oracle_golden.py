@@ -232,3 +232,14 @@ def test_oracle_gptq_dequantize_known_answer():
     z = (8 - torch.arange(8)).view(1, 8).float()
     assert torch.equal(w.float(), (k - z) * 0.5)
     assert torch.equal(oracle.gptq_dequantize(qw, qz, sc, 8, zero_offset=0).float(), (k - z + 1) * 0.5)
+
+
+@pytest.mark.parametrize("case", ["tree", "prefix_masked"])
+def test_oracle_extend_masked_golden(golden, case):
+    """The masked-extend restatement against the reference Triton kernel's output (interpreter run, gen_golden.py)."""
+    import oracle
+    g = golden("extend_masked_" + case)
+    got = oracle.extend_attention_masked(g["q_extend"], g["k_extend"], g["v_extend"], g["k_buffer"], g["v_buffer"],
+                                         g["qo_indptr"], g["kv_indptr"], g["kv_indices"], g["custom_mask"],
+                                         g["mask_indptr"], bool(g["skip_prefix_custom_mask"]), g["sm_scale"])
+    torch.testing.assert_close(got, g["expect_triton_f32"], rtol=2e-4, atol=2e-4)
