@@ -32,7 +32,7 @@ DEQUANT_GEMM_MIN_TOKENS = 256  # awq.py FP16_MATMUL_HEURISTIC_CONDITION
 class LlamaPrefill:
     """Extend forward over the weights of a LlamaDecoder and the buffers of an MHATokenToKVPool."""
 
-    def __init__(self, dec: LlamaDecoder, kv_pool: MHATokenToKVPool, max_tokens: int):
+    def __init__(self, dec: LlamaDecoder, kv_pool: MHATokenToKVPool, max_tokens: int, use_graph: bool = True):
         c = dec.cfg
         self.dec, self.cfg, self.kv = dec, c, kv_pool
         self.max_tokens = max_tokens
@@ -54,6 +54,16 @@ class LlamaPrefill:
         self.workspace = torch.zeros(ws, dtype=torch.uint8, device=dev)
         self.logits = torch.empty(1, c.vocab, dtype=dt, device=dev)
         self.next_id = torch.zeros(1, dtype=torch.int64, device=dev)
+        # fixed-address inputs of the captured single-request extends
+        self.use_graph = use_graph
+        self.graphs = {}
+        g = min(T, DEQUANT_GEMM_MIN_TOKENS)
+        self.g_ids = torch.zeros(g, dtype=torch.int64, device=dev)
+        self.g_pos = torch.zeros(g, dtype=torch.int64, device=dev)
+        self.g_loc = torch.zeros(g, dtype=torch.int64, device=dev)
+        self.g_qo = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.g_kp = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.g_ki = torch.zeros(max(T, 1), dtype=torch.int32, device=dev)
 
     def _linear(self, w, x, out):
         T = x.shape[0]
@@ -72,11 +82,39 @@ class LlamaPrefill:
                qo_indptr: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor, max_extend_len: int):
         """One extend forward over T = len(input_ids) new tokens of the requests described by the indptr arrays
         (ForwardMetadata of the attention backend); returns the hidden states [T, hidden] after the last layer's MLP
-        (before the final residual add and norm)."""
-        c = self.cfg
+        (before the final residual add and norm).
+
+        Single-request extends below the dequantise-then-GEMM switch (the tail of a request whose prefix came from the
+        cache: ≈290 launches of a few microseconds each) are replayed from a HIP graph captured once per token count;
+        the graph reads its inputs from fixed buffers, as the decode graphs do
+        (model_executor/cuda_graph_runner.py)."""
         T = input_ids.shape[0]
         if T > self.max_tokens:
             raise ValueError(f"extend of {T} tokens, buffers hold {self.max_tokens}")
+        single = qo_indptr.numel() == 2 and max_extend_len == T
+        if not (self.use_graph and single and T < DEQUANT_GEMM_MIN_TOKENS and kv_indices.numel() <= self.g_ki.numel()):
+            return self._extend(input_ids, positions, out_cache_loc, qo_indptr, kv_indptr, kv_indices, max_extend_len)
+        self.g_ids[:T].copy_(input_ids)
+        self.g_pos[:T].copy_(positions)
+        self.g_loc[:T].copy_(out_cache_loc)
+        self.g_qo.copy_(qo_indptr)
+        self.g_kp.copy_(kv_indptr)
+        self.g_ki[: kv_indices.numel()].copy_(kv_indices)
+        g = self.graphs.get(T)
+        if g is None:
+            args = (self.g_ids[:T], self.g_pos[:T], self.g_loc[:T], self.g_qo, self.g_kp, self.g_ki, T)
+            self._extend(*args)                      # first touch outside the capture (lazy initialisations)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._extend(*args)
+            self.graphs[T] = g
+        g.replay()
+        return self.hidden[:T], self.residual[:T]
+
+    def _extend(self, input_ids, positions, out_cache_loc, qo_indptr, kv_indptr, kv_indices, max_extend_len):
+        c = self.cfg
+        T = input_ids.shape[0]
         hidden, residual = self.hidden[:T], self.residual[:T]
         qkv, attn_out = self.qkv[:T], self.attn_out[:T]
         gate_up, act = self.gate_up[:T], self.act[:T]
@@ -133,7 +171,8 @@ class _Req:
 class PrefixCacheHarness:
     """One request at a time through match_prefix -> alloc -> extend -> first token -> cache_finished_req."""
 
-    def __init__(self, dec: LlamaDecoder, pool_tokens: int, max_ctx: int, judge=None, compat_fork: bool = True):
+    def __init__(self, dec: LlamaDecoder, pool_tokens: int, max_ctx: int, judge=None, compat_fork: bool = True,
+                 use_graph: bool = True):
         c = dec.cfg
         dev = dec.device
         self.dec = dec
@@ -141,7 +180,7 @@ class PrefixCacheHarness:
         self.alloc = TokenToKVPoolAllocator(pool_tokens, dec.dtype, dev, self.kv)
         self.req_pool = ReqToTokenPool(8, max_ctx, dev)
         self.tree = RadixCache(self.req_pool, self.alloc, 1, judge, compat_fork=compat_fork)
-        self.model = LlamaPrefill(dec, self.kv, max_ctx)
+        self.model = LlamaPrefill(dec, self.kv, max_ctx, use_graph)
         self.dev = dev
 
     def serve_first_token(self, token_ids: List[int], user_id, text: str = "", finish: bool = True):

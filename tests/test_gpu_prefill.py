@@ -138,3 +138,29 @@ def test_safekv_private_prefix_is_owner_only():
         assert pre_owner == 1024
         assert pre_other == want_other
         judge.close()
+
+
+def test_graph_replay_equals_eager():
+    """The captured single-request extend gives the bits of the eager one, on the capture call and on replays with
+    other tokens, another prefix length and the same token count."""
+    from sglang_security_amd.prefill_runner import PrefixCacheHarness
+
+    dec = _tiny("awq")
+    g = torch.Generator().manual_seed(9)
+    rnd = lambda n: torch.randint(0, dec.cfg.vocab, (n,), generator=g).tolist()
+    shared = rnd(1024)
+    reqs = [shared + rnd(30), shared + rnd(30), shared[:512] + rnd(542), shared + rnd(30), rnd(30)]
+    outs = []
+    for use_graph in (True, False):
+        h = PrefixCacheHarness(dec, 16384, 2048, None, use_graph=use_graph)
+        got = []
+        for r in reqs:
+            tok, pre, _ = h.serve_first_token(r, None)
+            ext = len(r) - pre
+            got.append((pre, int(tok.item()), h.model.hidden[:ext].clone(), h.model.residual[:ext].clone()))
+        outs.append(got)
+        if use_graph:
+            assert 30 in h.model.graphs                      # requests 2, 4 and 5 extend 30 tokens
+    for a, b in zip(*outs):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
