@@ -32,7 +32,8 @@ DEQUANT_GEMM_MIN_TOKENS = 256  # awq.py FP16_MATMUL_HEURISTIC_CONDITION
 class LlamaPrefill:
     """Extend forward over the weights of a LlamaDecoder and the buffers of an MHATokenToKVPool."""
 
-    def __init__(self, dec: LlamaDecoder, kv_pool: MHATokenToKVPool, max_tokens: int, use_graph: bool = True):
+    def __init__(self, dec: LlamaDecoder, kv_pool: MHATokenToKVPool, max_tokens: int, use_graph: bool = True,
+                 resident_bf16: bool = False):
         c = dec.cfg
         self.dec, self.cfg, self.kv = dec, c, kv_pool
         self.max_tokens = max_tokens
@@ -54,6 +55,10 @@ class LlamaPrefill:
         self.workspace = torch.zeros(ws, dtype=torch.uint8, device=dev)
         self.logits = torch.empty(1, c.vocab, dtype=dt, device=dev)
         self.next_id = torch.zeros(1, dtype=torch.int64, device=dev)
+        # resident_bf16: keep a dequantised copy of every AWQ weight for the large-batch path (2 bytes per weight on top
+        # of the int4 tensors: 14 GB for Llama-3-8B, affordable next to 288 GB of HBM) instead of dequantising per call
+        self.resident_bf16 = resident_bf16
+        self._dense = {}
         # fixed-address inputs of the captured single-request extends
         self.use_graph = use_graph
         self.graphs = {}
@@ -69,7 +74,13 @@ class LlamaPrefill:
         T = x.shape[0]
         if isinstance(w, _AwqLinear):
             if T >= DEQUANT_GEMM_MIN_TOKENS:
-                torch.matmul(x, ops.awq_dequantize_packed(w.packed, w.scales, w.qzeros), out=out)
+                if self.resident_bf16:
+                    wd = self._dense.get(id(w))
+                    if wd is None:
+                        wd = self._dense[id(w)] = ops.awq_dequantize_packed(w.packed, w.scales, w.qzeros)
+                else:
+                    wd = ops.awq_dequantize_packed(w.packed, w.scales, w.qzeros)
+                torch.matmul(x, wd, out=out)
             else:
                 ops.awq_gemm(x, w.packed, w.scales, w.qzeros, None, out, self.workspace)
         elif isinstance(w, _DenseLinear):
@@ -172,7 +183,7 @@ class PrefixCacheHarness:
     """One request at a time through match_prefix -> alloc -> extend -> first token -> cache_finished_req."""
 
     def __init__(self, dec: LlamaDecoder, pool_tokens: int, max_ctx: int, judge=None, compat_fork: bool = True,
-                 use_graph: bool = True):
+                 use_graph: bool = True, resident_bf16: bool = False):
         c = dec.cfg
         dev = dec.device
         self.dec = dec
@@ -180,7 +191,7 @@ class PrefixCacheHarness:
         self.alloc = TokenToKVPoolAllocator(pool_tokens, dec.dtype, dev, self.kv)
         self.req_pool = ReqToTokenPool(8, max_ctx, dev)
         self.tree = RadixCache(self.req_pool, self.alloc, 1, judge, compat_fork=compat_fork)
-        self.model = LlamaPrefill(dec, self.kv, max_ctx, use_graph)
+        self.model = LlamaPrefill(dec, self.kv, max_ctx, use_graph, resident_bf16)
         self.dev = dev
 
     def serve_first_token(self, token_ids: List[int], user_id, text: str = "", finish: bool = True):
@@ -221,7 +232,7 @@ class PrefixCacheHarness:
 
 
 def ttft_experiment(dec: LlamaDecoder, prefix_len: int, suffix_len: int, pool_tokens: int = 16384, seed: int = 0,
-                    repeats: int = 3) -> dict:
+                    repeats: int = 3, resident_bf16: bool = False) -> dict:
     """Time to first token of a request whose first `prefix_len` tokens another user has just sent, with the cached
     nodes public and with SafeKV holding them private, next to the cold request and to the owner's own re-use.
     Wall-clock per request, host work included (match_prefix, allocation, metadata), device synchronised on both
@@ -237,7 +248,7 @@ def ttft_experiment(dec: LlamaDecoder, prefix_len: int, suffix_len: int, pool_to
     out = {}
     for mode, is_private in (("public", False), ("private", True)):
         judge = PrivateJudgeClient(lambda text, p=is_private: p, num_workers=1)
-        h = PrefixCacheHarness(dec, pool_tokens, prefix_len + suffix_len + 8, judge)
+        h = PrefixCacheHarness(dec, pool_tokens, prefix_len + suffix_len + 8, judge, resident_bf16=resident_bf16)
         cold, other, owner, hits = [], [], [], []
         for r in range(repeats + 1):                     # round 0 warms kernels, GEMM heuristics and the allocator
             h.tree.reset()

@@ -16,7 +16,8 @@ ap.add_argument("--prefix", type=int, default=1024)
 ap.add_argument("--suffix", type=int, default=128)
 ap.add_argument("--quant", default="awq")
 ap.add_argument("--tiny", action="store_true")
+ap.add_argument("--resident-bf16", action="store_true", help="keep a dequantised copy of the weights for the prefill GEMMs")
 args = ap.parse_args()
 cfg = LlamaConfig.tiny(args.quant) if args.tiny else LlamaConfig.llama3_8b(args.quant)
 dec = LlamaDecoder(cfg, 1, 2, 16, device="cuda")
-print(json.dumps(ttft_experiment(dec, args.prefix, args.suffix)))
+print(json.dumps(ttft_experiment(dec, args.prefix, args.suffix, resident_bf16=args.resident_bf16)))
