@@ -647,18 +647,27 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     xoff[j] = (uint32_t)(2 * (min(m0 + row, M - 1) * x_stride + 128 * (p >> 4) + 8 * (i16 ^ (row & 15))) + 3072 -
                          1024 * (j & 3));
   }
+  // four 1-KiB pieces as raw instructions in the scalar-base form (uniform 64-bit base in SGPRs, 32-bit lane offset,
+  // instruction offset): through the builtin every piece costs two 64-bit vector adds for its address
+  auto glds_quad = [&](const char* src, char* dst, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+    const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)dst;
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %5\n\t"
+        "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
+        "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
+        "global_load_lds_dwordx4 %4, %5 offset:3072"
+        :
+        : "s"(lds_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(src)
+        : "memory", "m0");
+  };
   auto issue_x = [&](int stage, int buf) {
     const char* src = reinterpret_cast<const char*>(x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK) - 3072;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024;
     // eight 1-KiB pieces, two LDS bases (the instruction offset reaches 4095)
-    glds16_off<0>(src + xoff[0], dst);
-    glds16_off<1024>(src + xoff[1], dst);
-    glds16_off<2048>(src + xoff[2], dst);
-    glds16_off<3072>(src + xoff[3], dst);
-    glds16_off<0>(src + xoff[4], dst + 4096);
-    glds16_off<1024>(src + xoff[5], dst + 4096);
-    glds16_off<2048>(src + xoff[6], dst + 4096);
-    glds16_off<3072>(src + xoff[7], dst + 4096);
+    glds_quad(src, dst, xoff[0], xoff[1], xoff[2], xoff[3]);
+    glds_quad(src, dst + 4096, xoff[4], xoff[5], xoff[6], xoff[7]);
     if constexpr (XS_EXT) {
       // this wave's group of the stage: 64 row sums, one per lane, into the wave's own slot
       const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
@@ -672,10 +681,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   auto issue_x_half = [&](int stage, int buf, int half) {
     const char* src = reinterpret_cast<const char*>(x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK) - 3072;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024 + half * 4096;
-    glds16_off<0>(src + xoff[4 * half + 0], dst);
-    glds16_off<1024>(src + xoff[4 * half + 1], dst);
-    glds16_off<2048>(src + xoff[4 * half + 2], dst);
-    glds16_off<3072>(src + xoff[4 * half + 3], dst);
+    glds_quad(src, dst, xoff[4 * half + 0], xoff[4 * half + 1], xoff[4 * half + 2], xoff[4 * half + 3]);
     if constexpr (XS_EXT) {
       if (half == 1) {
         const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
