@@ -492,6 +492,13 @@ SGLK_API int sglk_tree_speculative_sampling_target_only(
     int num_draft_tokens, int total_draft_tokens, int vocab, float threshold_single, float threshold_acc,
     void* stream);
 
+/* Per-segment bit packing, least significant bit first: segment_packbits, sgl-kernel/csrc/speculative/packbit.cu:25-48
+ * (flashinfer's SegmentPackBits with BitOrder::kLittle; the draft-tree mask for backends that take it packed).
+ * x bool (1 byte) flat, input_indptr / output_indptr int32 [batch + 1], y uint8; segment i writes
+ * ceil(len_i / 8) bytes at output_indptr[i] (never past output_indptr[i + 1]). */
+SGLK_API int sglk_segment_packbits(const uint8_t* x, const int32_t* input_indptr,
+                                   const int32_t* output_indptr, uint8_t* y, int batch, void* stream);
+
 /* ------------------------------------------------------------------ C1: custom all-reduce ----- */
 
 /* One-/two-stage peer-to-peer all-reduce over xGMI on IPC-mapped buffers.

@@ -228,6 +228,28 @@ __global__ void __launch_bounds__(kSpecThreads) tree_spec_sampling_kernel(
   if (tid == 0 && s_last >= 0) predicts[s_last] = s_pick;
 }
 
+// Bytes of bits per segment, least significant bit first (numpy.packbits(..., bitorder="little") applied to every
+// segment on its own): segment i reads x[input_indptr[i], input_indptr[i + 1]) and writes ceil(len / 8) bytes at
+// y[output_indptr[i]].  One block per segment.
+__global__ void __launch_bounds__(256) segment_packbits_kernel(const uint8_t* __restrict__ x,
+                                                               const int32_t* __restrict__ input_indptr,
+                                                               const int32_t* __restrict__ output_indptr,
+                                                               uint8_t* __restrict__ y) {
+  const int seg = blockIdx.x;
+  const int64_t in0 = input_indptr[seg];
+  const int len = input_indptr[seg + 1] - input_indptr[seg];
+  const int64_t out0 = output_indptr[seg];
+  const int room = output_indptr[seg + 1] - output_indptr[seg];
+  const int nbytes = min((len + 7) / 8, room);
+  for (int k = threadIdx.x; k < nbytes; k += 256) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (8 * k + j < len && x[in0 + 8 * k + j]) v |= 1u << j;
+    y[out0 + k] = (uint8_t)v;
+  }
+}
+
 }  // namespace
 }  // namespace sglk
 
@@ -289,6 +311,17 @@ int sglk_tree_speculative_sampling_target_only(int32_t* predicts, int32_t* accep
                      uniform_samples, target_probs, draft_probs, num_spec_step, num_draft_tokens, vocab, total_draft_tokens,
                      threshold_single,
                      fmaxf(threshold_acc, 1e-9f));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_segment_packbits(const uint8_t* x, const int32_t* input_indptr, const int32_t* output_indptr, uint8_t* y,
+                          int batch, void* stream) {
+  SGLK_CHECK(batch >= 0, "segment_packbits: bad batch");
+  if (batch == 0) return SGLK_OK;
+  SGLK_CHECK(x && input_indptr && output_indptr && y, "segment_packbits: null pointer");
+  hipLaunchKernelGGL(segment_packbits_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, x, input_indptr,
+                     output_indptr, y);
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -869,3 +869,19 @@ def tree_speculative_sampling_target_only(predicts, accept_index, accept_token_n
         _ptr(predicts), _ptr(accept_index), _ptr(accept_token_num), _ptr(candidates), _ptr(retrive_index),
         _ptr(retrive_next_token), _ptr(retrive_next_sibling), _ptr(uniform_samples), _ptr(target_probs), _ptr(draft_probs),
         bs, steps, n, predicts.numel(), vocab, float(threshold_single), float(threshold_acc), _stream(candidates)), name)
+
+
+def segment_packbits(x, input_indptr, output_indptr, y):
+    """In place, arguments as sgl_kernel.segment_packbits (speculative.py:89-101)."""
+    name = "segment_packbits"
+    _need_gpu(x, input_indptr, output_indptr, y)
+    xb = x.view(torch.uint8) if x.dtype == torch.bool else x
+    if xb.dtype != torch.uint8 or y.dtype != torch.uint8 or not (xb.is_contiguous() and y.is_contiguous()):
+        raise SglkError(f"{name}: x must be contiguous bool / uint8 and y contiguous uint8")
+    for t in (input_indptr, output_indptr):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise SglkError(f"{name}: indptr arrays must be contiguous int32")
+    batch = input_indptr.numel() - 1
+    if output_indptr.numel() != batch + 1:
+        raise SglkError(f"{name}: output_indptr must have batch + 1 entries")
+    check(lib().sglk_segment_packbits(_ptr(xb), _ptr(input_indptr), _ptr(output_indptr), _ptr(y), batch, _stream(x)), name)

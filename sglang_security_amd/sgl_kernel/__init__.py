@@ -25,7 +25,7 @@ __all__ = [
     "sgl_per_tensor_quant_fp8", "moe_align_block_size", "topk_softmax", "top_k_renorm_probs", "top_k_renorm_prob",
     "top_p_renorm_probs", "top_p_renorm_prob", "top_p_sampling_from_probs", "top_k_top_p_sampling_from_probs",
     "min_p_sampling_from_probs", "build_tree_kernel_efficient", "verify_tree_greedy",
-    "tree_speculative_sampling_target_only", "merge_state", "merge_state_v2", "install",
+    "tree_speculative_sampling_target_only", "segment_packbits", "merge_state", "merge_state_v2", "install",
 ]
 
 
@@ -195,6 +195,11 @@ def tree_speculative_sampling_target_only(predicts, accept_index, accept_token_n
     _ops.tree_speculative_sampling_target_only(predicts, accept_index, accept_token_num, candidates, retrive_index,
                                                retrive_next_token, retrive_next_sibling, uniform_samples, target_probs,
                                                draft_probs, threshold_single, threshold_acc, deterministic)
+
+
+def segment_packbits(x, input_indptr, output_indptr, y) -> None:
+    """speculative.py:89-101."""
+    _ops.segment_packbits(x, input_indptr, output_indptr, y)
 
 
 # ---- moe.py -------------------------------------------------------------------------------------------------

@@ -251,3 +251,22 @@ def test_tree_helpers_empty_batch():
     e64 = lambda *s: torch.empty(*s, dtype=torch.int64, device=DEV)
     sk.build_tree_kernel_efficient(e64(0, 13), e64(0, 7), e32(0), torch.empty(0, dtype=torch.bool, device=DEV), e64(0),
                                    e64(0, 8), e64(0, 8), e64(0, 8), 4, 4, 8)
+
+
+@pytest.mark.parametrize("lens", [[1], [8, 9, 0, 64, 7], [1000, 3, 129]])
+def test_segment_packbits(lens):
+    """Every segment equals numpy.packbits(bitorder="little") of its bits (the definition flashinfer's SegmentPackBits
+    follows; flashinfer itself is not in the reference tree: parity unpinned beyond that definition)."""
+    import numpy as np
+    import sglang_security_amd.sgl_kernel as sk
+
+    g = torch.Generator().manual_seed(sum(lens))
+    x = torch.rand(sum(lens), generator=g) < 0.5
+    iptr = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32)
+    olen = [(n + 7) // 8 for n in lens]
+    optr = torch.tensor([0] + list(np.cumsum(olen)), dtype=torch.int32)
+    y = torch.full((sum(olen),), 0xAA, dtype=torch.uint8, device=DEV)
+    sk.segment_packbits(x.to(DEV), iptr.to(DEV), optr.to(DEV), y)
+    want = np.concatenate([np.packbits(x[iptr[i]: iptr[i + 1]].numpy(), bitorder="little") for i in range(len(lens))]
+                          + [np.zeros(0, dtype=np.uint8)])
+    assert y.cpu().numpy().tolist() == want.tolist()
