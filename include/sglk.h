@@ -422,6 +422,16 @@ SGLK_API int sglk_topk_softmax(const void* gating_output, float* topk_weights, i
                                int32_t* token_expert_indices, int num_tokens, int num_experts,
                                int topk, int64_t gating_stride, int dtype, void* stream);
 
+/* Grouped, bias-corrected top-k gate: moe_fused_gate, sgl-kernel/csrc/moe/moe_fused_gate.cu:52-245,362-500
+ * (== biased_grouped_topk, python/sglang/srt/layers/moe/topk.py:155-215).  input [rows, num_experts] and bias
+ * [num_experts] in fp32 / fp16 / bf16; output fp32 and indices int32 [rows, topk].  n_share_experts_fusion > 0: the
+ * last slot is the shared expert num_experts + row % n_share with weight sum / routed_scaling_factor.  Any
+ * num_experts up to 1024 that num_expert_group (<= 64) divides (the reference: powers of two, 32 per group at most). */
+SGLK_API int sglk_moe_fused_gate(const void* input, const void* bias, float* output, int32_t* indices,
+                                 int num_rows, int num_experts, int num_expert_group, int topk_group,
+                                 int topk, int n_share_experts_fusion, float routed_scaling_factor,
+                                 int64_t input_stride, int dtype, void* stream);
+
 /* The block-scaled product with the same scratch buffer (sglk_fp8_mm_workspace_bytes()): K split over blocks for
  * narrow outputs; the partials are already scaled, the second launch adds them up in split order. */
 SGLK_API int sglk_fp8_blockwise_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a,

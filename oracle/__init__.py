@@ -519,3 +519,35 @@ def extend_attention_masked(q_ext, k_ext, v_ext, k_buffer, v_buffer, qo_indptr, 
             s = s.masked_fill(~allow, float("-inf"))
             o[qo[b]: qo[b + 1], h] = torch.softmax(s, -1) @ V
     return o
+
+
+# ---------------------------------------------------------------------------------------------- grouped top-k gate
+def moe_fused_gate(gating, bias, topk, num_expert_group, topk_group, n_share_experts_fusion=0,
+                   routed_scaling_factor=1.0):
+    """The grouped, bias-corrected top-k gate with the arithmetic and the tie rules of the reference's kernel
+    (sgl-kernel/csrc/moe/moe_fused_gate.cu:102-245): sigmoid, bias add and the sum of a group's two best choice scores
+    are rounded to the input type (:104-112,146); the groups kept are the topk_group best, a tie going to the lower
+    group (:149-157 removes the higher one first); experts are taken best first, a tie going to the lower id
+    (:193-199); weights are the rounded sigmoids over their fp32 sum, the shared expert of row r is
+    num_experts + r % n_share at sum / routed_scaling_factor (:225-243).  For fp32 inputs without ties this is
+    biased_grouped_topk_impl(renormalize=True) of python/sglang/srt/layers/moe/topk.py:155-215."""
+    g = gating.detach().cpu()
+    dt = g.dtype
+    sig = (1.0 / (1.0 + torch.exp(-g.float()))).to(dt)
+    n, E = sig.shape
+    choice = (sig.float() + bias.detach().cpu().float().unsqueeze(0)).to(dt).float()
+    top2 = choice.view(n, num_expert_group, -1).topk(2, dim=-1)[0]
+    gsum = (top2[..., 0] + top2[..., 1]).to(dt).float()
+    order = torch.sort(gsum, dim=-1, descending=True, stable=True)[1]
+    keep = torch.zeros(n, num_expert_group, dtype=torch.bool)
+    keep.scatter_(1, order[:, :topk_group], True)
+    mask = keep.unsqueeze(-1).expand(n, num_expert_group, E // num_expert_group).reshape(n, E)
+    cand = choice.masked_fill(~mask, float("-inf"))
+    k_routed = topk - (1 if n_share_experts_fusion else 0)
+    ids = torch.sort(cand, dim=-1, descending=True, stable=True)[1][:, :k_routed]
+    w = sig.float().gather(1, ids)
+    ssum = w.sum(dim=-1, keepdim=True)
+    if n_share_experts_fusion:
+        ids = torch.cat([ids, (E + torch.arange(n) % n_share_experts_fusion).unsqueeze(1)], dim=1)
+        w = torch.cat([w, ssum / routed_scaling_factor], dim=1)
+    return (w / ssum).float(), ids.to(torch.int32)

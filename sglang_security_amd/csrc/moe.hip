@@ -135,6 +135,104 @@ __global__ void __launch_bounds__(256) topk_softmax_kernel(const void* __restric
   }
 }
 
+// Grouped, bias-corrected top-k gate of DeepSeek-V3 style routers (sgl-kernel/csrc/moe/moe_fused_gate.cu:52-245 ==
+// biased_grouped_topk_impl, python/sglang/srt/layers/moe/topk.py:155-215): scores = sigmoid(logits); choice scores =
+// scores + bias; a group's score is the sum of its two best choice scores; all but the topk_group best groups are
+// dropped (lowest first, ties: the higher group goes first); the topk best choice scores of the groups kept win
+// (ties: the lower expert id); weights are the plain scores, normalised by their sum.  With n_share > 0 the last of
+// the topk slots names a shared expert (E + row % n_share) weighing sum / routed_scaling_factor before the
+// normalisation.  Sigmoid, bias add and group sum are rounded to the input type, as the reference computes in it.
+// One wave per row; the row lives in LDS.
+static constexpr int kGateMaxExperts = 1024;
+template <typename T>
+__global__ void __launch_bounds__(256) moe_fused_gate_kernel(const void* __restrict__ logits, const void* __restrict__ bias,
+                                                             float* __restrict__ out, int32_t* __restrict__ idx, int rows,
+                                                             int E, int ng, int topk_group, int topk, int n_share,
+                                                             float routed_scaling, int64_t in_stride) {
+  extern __shared__ float gatebuf[];  // per wave: sig[E], sc[E], wout[64], alive[64]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + w;
+  if (row >= rows) return;  // no block-level synchronisation below
+  float* sig = gatebuf + (size_t)w * (2 * E + 128);
+  float* sc = sig + E;
+  float* wout = sc + E;
+  int* alive = reinterpret_cast<int*>(wout + 64);
+  auto rnd = [](float v) { return Conv<T>::to_f32(Conv<T>::from_f32(v)); };
+  for (int e = lane; e < E; e += 64) {
+    const float x = ld<T>(logits, (int64_t)row * in_stride + e);
+    const float s = rnd(1.0f / (1.0f + expf(-x)));
+    sig[e] = s;
+    sc[e] = rnd(s + ld<T>(bias, e));
+  }
+  // group scores: lane g scans group g
+  const int gs = E / ng;
+  float gsum = INFINITY;  // lanes without a group never win the arg-min
+  if (lane < ng) {
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int e = lane * gs; e < (lane + 1) * gs; ++e) {
+      const float v = sc[e];
+      if (v > m1) {
+        m2 = m1;
+        m1 = v;
+      } else if (v > m2) {
+        m2 = v;
+      }
+    }
+    gsum = rnd(m1 + m2);
+  }
+  int keep = lane < ng ? 1 : 0;
+  for (int r = 0; r < ng - topk_group; ++r) {
+    float v = keep ? gsum : INFINITY;
+    int gi = keep ? lane : -1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(v, o, 64);
+      const int oi = __shfl_xor(gi, o, 64);
+      if (ov < v || (ov == v && oi > gi)) {
+        v = ov;
+        gi = oi;
+      }
+    }
+    if (lane == gi) keep = 0;
+  }
+  if (lane < ng) alive[lane] = keep;
+  const int k_routed = topk - (n_share > 0 ? 1 : 0);
+  float sum = 0.f;
+  for (int j = 0; j < k_routed; ++j) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int e = lane; e < E; e += 64) {
+      const float x = sc[e];
+      if (alive[e / gs] && x > best) {  // ascending e per lane: the first maximum stays
+        best = x;
+        bi = e;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) {
+        best = ob;
+        bi = oi;
+      }
+    }
+    if (bi >= E) bi = 0;  // nothing left to choose from (NaN rows, topk beyond the kept groups): stay in range
+    const float wgt = sig[bi];
+    sum += wgt;
+    if (lane == 0) {
+      wout[j] = wgt;
+      idx[(int64_t)row * topk + j] = bi;
+    }
+    if (lane == (bi & 63)) sc[bi] = -INFINITY;  // the owner lane retires the winner; same-wave LDS stays in order
+  }
+  if (n_share > 0 && lane == 0) {
+    wout[k_routed] = sum / routed_scaling;
+    idx[(int64_t)row * topk + k_routed] = E + row % n_share;
+  }
+  if (lane < topk) out[(int64_t)row * topk + lane] = wout[lane] / sum;
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -175,6 +273,32 @@ int sglk_topk_softmax(const void* gating_output, float* topk_weights, int32_t* t
                       hipLaunchKernelGGL((topk_softmax_kernel<T>), dim3((num_tokens + 3) / 4), dim3(256), lds,
                                          (hipStream_t)stream, gating_output, topk_weights, topk_ids, token_expert_indices,
                                          num_tokens, num_experts, topk, gating_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_moe_fused_gate(const void* input, const void* bias, float* output, int32_t* indices, int num_rows,
+                        int num_experts, int num_expert_group, int topk_group, int topk, int n_share_experts_fusion,
+                        float routed_scaling_factor, int64_t input_stride, int dtype, void* stream) {
+  SGLK_CHECK(num_rows >= 0 && num_experts > 0 && num_experts <= kGateMaxExperts, "moe_fused_gate: num_experts=%d not in 1..%d",
+             num_experts, kGateMaxExperts);
+  SGLK_CHECK(num_expert_group > 0 && num_expert_group <= 64 && num_experts % num_expert_group == 0,
+             "moe_fused_gate: num_expert_group=%d must divide num_experts and be at most 64", num_expert_group);
+  SGLK_CHECK(topk_group > 0 && topk_group <= num_expert_group, "moe_fused_gate: bad topk_group");
+  SGLK_CHECK(topk > 0 && topk <= 64 && n_share_experts_fusion >= 0, "moe_fused_gate: topk=%d not in 1..64", topk);
+  SGLK_CHECK(topk - (n_share_experts_fusion > 0 ? 1 : 0) <= topk_group * (num_experts / num_expert_group) &&
+                 topk - (n_share_experts_fusion > 0 ? 1 : 0) >= 1,
+             "moe_fused_gate: topk exceeds the experts of the groups kept");
+  SGLK_CHECK(n_share_experts_fusion == 0 || routed_scaling_factor != 0.f, "moe_fused_gate: routed_scaling_factor is 0");
+  SGLK_CHECK(input_stride >= num_experts, "moe_fused_gate: row stride smaller than the row");
+  if (num_rows == 0) return SGLK_OK;
+  SGLK_CHECK(input && bias && output && indices, "moe_fused_gate: null pointer");
+  const size_t lds = (size_t)4 * (2 * num_experts + 128) * sizeof(float);
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((moe_fused_gate_kernel<T>), dim3((num_rows + 3) / 4), dim3(256), lds,
+                                         (hipStream_t)stream, input, bias, output, indices, num_rows, num_experts,
+                                         num_expert_group, topk_group, topk, n_share_experts_fusion,
+                                         routed_scaling_factor, input_stride));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

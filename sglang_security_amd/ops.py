@@ -885,3 +885,21 @@ def segment_packbits(x, input_indptr, output_indptr, y):
     if output_indptr.numel() != batch + 1:
         raise SglkError(f"{name}: output_indptr must have batch + 1 entries")
     check(lib().sglk_segment_packbits(_ptr(xb), _ptr(input_indptr), _ptr(output_indptr), _ptr(y), batch, _stream(x)), name)
+
+
+def moe_fused_gate(input_tensor, bias, num_expert_group, topk_group, topk, n_share_experts_fusion=0,
+                   routed_scaling_factor=0.0):
+    """-> (weights fp32 [rows, topk], expert ids int32 [rows, topk]); sgl_kernel.moe_fused_gate (moe.py:37-62)."""
+    name = "moe_fused_gate"
+    _need_gpu(input_tensor, bias)
+    if input_tensor.dim() != 2 or input_tensor.stride(1) != 1 or bias.dtype != input_tensor.dtype or not bias.is_contiguous():
+        raise SglkError(f"{name}: input must be [rows, experts] with unit inner stride, bias [experts] of the same dtype")
+    rows, E = input_tensor.shape
+    if bias.numel() != E:
+        raise SglkError(f"{name}: bias must have one entry per expert")
+    out = torch.empty((rows, topk), dtype=torch.float32, device=input_tensor.device)
+    idx = torch.empty((rows, topk), dtype=torch.int32, device=input_tensor.device)
+    check(lib().sglk_moe_fused_gate(_ptr(input_tensor), _ptr(bias), _ptr(out), _ptr(idx), rows, E, int(num_expert_group),
+                                    int(topk_group), int(topk), int(n_share_experts_fusion), float(routed_scaling_factor),
+                                    input_tensor.stride(0), dtype_code(input_tensor.dtype), _stream(input_tensor)), name)
+    return out, idx

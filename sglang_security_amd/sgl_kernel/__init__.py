@@ -25,7 +25,7 @@ __all__ = [
     "sgl_per_tensor_quant_fp8", "moe_align_block_size", "topk_softmax", "top_k_renorm_probs", "top_k_renorm_prob",
     "top_p_renorm_probs", "top_p_renorm_prob", "top_p_sampling_from_probs", "top_k_top_p_sampling_from_probs",
     "min_p_sampling_from_probs", "build_tree_kernel_efficient", "verify_tree_greedy",
-    "tree_speculative_sampling_target_only", "segment_packbits", "merge_state", "merge_state_v2", "install",
+    "tree_speculative_sampling_target_only", "segment_packbits", "moe_fused_gate", "merge_state", "merge_state_v2", "install",
 ]
 
 
@@ -208,6 +208,13 @@ def moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, ex
     """moe.py:4-23."""
     _ops.moe_align_block_size(topk_ids, num_experts, block_size, sorted_token_ids, experts_ids, num_tokens_post_pad,
                               token_cnts_buffer, cumsum_buffer)
+
+
+def moe_fused_gate(input_tensor, bias, num_expert_group, topk_group, topk, n_share_experts_fusion=0,
+                   routed_scaling_factor=0):
+    """moe.py:37-62."""
+    return _ops.moe_fused_gate(input_tensor, bias, num_expert_group, topk_group, topk, n_share_experts_fusion,
+                               routed_scaling_factor)
 
 
 def topk_softmax(topk_weights, topk_ids, token_expert_indices, gating_output) -> None:

@@ -30,6 +30,7 @@ _SCHEMAS = {
     "gelu_tanh_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
     "gelu_and_mul": "(Tensor! out, Tensor input, int cuda_stream) -> ()",
     "apply_rope_pos_ids_cos_sin_cache": "(Tensor q, Tensor k, Tensor! q_rope, Tensor! k_rope, Tensor cos_sin_cache, Tensor pos_ids, bool interleave, int cuda_stream) -> ()",
+    "moe_fused_gate": "(Tensor input, Tensor bias, int num_expert_group, int topk_group, int topk, int n_share_experts_fusion, float routed_scaling_factor) -> Tensor[]",
     "verify_tree_greedy": "(Tensor! predicts, Tensor! accept_index, Tensor! accept_token_num, Tensor candidates, Tensor retrive_index, Tensor retrive_next_token, Tensor retrive_next_sibling, Tensor target_predict, int cuda_stream) -> ()",
     "build_tree_kernel_efficient": "(Tensor parent_list, Tensor selected_index, Tensor verified_seq_len, Tensor! tree_mask, Tensor! positions, Tensor! retrive_index, Tensor! retrive_next_token, Tensor! retrive_next_sibling, int topk, int depth, int draft_token_num) -> ()",
     "tree_speculative_sampling_target_only": "(Tensor! predicts, Tensor! accept_index, Tensor! accept_token_num, Tensor candidates, Tensor retrive_index, Tensor retrive_next_token, Tensor retrive_next_sibling, Tensor uniform_samples, Tensor target_probs, Tensor! draft_probs, float threshold_single, float threshold_acc, bool deterministic, int cuda_stream) -> ()",
@@ -71,6 +72,7 @@ _IMPLS = {
     "gelu_tanh_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 1),
     "gelu_and_mul": lambda out, x, stream: _ops.act_and_mul(_rows(out), _rows(x), 2),
     "apply_rope_pos_ids_cos_sin_cache": _rope,
+    "moe_fused_gate": lambda x, b, ng, tg, k, ns, rs: list(_ops.moe_fused_gate(x, b, ng, tg, k, ns, rs)),
     "verify_tree_greedy": lambda pr, ai, an, c, ri, nt, ns, tp, stream: _ops.verify_tree_greedy(pr, ai, an, c, ri, nt, ns, tp),
     "build_tree_kernel_efficient": lambda pl, si, sl, m, pos, ri, nt, ns, topk, depth, n: _ops.build_tree_kernel_efficient(pl, si, sl, m, pos, ri, nt, ns, topk, depth, n),
     "tree_speculative_sampling_target_only": lambda pr, ai, an, c, ri, nt, ns, u, tp, dp, ts, ta, det, stream: _ops.tree_speculative_sampling_target_only(pr, ai, an, c, ri, nt, ns, u, tp, dp, ts, ta, det),

@@ -174,3 +174,77 @@ def test_empty_inputs():
     one = torch.ones(1, device=DEV)
     assert ops.bmm_fp8(a, b, one, one, torch.bfloat16).shape == (0, 4, 16)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("seq_length", [1, 2, 7, 64, 1024, 8192])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("params", [(128, 4, 2, 4), (256, 8, 4, 8), (512, 16, 8, 16)])
+@pytest.mark.parametrize("n_share", [0, 1, 8])
+def test_moe_fused_gate(seq_length, dtype, params, n_share):
+    """The inputs of the reference's own test (sgl-kernel/tests/test_moe_fused_gate.py:8-45) against the restatement of
+    its kernel (arithmetic in the input type, its tie rules): expert ids equal slot for slot, weights to 1e-5, where
+    the reference's test (:77-88, against a torch formula that leaves ties open) compares sorted rows at 1e-2."""
+    import oracle
+    import sglang_security_amd.sgl_kernel as sk
+
+    num_experts, num_expert_group, topk_group, topk = params
+    torch.manual_seed(seq_length)
+    tensor = torch.rand((seq_length, num_experts)).to(dtype)
+    bias = torch.rand(num_experts).to(dtype)
+    topk = topk + min(1, n_share)
+    out, idx = sk.moe_fused_gate(tensor.cuda(), bias.cuda(), num_expert_group=num_expert_group, topk_group=topk_group,
+                                 topk=topk, n_share_experts_fusion=n_share, routed_scaling_factor=2.5)
+    out, idx = out.cpu(), idx.cpu()
+    ref_out, ref_idx = oracle.moe_fused_gate(tensor, bias, topk, num_expert_group, topk_group, n_share, 2.5)
+    assert out.dtype == torch.float32 and idx.dtype == torch.int32
+    # a sigmoid that lands on the other side of a rounding boundary on the CPU (expf differs in the last bit) may move
+    # a 16-bit choice score by one step and with it a tie: allow a few such rows in the large cases
+    same = (ref_idx == idx).all(dim=1)
+    assert same.float().mean().item() >= (1.0 if seq_length < 64 or dtype == torch.float32 else 0.995)
+    torch.testing.assert_close(out[same], ref_out[same], rtol=1e-5, atol=1e-6)
+    if n_share:
+        assert torch.equal(idx[:, -1].long(), num_experts + torch.arange(seq_length) % n_share)
+    k_routed = topk - min(1, n_share)
+    torch.testing.assert_close(out[:, :k_routed].sum(-1), torch.ones(seq_length), rtol=1e-5, atol=1e-5)
+
+
+def test_moe_fused_gate_matches_torch_formula_fp32():
+    """fp32 inputs have no ties: the kernel agrees with the reference's torch formula itself
+    (biased_grouped_topk_impl, topk.py:170-211), restated inline."""
+    import sglang_security_amd.sgl_kernel as sk
+
+    n, E, ng, tg, k = 333, 256, 8, 4, 8
+    g = torch.Generator().manual_seed(0)
+    x, b = torch.randn(n, E, generator=g), torch.rand(E, generator=g)
+    scores = x.sigmoid()
+    choice = scores + b
+    gs = choice.view(n, ng, -1).topk(2, dim=-1)[0].sum(-1)
+    gmask = torch.zeros_like(gs).scatter_(1, torch.topk(gs, tg, dim=-1)[1], 1)
+    smask = gmask.unsqueeze(-1).expand(n, ng, E // ng).reshape(n, -1)
+    ids = torch.topk(choice.masked_fill(~smask.bool(), float("-inf")), k, dim=-1)[1]
+    w = scores.gather(1, ids)
+    w = w / w.sum(-1, keepdim=True)
+    out, idx = sk.moe_fused_gate(x.cuda(), b.cuda(), ng, tg, k)
+    assert torch.equal(idx.cpu().long().sort()[0], ids.sort()[0])
+    torch.testing.assert_close(out.cpu().sort()[0], w.sort()[0], rtol=1e-4, atol=1e-6)
+
+
+def test_moe_fused_gate_group_limit():
+    """Experts outside the topk_group best groups never win, however large their own score."""
+    import sglang_security_amd.sgl_kernel as sk
+
+    E, ng, tg, k = 64, 8, 2, 4
+    x = torch.full((1, E), -4.0)
+    x[0, 0] = 9.0                      # group 0: one huge score, second best tiny -> group sum ~ 1.02
+    x[0, 8:10] = 2.0                   # group 1: two good scores -> ~1.76
+    x[0, 16:18] = 1.5                  # group 2: ~1.63
+    out, idx = sk.moe_fused_gate(x.cuda(), torch.zeros(E).cuda(), ng, tg, k)
+    assert sorted(idx[0].tolist()) == [8, 9, 16, 17]
+    assert abs(out.sum().item() - 1.0) < 1e-6
+
+
+def test_moe_fused_gate_empty():
+    import sglang_security_amd.sgl_kernel as sk
+
+    out, idx = sk.moe_fused_gate(torch.empty(0, 256, device="cuda"), torch.zeros(256, device="cuda"), 8, 4, 8)
+    assert out.shape == (0, 8) and idx.shape == (0, 8)

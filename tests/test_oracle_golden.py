@@ -243,3 +243,25 @@ def test_oracle_extend_masked_golden(golden, case):
                                          g["qo_indptr"], g["kv_indptr"], g["kv_indices"], g["custom_mask"],
                                          g["mask_indptr"], bool(g["skip_prefix_custom_mask"]), g["sm_scale"])
     torch.testing.assert_close(got, g["expect_triton_f32"], rtol=2e-4, atol=2e-4)
+
+
+def test_oracle_moe_fused_gate_matches_torch_formula():
+    """Without ties (fp32) the kernel restatement equals biased_grouped_topk_impl (topk.py:170-211), restated inline."""
+    import oracle
+    n, E, ng, tg, k = 200, 256, 8, 4, 8
+    g = torch.Generator().manual_seed(0)
+    x, b = torch.randn(n, E, generator=g), torch.rand(E, generator=g)
+    scores = x.sigmoid()
+    choice = scores + b
+    gs = choice.view(n, ng, -1).topk(2, dim=-1)[0].sum(-1)
+    gmask = torch.zeros_like(gs).scatter_(1, torch.topk(gs, tg, dim=-1)[1], 1)
+    smask = gmask.unsqueeze(-1).expand(n, ng, E // ng).reshape(n, -1)
+    ids = torch.topk(choice.masked_fill(~smask.bool(), float("-inf")), k, dim=-1)[1]
+    w = scores.gather(1, ids)
+    w = w / w.sum(-1, keepdim=True)
+    out, idx = oracle.moe_fused_gate(x, b, k, ng, tg)
+    assert torch.equal(idx.long(), ids)                       # torch.topk returns them best first as well
+    torch.testing.assert_close(out, w, rtol=1e-5, atol=1e-7)
+    out, idx = oracle.moe_fused_gate(x, b, k + 1, ng, tg, 4, 2.5)
+    assert torch.equal(idx[:, -1].long(), E + torch.arange(n) % 4)
+    torch.testing.assert_close(out[:, -1], torch.full((n,), 0.4))
