@@ -108,6 +108,21 @@ SGLK_API int sglk_prepare_for_decode(const int32_t* req_to_token, int64_t row_st
                                      const void* req_pool_indices, int idx_is64, void* seq_lens,
                                      int lens_is64, int64_t* positions, void* out_cache_loc,
                                      int loc_is64, int bs, void* stream);
+/* Rotary step of the absorbed-MLA decode with fused rotation (decode_attention_fwd_grouped_rope,
+ * python/sglang/srt/layers/attention/triton_ops/rocm_mla_decode_rope.py:45-202,402-440): q_out = q with the rope
+ * part (elements kv_lora_rank .. + rope_dim, the first rotary_dim of them rotated) turned at positions[b]; the rope
+ * part of each request's newest pool row (kv_indices[kv_indptr[b + 1] - 1], which the caller stored unrotated) is
+ * rotated IN PLACE in kv_buffer and copied to k_pe_out [B, rope_dim] -- the reference leaves the pool row as it is
+ * and the caller then stores k_pe_out over it (models/deepseek_v2.py:1189-1193), after which the two agree.
+ * Follow with sglk_decode_attention on q_out.  cos_sin_cache fp32 [max_pos, rotary_dim] (cos half, sin half). */
+SGLK_API int sglk_mla_rope_prepare(const void* q, void* q_out, void* kv_buffer, void* k_pe_out,
+                                   const int32_t* kv_indptr, const int32_t* kv_indices,
+                                   const float* cos_sin_cache, const int64_t* positions, int B, int H,
+                                   int kv_lora_rank, int rope_dim, int rotary_dim, int64_t q_stride_b,
+                                   int64_t q_stride_h, int64_t qo_stride_b, int64_t qo_stride_h,
+                                   int64_t kv_stride_n, int64_t kpe_stride_b, int64_t cos_sin_stride,
+                                   int is_neox, int dtype, void* stream);
+
 /* Greedy sampling: out[r] = index of the first maximum of row r (torch.argmax(logits, -1),
  * python/sglang/srt/layers/sampler.py greedy branch). */
 SGLK_API int sglk_argmax(const void* x, int64_t* out, int64_t rows, int cols, int64_t row_stride,

@@ -37,6 +37,7 @@ _SIGS = {
     "sglk_gptq_repack": (i32, [p, p, p, p, p, i32, i32, i32, i32, p]),
     "sglk_segment_packbits": (i32, [p, p, p, p, i32, p]),
     "sglk_moe_fused_gate": (i32, [p, p, p, p, i32, i32, i32, i32, i32, i32, f32, i64, i32, p]),
+    "sglk_mla_rope_prepare": (i32, [p] * 8 + [i32] * 5 + [i64] * 7 + [i32, i32, p]),
     "sglk_prepare_for_decode": (i32, [p, i64, p, i32, p, i32, p, p, i32, i32, p]),
     "sglk_argmax": (i32, [p, p, i64, i32, i64, i32, p]),
     "sglk_decode_shared_workspace_bytes": (i64, [i32, i32, i32, i32]),

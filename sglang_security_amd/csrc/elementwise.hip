@@ -570,6 +570,62 @@ __global__ void __launch_bounds__(1024) argmax_rows_kernel(const void* __restric
   }
 }
 
+// Rotary step in front of the absorbed-MLA decode with fused rotation (triton_ops/rocm_mla_decode_rope.py:116-202):
+// q_out[b, h] = q[b, h] with its rope part (elements lora .. lora + rope_dim) rotated at positions[b]; the rope part of
+// the request's newest token (pool row kv_indices[kv_indptr[b + 1] - 1], stored unrotated by the caller) is rotated
+// in place and copied to k_pe_out[b].  One block per request; a thread owns one (element, partner) pair.
+template <typename T>
+__global__ void __launch_bounds__(256) mla_rope_prepare_kernel(const void* __restrict__ q, void* __restrict__ q_out,
+                                                               void* __restrict__ kv_buffer, void* __restrict__ k_pe_out,
+                                                               const int32_t* __restrict__ kv_indptr,
+                                                               const int32_t* __restrict__ kv_indices,
+                                                               const float* __restrict__ cos_sin,
+                                                               const int64_t* __restrict__ positions, int H, int lora,
+                                                               int rope_dim, int rot_dim, int64_t q_stride_b,
+                                                               int64_t q_stride_h, int64_t qo_stride_b, int64_t qo_stride_h,
+                                                               int64_t kv_stride_n, int64_t kpe_stride_b,
+                                                               int64_t cs_stride, int neox) {
+  const int b = blockIdx.x;
+  const int64_t pos = positions[b];
+  const float* cs = cos_sin + pos * cs_stride;
+  const int half = rot_dim / 2;
+  // pair p < half: elements (p, p + half) in the neox layout, (2p, 2p + 1) interleaved; rows: heads then the key
+  const int rows = H + 1;
+  const int64_t last = (int64_t)kv_indptr[b + 1] - 1;
+  const bool has_key = last >= kv_indptr[b];
+  const int64_t loc = has_key ? kv_indices[last] : 0;
+  for (int i = threadIdx.x; i < rows * half; i += blockDim.x) {
+    const int r = i / half, p = i - r * half;
+    const int e0 = neox ? p : 2 * p, e1 = neox ? p + half : 2 * p + 1;
+    const float c = cs[p], sn = cs[half + p];
+    if (r < H) {
+      const int64_t src = (int64_t)b * q_stride_b + (int64_t)r * q_stride_h + lora;
+      const int64_t dst = (int64_t)b * qo_stride_b + (int64_t)r * qo_stride_h + lora;
+      const float x0 = ld<T>(q, src + e0), x1 = ld<T>(q, src + e1);
+      st<T>(q_out, dst + e0, x0 * c - x1 * sn);
+      st<T>(q_out, dst + e1, x1 * c + x0 * sn);
+    } else if (has_key) {
+      const int64_t src = loc * kv_stride_n + lora;
+      const float x0 = ld<T>(kv_buffer, src + e0), x1 = ld<T>(kv_buffer, src + e1);
+      const float y0 = x0 * c - x1 * sn, y1 = x1 * c + x0 * sn;
+      st<T>(kv_buffer, src + e0, y0);
+      st<T>(kv_buffer, src + e1, y1);
+      st<T>(k_pe_out, (int64_t)b * kpe_stride_b + e0, y0);
+      st<T>(k_pe_out, (int64_t)b * kpe_stride_b + e1, y1);
+    }
+  }
+  // the rest: the latent part of q and rope elements past the rotary dimension, copied
+  for (int i = threadIdx.x; i < H * (lora + rope_dim); i += blockDim.x) {
+    const int h = i / (lora + rope_dim), e = i - h * (lora + rope_dim);
+    if (e >= lora && e < lora + rot_dim) continue;
+    st<T>(q_out, (int64_t)b * qo_stride_b + (int64_t)h * qo_stride_h + e,
+          ld<T>(q, (int64_t)b * q_stride_b + (int64_t)h * q_stride_h + e));
+  }
+  if (has_key)
+    for (int e = rot_dim + threadIdx.x; e < rope_dim; e += blockDim.x)
+      st<T>(k_pe_out, (int64_t)b * kpe_stride_b + e, ld<T>(kv_buffer, loc * kv_stride_n + lora + e));
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -773,6 +829,27 @@ int sglk_argmax(const void* x, int64_t* out, int64_t rows, int cols, int64_t row
   SGLK_DISPATCH_FLOAT(dtype, T,
                       hipLaunchKernelGGL((argmax_rows_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
                                          x, out, cols, row_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_mla_rope_prepare(const void* q, void* q_out, void* kv_buffer, void* k_pe_out, const int32_t* kv_indptr,
+                          const int32_t* kv_indices, const float* cos_sin_cache, const int64_t* positions, int B, int H,
+                          int kv_lora_rank, int rope_dim, int rotary_dim, int64_t q_stride_b, int64_t q_stride_h,
+                          int64_t qo_stride_b, int64_t qo_stride_h, int64_t kv_stride_n, int64_t kpe_stride_b,
+                          int64_t cos_sin_stride, int is_neox, int dtype, void* stream) {
+  SGLK_CHECK(B >= 0 && H > 0 && kv_lora_rank >= 0 && rope_dim > 0, "mla_rope_prepare: bad shape");
+  SGLK_CHECK(rotary_dim > 0 && rotary_dim % 2 == 0 && rotary_dim <= rope_dim, "mla_rope_prepare: bad rotary dim");
+  SGLK_CHECK(cos_sin_stride >= rotary_dim && kpe_stride_b >= rope_dim && kv_stride_n >= kv_lora_rank + rope_dim,
+             "mla_rope_prepare: bad strides");
+  if (B == 0) return SGLK_OK;
+  SGLK_CHECK(q && q_out && kv_buffer && k_pe_out && kv_indptr && kv_indices && cos_sin_cache && positions,
+             "mla_rope_prepare: null pointer");
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((mla_rope_prepare_kernel<T>), dim3(B), dim3(256), 0, (hipStream_t)stream, q, q_out,
+                                         kv_buffer, k_pe_out, kv_indptr, kv_indices, cos_sin_cache, positions, H,
+                                         kv_lora_rank, rope_dim, rotary_dim, q_stride_b, q_stride_h, qo_stride_b,
+                                         qo_stride_h, kv_stride_n, kpe_stride_b, cos_sin_stride, is_neox ? 1 : 0));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

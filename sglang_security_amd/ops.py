@@ -903,3 +903,42 @@ def moe_fused_gate(input_tensor, bias, num_expert_group, topk_group, topk, n_sha
                                     int(topk_group), int(topk), int(n_share_experts_fusion), float(routed_scaling_factor),
                                     input_tensor.stride(0), dtype_code(input_tensor.dtype), _stream(input_tensor)), name)
     return out, idx
+
+
+_mla_scratch = {}
+
+
+def decode_attention_fwd_grouped_rope(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, k_pe_tokens, kv_lora_rank,
+                                      rotary_dim, cos_sin_cache, positions, attn_logits, num_kv_splits, sm_scale,
+                                      logit_cap=0.0, use_rope=False, is_neox_style=False):
+    """Same signature as triton_ops/rocm_mla_decode_rope.py:402-440.  With use_rope the rope part of q and of every
+    request's newest pool row is rotated first (the pool row in place; see sglk_mla_rope_prepare), then the absorbed-MLA
+    decode runs.  attn_logits only sizes the split count (dim 2); the kernels keep their own fp32 scratch."""
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, num_kv_splits)
+    B, H, D = q.shape
+    rope_dim = D - kv_lora_rank
+    max_kv_splits = attn_logits.shape[2]
+    Dv = v_buffer.shape[-1]
+    key = (q.device, B, H, max_kv_splits, Dv, D, q.dtype)
+    sc = _mla_scratch.get(key)
+    if sc is None:
+        sc = (torch.empty(B, H, max_kv_splits, Dv, dtype=torch.float32, device=q.device),
+              torch.empty(B, H, max_kv_splits, dtype=torch.float32, device=q.device), torch.empty_like(q))
+        _mla_scratch[key] = sc
+    logits, lse, q_rot = sc
+    if use_rope:
+        _need_gpu(k_pe_tokens, cos_sin_cache, positions)
+        cs = cos_sin_cache if cos_sin_cache.dtype == torch.float32 else cos_sin_cache.float()
+        pos = positions if positions.dtype == torch.int64 else positions.long()
+        kb = k_buffer.view(k_buffer.shape[0], -1)
+        kpe = k_pe_tokens.view(B, -1)
+        if kb.stride(1) != 1 or kpe.stride(1) != 1 or cs.stride(1) != 1 or q.stride(2) != 1:
+            raise SglkError("decode_attention_fwd_grouped_rope: rows must be contiguous")
+        check(lib().sglk_mla_rope_prepare(_ptr(q), _ptr(q_rot), _ptr(kb), _ptr(kpe), _ptr(kv_indptr), _ptr(kv_indices),
+                                          _ptr(cs), _ptr(pos), B, H, int(kv_lora_rank), rope_dim, int(rotary_dim),
+                                          q.stride(0), q.stride(1), q_rot.stride(0), q_rot.stride(1), kb.stride(0),
+                                          kpe.stride(0), cs.stride(0), 1 if is_neox_style else 0, dtype_code(q.dtype),
+                                          _stream(q)), "mla_rope_prepare")
+        q = q_rot
+    decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, logits, lse, num_kv_splits, max_kv_splits,
+                         sm_scale, logit_cap)

@@ -326,3 +326,77 @@ def test_decode_attention_rejects_bad_arguments():
         ops.decode_attention_fwd(q, kb, kb, o, ptr, ind, al, lse, ns, 2, 1.0)  # 6 heads over 4 kv heads
     with pytest.raises(SglkError):
         ops.decode_attention_fwd(q.cpu(), kb, kb, o, ptr, ind, al, lse, ns, 2, 1.0)  # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("neox", [False, True])
+@pytest.mark.parametrize("rotary_dim", [64, 32])
+def test_decode_attention_mla_fused_rope(dtype, neox, rotary_dim):
+    """decode_attention_fwd_grouped_rope (rocm_mla_decode_rope.py:402-440): rotating q's rope part and the newest
+    token's rope part inside the call equals rotating them beforehand (torch restatement of :116-202) and running
+    the plain absorbed-MLA decode; the rotated key part comes back in k_pe_tokens and sits in the pool row."""
+    import oracle
+
+    ops = _ops()
+    B, H, lora, rope = 5, 16, 512, 64
+    gen = torch.Generator().manual_seed(11)
+    lens = [1, 40, 97, 33, 64]
+    n = sum(lens) + 3
+    kv = torch.randn(n, 1, lora + rope, generator=gen).to(dtype)
+    q = (torch.randn(B, H, lora + rope, generator=gen) * 0.5).to(dtype)
+    ind = (torch.randperm(n - 1, generator=gen)[:sum(lens)] + 1).to(torch.int32)
+    ptr = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    positions = torch.tensor([l - 1 for l in lens], dtype=torch.int64)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rotary_dim, 2).float() / rotary_dim))
+    fr = torch.einsum("i,j->ij", torch.arange(256).float(), inv)
+    cos_sin = torch.cat([fr.cos(), fr.sin()], dim=-1)
+
+    def rot(x, pos):                                        # x [..., rope] fp32, one position
+        c, s = cos_sin[pos, : rotary_dim // 2], cos_sin[pos, rotary_dim // 2:]
+        y = x.clone()
+        if neox:
+            a, b = x[..., : rotary_dim // 2], x[..., rotary_dim // 2: rotary_dim]
+            y[..., : rotary_dim // 2], y[..., rotary_dim // 2: rotary_dim] = a * c - b * s, b * c + a * s
+        else:
+            a, b = x[..., 0:rotary_dim:2], x[..., 1:rotary_dim:2]
+            y[..., 0:rotary_dim:2], y[..., 1:rotary_dim:2] = a * c - b * s, b * c + a * s
+        return y
+
+    q_ref, kv_ref = q.clone(), kv.clone()
+    kpe_ref = torch.zeros(B, rope, dtype=dtype)
+    for b in range(B):
+        p = int(positions[b])
+        q_ref[b, :, lora:] = rot(q[b, :, lora:].float(), p).to(dtype)
+        last = int(ind[ptr[b + 1] - 1])
+        kpe_ref[b] = rot(kv[last, 0, lora:].float(), p).to(dtype)
+        kv_ref[last, 0, lora:] = kpe_ref[b]
+    S = 4
+    ns = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(ns, torch.tensor(lens, device=DEV), H, 1, S, 256)
+    sm = 1.0 / math.sqrt(192)
+    want = oracle.decode_attention(q_ref, kv_ref, kv_ref[..., :lora].contiguous(), ptr, ind, ns.cpu(), sm, 0.0)
+
+    kv_d = kv.to(DEV)
+    o = torch.full((B, H, lora), float("nan"), dtype=dtype, device=DEV)
+    kpe = torch.zeros(B, 1, rope, dtype=dtype, device=DEV)
+    logits = torch.empty(B, H, S, lora + 1, dtype=torch.float32, device=DEV)
+    ops.decode_attention_fwd_grouped_rope(q.to(DEV), kv_d, kv_d[..., :lora], o, ptr.to(DEV), ind.to(DEV), kpe, lora,
+                                          rotary_dim, cos_sin.to(DEV), positions.to(DEV), logits, ns, sm, 0.0,
+                                          use_rope=True, is_neox_style=neox)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (o.float().cpu() - want).abs().max().item() < tol
+    step = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10           # one unit in the last place at magnitude < 4
+    assert (kpe.view(B, rope).float().cpu() - kpe_ref.float()).abs().max().item() <= 4 * step
+    assert torch.equal(kv_d.cpu()[ind[ptr[1:] - 1].long(), 0, lora:], kpe.view(B, rope).cpu())   # pool row == output
+    untouched = torch.ones(n, dtype=torch.bool)
+    untouched[ind[ptr[1:] - 1].long()] = False
+    assert torch.equal(kv_d.cpu()[untouched], kv[untouched])
+    assert torch.equal(kv_d.cpu()[..., :lora], kv[..., :lora])
+    # without rotation the call is the plain decode
+    o2 = torch.empty_like(o)
+    kv_d2 = kv.to(DEV)
+    ops.decode_attention_fwd_grouped_rope(q.to(DEV), kv_d2, kv_d2[..., :lora], o2, ptr.to(DEV), ind.to(DEV), kpe, lora,
+                                          rotary_dim, cos_sin.to(DEV), positions.to(DEV), logits, ns, sm, 0.0)
+    want2 = oracle.decode_attention(q, kv, kv[..., :lora].contiguous(), ptr, ind, ns.cpu(), sm, 0.0)
+    assert (o2.float().cpu() - want2).abs().max().item() < tol
+    assert torch.equal(kv_d2.cpu(), kv)
