@@ -464,7 +464,8 @@ SGLK_API int sglk_top_k_renorm_probs(const float* probs, float* out, const int32
                                      int top_k_val, int batch, int vocab, int64_t in_stride,
                                      int64_t out_stride, void* stream);
 /* Drop the longest ascending run of entries whose cumulative mass stays below 1 - top_p, renormalise the rest:
- * top_p_renorm_probs, sampling.py:69-102. */
+ * top_p_renorm_probs, sampling.py:69-102.  The cumulative masses are fp32 sums whose order is not fixed: an entry
+ * whose cumulative mass sits within rounding of 1 - top_p may fall on either side of the cut from run to run. */
 SGLK_API int sglk_top_p_renorm_probs(const float* probs, float* out, const float* top_p_arr,
                                      float top_p_val, int batch, int vocab, int64_t in_stride,
                                      int64_t out_stride, void* stream);
