@@ -164,3 +164,27 @@ def test_graph_replay_equals_eager():
     for a, b in zip(*outs):
         assert a[0] == b[0] and a[1] == b[1]
         assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+def test_bench_tiny_line_and_ttft_block():
+    """bench.py end to end on the tiny configuration: one JSON line with the contract's keys, and the
+    time-to-first-token experiment on the same model (cache hits where expected)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from sglang_security_amd.prefill_runner import ttft_experiment
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tiny", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in line
+    assert line["steps"] == 3 and line["n_gpus"] == 1 and line["value"] > 0 and "workload" in line["config"]
+    out = ttft_experiment(_tiny("awq"), 1024, 16, pool_tokens=8192, repeats=1)
+    assert out["public"]["cached_prefix_tokens_cold_other_owner"] == [0, 1024, 1024]
+    assert out["private"]["cached_prefix_tokens_cold_other_owner"] == [0, 0, 1024]
