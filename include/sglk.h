@@ -274,6 +274,23 @@ SGLK_API int sglk_awq_gemm(const void* x, const int32_t* packed, const void* sca
                            int M, int N, int K, int group_size, int64_t x_stride, int64_t out_stride,
                            int dtype, void* stream);
 
+/* sglk_awq_gemm without the workspace argument, for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * split-K workspace is a static device array inside the library (sglk_awq_gemm_static_max_workspace_bytes() =
+ * 7 MiB + 16 KiB per GPU the library runs on, held until the process ends: enough for every projection of
+ * Llama-3-8B at up to 64 rows); shapes whose
+ * sglk_awq_gemm_workspace_bytes() exceeds it are rejected with SGLK_EINVAL.  The call allocates and frees nothing
+ * and clears the ticket words itself (a memset node on `stream`).  Every call on one GPU shares that GPU's array:
+ * calls that overlap on one GPU (two streams) race -- use sglk_awq_gemm with separate workspaces there.
+ * sglk_awq_gemm_static_init() resolves the array's address for the current device ahead of time (otherwise the
+ * first call on a device does it). */
+SGLK_API int64_t sglk_awq_gemm_static_max_workspace_bytes(void);
+SGLK_API int sglk_awq_gemm_static_init(void);
+SGLK_API int sglk_awq_gemm_static(const void* x, const int32_t* packed, const void* scales,
+                                  const int32_t* qzeros, const void* bias, void* out, int M, int N, int K,
+                                  int group_size, int64_t x_stride, int64_t out_stride, int dtype,
+                                  void* stream);
+
 /* ---- fusion forms of the decode layer --------------------------------------------------------------
  * None of these has a counterpart in the reference, which runs norm / GEMM / rope / activation as separate
  * ops; they are for callers that own the whole decoder layer (the graph-captured decode step).  Two ideas:

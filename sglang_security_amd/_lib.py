@@ -61,6 +61,9 @@ _SIGS = {
     "sglk_awq_repack": (i32, [p, p, i32, i32, p]),
     "sglk_awq_gemm_workspace_bytes": (i64, [i32, i32, i32]),
     "sglk_awq_gemm": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p]),
+    "sglk_awq_gemm_static_max_workspace_bytes": (i64, []),
+    "sglk_awq_gemm_static_init": (i32, []),
+    "sglk_awq_gemm_static": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p]),
     "sglk_awq_gemm_xs": (i32, [p, p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p, i64, p]),
     "sglk_awq_gemm_partial_splits": (i32, [i32, i32, i32, i32]),
     "sglk_awq_gemm_partial": (i32, [p, p, p, p, p, i64, p, i32, i32, i32, i32, i64, i32, p]),

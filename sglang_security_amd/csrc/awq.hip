@@ -20,6 +20,7 @@
 // i.e. out = x @ ((q - z) * s) with the product (q - z) * s never rounded to half precision.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -1336,5 +1337,55 @@ int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, cons
                   int64_t out_stride, int dtype, void* stream) {
   return sglk_awq_gemm_xs(x, packed, scales, qzeros, bias, out, workspace, M, N, K, group_size, x_stride, out_stride,
                           dtype, nullptr, 0, stream);
+}
+
+// ---- sglk_awq_gemm for callers that cannot allocate: the split-K workspace (ticket words + fp32 slabs) lives in a
+// static device array of the code object.  Every GPU the library runs on holds its own copy at its own address; the
+// address is looked up once per device (the array's name is only a host-side handle, never a device pointer).
+static constexpr int64_t kStaticWsBytes = (int64_t)kMaxTiles * 4 + ((int64_t)7 << 20);
+static __device__ __align__(256) unsigned char scratch[kStaticWsBytes];
+static constexpr int kMaxDevices = 64;
+static void* g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+static int static_scratch(void** ptr) {
+  int dev = -1;
+  SGLK_HIP(hipGetDevice(&dev));
+  SGLK_CHECK(dev >= 0 && dev < kMaxDevices, "awq_gemm_static: device ordinal %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    SGLK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+    SGLK_CHECK(p != nullptr, "awq_gemm_static: no device address for the static workspace");
+    g_scratch_ptr[dev] = p;
+  }
+  *ptr = g_scratch_ptr[dev];
+  return SGLK_OK;
+}
+
+int64_t sglk_awq_gemm_static_max_workspace_bytes(void) { return kStaticWsBytes; }
+
+int sglk_awq_gemm_static_init(void) {
+  void* p = nullptr;
+  return static_scratch(&p);
+}
+
+int sglk_awq_gemm_static(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros,
+                         const void* bias, void* out, int M, int N, int K, int group_size, int64_t x_stride,
+                         int64_t out_stride, int dtype, void* stream) {
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && K % 128 == 0, "awq_gemm_static: bad shape");
+  const int64_t need = sglk_awq_gemm_workspace_bytes(M, N, K);
+  if (need > kStaticWsBytes)
+    return fail(SGLK_EINVAL,
+                "awq_gemm_static: M=%d N=%d K=%d needs a %lld-byte workspace, the static one holds %lld: use "
+                "sglk_awq_gemm with a caller-provided workspace",
+                M, N, K, (long long)need, (long long)kStaticWsBytes);
+  void* ws = nullptr;
+  const int rc = static_scratch(&ws);
+  if (rc != SGLK_OK) return rc;
+  // the array keeps the previous call's contents: the ticket words must start at zero
+  SGLK_HIP(hipMemsetAsync(ws, 0, (size_t)kMaxTiles * 4, (hipStream_t)stream));
+  return sglk_awq_gemm_xs(x, packed, scales, qzeros, bias, out, reinterpret_cast<float*>(ws), M, N, K, group_size,
+                          x_stride, out_stride, dtype, nullptr, 0, stream);
 }
 }
