@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libsglk.so")
+LIB_PATH = os.environ.get("SGLK_LIB") or os.path.join(_PKG, "libsglk.so")  # SGLK_LIB: a development build
 
 F32, F16, BF16, FP8_E4M3 = 0, 1, 2, 3
 

@@ -22,7 +22,7 @@
 #include <cstdlib>
 #include <mutex>
 
-#include "common.h"
+#include "awq_common.h"
 
 namespace sglk {
 
@@ -219,37 +219,6 @@ __global__ void __launch_bounds__(256) awq_dequant_packed_tile_kernel(const int3
   }
 }
 
-template <typename T>
-struct AwqMagic;
-template <>
-struct AwqMagic<bf16_t> {
-  static constexpr uint32_t kOr = 0x43004300u;
-  static constexpr float kOff = 128.f;
-  static __device__ __forceinline__ float4v mma(int4v a, int4v b, float4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfloat8, a), __builtin_bit_cast(bfloat8, b), c, 0,
-                                                   0, 0);
-  }
-  // acc + lo + hi of a packed pair
-  static __device__ __forceinline__ float pair_sum(uint32_t v, float acc) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, v), __builtin_bit_cast(bf2, 0x3F803F80u), acc, false);
-  }
-};
-template <>
-struct AwqMagic<f16_t> {
-  static constexpr uint32_t kOr = 0x64006400u;
-  static constexpr float kOff = 1024.f;
-  static __device__ __forceinline__ float4v mma(int4v a, int4v b, float4v c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0,
-                                                  0);
-  }
-  static __device__ __forceinline__ float pair_sum(uint32_t v, float acc) {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_fdot2(__builtin_bit_cast(h2, v), __builtin_bit_cast(h2, 0x3C003C00u), acc, false);
-  }
-};
-
-static constexpr int kGemmBM = 64;  // activation rows per block (4 MFMA row tiles)
 
 // x tile in LDS: 16-byte chunk c of row r at slot c ^ (r & 15) (conflict-free row reads, as the K tile
 // of the attention kernel)
@@ -575,16 +544,23 @@ __global__ void __launch_bounds__(64 * NW, NW / 4) awq_gemm_kernel(
 // ---------------------------------------------------------------------------------------------
 // Wide kernel: 8 waves = 4 k-groups x 2 column chunks of 64, one block per CU (two waves per SIMD).
 //
-// The inner loop of the kernel above spends ~15 instructions per MFMA on 16 columns per wave; issue slots,
-// not HBM, bound it.  Here a wave owns 64 columns (4 strips) of one 128-k group per stage, so every A
-// fragment read from LDS feeds 4 strips and the per-stage bookkeeping is spread over 64 MFMAs.  The four
-// k-waves of a column chunk work on four consecutive groups (a stage is 512 k) and add their tiles up
-// through LDS at the end, so a block needs no split-K partner for K <= 4096.
+// The narrow kernel above spends ~15 instructions per matrix instruction on 16 columns per wave; issue slots,
+// not HBM, bound it.  Here a wave owns 64 columns x 64 rows of one 128-k group per stage and multiplies with
+// v_mfma_f32_32x32x16: one dequantised B operand (7 vector instructions for 8 weights per lane) feeds two matrix
+// instructions of 32 cycles each, and a matrix instruction holds the vector issue port for 8 cycles whatever its
+// size.  The four k-waves of a column chunk work on four consecutive groups (a stage is 512 k) and add their
+// tiles up through LDS at the end, so a block needs no split-K partner for K <= 4096.
 //
 //   x   : stage = 4 tiles of 64 rows x 128 k (64 KiB) by LDS-DMA, two stages;
 //   sz  : per wave and stage one 256-byte LDS-DMA piece (scale pairs + zero words), three stages;
-//   w   : 4 x 16 bytes per lane straight into registers, two stages ahead (three register sets);
-//   X   : block sums of x per (group, row), computed once per stage from the landed tile by all threads.
+//   w   : 4 x 16 bytes per lane straight into registers, two stages ahead (three register sets).  The
+//         repacked layout serves the 32-column operand as it stands: lane (r = lane & 31, h = lane >> 5) of
+//         column tile ct takes the 16-byte pieces of strip-lanes (r & 15) + 16 h and + 32 of strip 2 ct + (r >> 4),
+//         whose word d holds k-step 2 d and 2 d + 1 respectively;
+//   X   : block sums of x per (group, row), from the producer of x or computed here once per stage.
+// The zero-point term -(OFF + z) * X of a group is one more k-step on the matrix cores (16-bit floats with eight
+// significant bits, bf16): X split exactly into three such values in k-slots 0..2 of the A operand, -(OFF + z)
+// (exact) in the same slots of B.  Types with a narrower exponent (fp16) keep that term on the vector unit.
 // Per-wave issue order inside a stage is x(i+1), sz(i+2), w(i+2): waiting for x(i+1) leaves the five younger
 // operations outstanding.
 // ---------------------------------------------------------------------------------------------
@@ -598,18 +574,46 @@ struct Wide {
   static constexpr int kTileFloats = 64 * 128;
 };
 
+// Development builds only (tools/build_abl.sh): SGLK_ABL bit 64 compiles per-phase clock stamps into the wide kernel
+// (tools/bench_gemm.py --fused --stamps reads them), the other bits remove one component of its main loop each
+// (1 matrix instructions, 2 dequantisation, 4 LDS fragment reads, 16 rescale, 32 stage barrier, 128 activation DMA,
+// 256 weight loads, 512 half of the activation DMA) for timing experiments.  The product build has SGLK_ABL == 0.
+#ifndef SGLK_ABL
+#define SGLK_ABL 0
+#endif
+#if SGLK_ABL & 64
+__device__ long long g_stamps[256 * 24];
+#define SGLK_STAMP(k)                                                                             \
+  do {                                                                                            \
+    if (tid == 0 && blin < 256 && (k) < 24) g_stamps[blin * 24 + (k)] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define SGLK_STAMP(k) \
+  do {                \
+  } while (0)
+#endif
+template <typename T>
+struct ZpOnMatrixCores {
+  static constexpr bool value = false;
+};
+template <>
+struct ZpOnMatrixCores<bf16_t> {
+  static constexpr bool value = true;
+};
+
 // XS_EXT: the block sums X[group][row] come from the kernel that produced x (xsum_in, row stride xs_stride) instead
 // of being computed here: one barrier per stage instead of two.  partial_mode: every split stores its fp32 tile
 // row-major to partial[split][M][N] and returns; the consumer kernel adds the splits up.
-// MQ: 16-row tiles of the 64-row block that are multiplied (batches of up to 16 / 32 rows skip the matrix work of
-// the rows they do not have; staging, reduction and stores keep the 64-row shape, the skipped tiles are zeros).
-template <typename T, bool XS_EXT, int MQ = 4>
+// MT: 32-row tiles of the 64-row block that are multiplied (batches of up to 32 rows skip the matrix work of the
+// rows they do not have; staging, reduction and stores keep the 64-row shape, the skipped tile is zeros).
+template <typename T, bool XS_EXT, int MT = 2>
 __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     const uint16_t* __restrict__ x, const int32_t* __restrict__ packed, const uint16_t* __restrict__ scales,
     const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
     float* __restrict__ partial, int* __restrict__ tickets, int M, int N, int K, int stages_per_split, int splits,
-    int64_t x_stride, int64_t out_stride, int abl, const float* __restrict__ xsum_in, int64_t xs_stride,
-    int partial_mode, int act_mode, float* __restrict__ xsum_out, int64_t xs_out_stride) {
+    int64_t x_stride, int64_t out_stride, const float* __restrict__ xsum_in, int64_t xs_stride, int partial_mode,
+    int act_mode, float* __restrict__ xsum_out, int64_t xs_out_stride) {
+  constexpr bool ZPM = ZpOnMatrixCores<T>::value;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xsumS = reinterpret_cast<float*>(smem + Wide::kXsumOff);
   int* flag = reinterpret_cast<int*>(smem + Wide::kFlagOff);
@@ -618,6 +622,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kw = wid & 3, nw = wid >> 2;
   const int i16 = lane & 15, g = lane >> 4;
+  const int r32 = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.z * kGemmBM;
   const int total_stages = K / Wide::kStageK;
   const int st0 = blockIdx.y * stages_per_split;
@@ -625,16 +630,8 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   const int n0 = blockIdx.x * 128 + nw * 64;
   const int64_t nstrips = N / 16;
   const int qcols = N / 8;
-  // timing experiments (abl & 16): thread 0 drops 100 MHz clock stamps behind the ticket words in use
-  const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  auto stamp = [&](int k) {
-    if ((abl & 16) && tickets && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
-  };
-  // abl & 32: six stamps inside stage 3 (wave 0 lane 0) instead
-  auto stamp_in = [&](int stage, int k) {
-    if ((abl & 32) && tickets && stage == 3 && tid == 0 && blin < 256) tickets[2048 + blin * 8 + k] = (int)wall_clock64();
-  };
-  stamp(0);
+  [[maybe_unused]] const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  SGLK_STAMP(0);
 
   // ---- x DMA: wave w fills pieces 8w .. 8w+7 of a stage; piece p = (tile p >> 4, rows 4 * (p & 15) + g)
   // byte offset of this lane's 16-byte source chunk inside stage 0, biased so that "uniform base + 32-bit lane offset +
@@ -703,17 +700,19 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  // ---- weights: strip t of group gq is 1 KiB at ((gq * nstrips) + n0/16 + t) * 1024; 16 bytes per lane.
-  // Issued as raw instructions so that the compiler neither counts them nor waits for them: the counted
-  // vmcnt at each stage boundary (bound to the registers through its operands) is the only wait.
-  const uint32_t wvoff = (uint32_t)((((int64_t)kw * nstrips + (n0 >> 4)) * 64 + lane) * 16);
+  // ---- weights: strip t of group gq is 1 KiB at ((gq * nstrips) + n0/16 + t) * 1024.  Load 2 ct + j (j = 0, 1) of a
+  // stage fetches, for column tile ct, the piece of strip-lane (r & 15) + 16 h + 32 j of strip 2 ct + (r >> 4): word d of
+  // it is this lane's B operand source of k-step 2 d + j.  Issued as raw instructions so that the compiler neither
+  // counts them nor waits for them: the counted vmcnt at each stage boundary (bound to the registers through its
+  // operands) is the only wait.
+  const uint32_t wvoff = (uint32_t)((((int64_t)kw * nstrips + (n0 >> 4) + (r32 >> 4)) * 64 + i16 + 16 * h) * 16);
   auto load_w = [&](int stage, int4v(&w)[4]) {
     const char* src = reinterpret_cast<const char*>(packed) + (int64_t)(st0 + min(stage, nst - 1)) * 4 * nstrips * 1024;
     asm volatile(
         "global_load_dwordx4 %0, %4, %5\n\t"
-        "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+        "global_load_dwordx4 %1, %4, %5 offset:512\n\t"
         "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-        "global_load_dwordx4 %3, %4, %5 offset:3072"
+        "global_load_dwordx4 %3, %4, %5 offset:2560"
         : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
         : "v"(wvoff), "s"(src)
         : "memory");
@@ -725,26 +724,25 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
   };
 
-  // One accumulator set: R[t][q] holds the running sum of strip t in units of the current group's scale,
+  // One accumulator set: R[ct][rt] (column tile, row tile; lane = column, registers = rows) holds the running sum
+  // in units of the current group's scale,
   //   R = sum_{g' <= g} (s_g' / s_g) * (x . (OFF + q_g') - (OFF + z_g') * X_g'),
   // so the matrix cores add straight into it; moving to the next group multiplies R by s_g / s_{g+1}.
   // A column whose scale is zero keeps its previous unit (see below); non-finite scales propagate.
-  float4v R[4][4];
+  float16v R[2][2];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) R[t][q] = float4v{0.f, 0.f, 0.f, 0.f};
-  float s_cur[4] = {1.f, 1.f, 1.f, 1.f};
-  int zsh[4];
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    // AWQ order {0,4,1,5,2,6,3,7} in arithmetic: a table lookup here would be a load the stage pipeline waits for
-    const int j = (n0 + 16 * t + i16) & 7;
-    zsh[t] = 4 * ((j >> 1) + 4 * (j & 1));
-  }
-  int aoff[4];
+      for (int e = 0; e < 16; ++e) R[ct][rt][e] = 0.f;
+  float s_cur[2] = {1.f, 1.f};
+  // AWQ order {0,4,1,5,2,6,3,7} in arithmetic: a table lookup here would be a load the stage pipeline waits for
+  const int zsh = 4 * (((r32 & 7) >> 1) + 4 * (r32 & 1));
+  // A operand of k-step s, row tile rt: 16 bytes at row 32 rt + r, chunk 2 s + h of this wave's x tile
+  int aoff[8];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) aoff[ks] = kw * 16384 + x_off(i16, 4 * ks + g);
+  for (int s = 0; s < 8; ++s) aoff[s] = kw * 16384 + x_off(r32, 2 * s + h);
   uint32_t or_const = AwqMagic<T>::kOr;
   uint32_t nib_mask = 0x000F000Fu;
   asm volatile("" : "+v"(or_const));
@@ -772,7 +770,13 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   issue_x(0, 0);
   issue_sz(1, 1);
   load_w(1, wreg[1]);
+  SGLK_STAMP(19);
+  if constexpr ((SGLK_ABL & 64) != 0) {
+    if constexpr (XS_EXT) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    SGLK_STAMP(20);
+  }
   stage_wait(wreg[0]);  // sz(0), w(0), x(0) landed; sz(1) and w(1) fly on
+  SGLK_STAMP(21);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if constexpr (!XS_EXT) {
@@ -782,103 +786,154 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     asm volatile("" ::: "memory");
   }
 
-  stamp(1);
-  const int npad = (nst + 2) / 3 * 3;  // register set = unroll index; padded stages only keep the pipeline counts
-  for (int i0 = 0; i0 < npad; i0 += 3) {
+  SGLK_STAMP(1);
+  // register set = unroll index mod 3, x buffer = unroll index mod 2: unrolled six times, every index is static
+  const int npad = (nst + 5) / 6 * 6;
+  for (int i0 = 0; i0 < npad; i0 += 6) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < 6; ++u) {
       const int i = i0 + u;
-      const int buf = i & 1;
-      stamp_in(i, 0);
-      // spread (default): this stage's memory instructions go out between its k-steps, x(i+1) after k-steps 0 and 1,
-      // then sz(i+2) and w(i+2) after k-step 2 -- the CU's address unit takes 16 cycles per 1-KiB instruction, and
-      // eight waves issuing everything at the top of a stage would stall each other there.  Same order as the
-      // all-at-the-top form (abl & 64), so the same counted wait holds.
-      const bool spread = !(abl & 64) && i < nst;
-      if (!spread) {
-        issue_x((abl & 2) ? 0 : i + 1, buf ^ 1);
-        issue_sz(i + 2, (u + 2) % 3);
-        load_w((abl & 8) ? 0 : i + 2, wreg[(u + 2) % 3]);
-      }
-      stamp_in(i, 1);
-      if (i < nst && !(abl & 4)) {  // block-uniform
+      constexpr int kUnused = 0;
+      (void)kUnused;
+      const int buf = u & 1;
+      const int ws = u % 3;
+      {
         const char* xt = smem + buf * Wide::kXStage;
         // this stage's per-column scale and zero (landed two stages ago); rescale R to the new unit
-        float nzo[4];        // -(OFF + z)
-        uint32_t msk[4], orc[4];  // per-strip dequantisation constants (zeroed for a column whose scale is zero)
+        uint32_t msk[2], orc[2];  // per-column-tile dequantisation constants (zeroed for a column whose scale is zero)
+        int4v bz[2];              // B operand of the zero-point k-step
+        float nzo[2];             // -(OFF + z), vector-unit form
         {
-          const char* szp = smem + Wide::kSzOff + (u * 8 + wid) * 256;
-          float sg[4];
-          // A zero (or denormal) scale cannot become the unit of R: that column keeps its unit and this group
-          // contributes nothing to it (its B operand and zero-point term are zeroed).
+          const char* szp = smem + Wide::kSzOff + (ws * 8 + wid) * 256;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int c = 16 * t + i16;
+          for (int ct = 0; ct < 2; ++ct) {
+            const int c = 32 * ct + r32;
             const float s_in = Conv<T>::to_f32(*reinterpret_cast<const uint16_t*>(szp + 2 * c));
             const uint32_t zw = *reinterpret_cast<const uint32_t*>(szp + 128 + 4 * (c >> 3));
+            // A zero (or denormal) scale cannot become the unit of R: that column keeps its unit and this group
+            // contributes nothing to it (its B operand and zero-point term are zeroed).
             const bool ok = fabsf(s_in) >= 1.17549435e-38f;
-            sg[t] = ok ? s_in : s_cur[t];
-            nzo[t] = ok ? -(AwqMagic<T>::kOff + (float)((zw >> zsh[t]) & 0xF)) : 0.f;
-            msk[t] = ok ? nib_mask : 0u;
-            orc[t] = ok ? or_const : 0u;
+            const float sg = ok ? s_in : s_cur[ct];
+            const float ratio = s_cur[ct] * __builtin_amdgcn_rcpf(sg);
+            s_cur[ct] = sg;
+            const uint32_t z = (zw >> zsh) & 0xF;
+            msk[ct] = ok ? nib_mask : 0u;
+            orc[ct] = ok ? or_const : 0u;
+            if constexpr (ZPM) {
+              // -(OFF + z) as the 16-bit pattern of the operand type: sign bit on the dequantisation constant
+              const uint32_t nzb = ((AwqMagic<T>::kOr & 0xFFFFu) | 0x8000u) | z;
+              const bool okh = ok && h == 0;  // k-slots 0..2 belong to the lower half-wave
+              bz[ct] = int4v{okh ? (int)(nzb * 0x10001u) : 0, okh ? (int)nzb : 0, 0, 0};
+            } else {
+              nzo[ct] = ok ? -(AwqMagic<T>::kOff + (float)z) : 0.f;
+            }
+#pragma unroll
+            for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                if constexpr (!(SGLK_ABL & 16)) R[ct][rt][e] *= ratio;
+            if constexpr (SGLK_ABL & 16) asm volatile("" ::"v"(ratio));
           }
+        }
+        const float* xp = xsumS + (XS_EXT ? (buf * 8 + wid) : (buf * 4 + kw)) * 64;
+        if constexpr (ZPM) {
+          // zero-point k-step: X[row] = a + b + c exactly, three values of the operand type
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float ratio = s_cur[t] * __builtin_amdgcn_rcpf(sg[t]);
-            s_cur[t] = sg[t];
+          for (int rt = 0; rt < MT; ++rt) {
+            const float X = xp[32 * rt + r32];
+            const uint32_t a = __float_as_uint(X) & 0xFFFF0000u;
+            const float r1 = X - __uint_as_float(a);
+            const uint32_t b = __float_as_uint(r1) & 0xFFFF0000u;
+            const float r2 = r1 - __uint_as_float(b);
+            const int4v ax = int4v{(int)((a >> 16) | b), (int)(__float_as_uint(r2) >> 16), 0, 0};
 #pragma unroll
-            for (int q = 0; q < MQ; ++q) R[t][q] *= ratio;
+            for (int ct = 0; ct < 2; ++ct) R[ct][rt] = AwqMagic<T>::mma32(ax, bz[ct], R[ct][rt]);
           }
         }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          int4v af[MQ];
+        for (int s = 0; s < 8; ++s) {
+          int4v af[MT];
 #pragma unroll
-          for (int q = 0; q < MQ; ++q) af[q] = *reinterpret_cast<const int4v*>(xt + q * 4096 + aoff[ks]);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const uint32_t w = (uint32_t)wreg[u][t][ks];
-            int4v bf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bf[e] = (int)(((w >> (4 * e)) & msk[t]) | orc[t]);
-#pragma unroll
-            for (int q = 0; q < MQ; ++q) R[t][q] = AwqMagic<T>::mma(af[q], bf, R[t][q]);
-          }
-          if (spread) {
-            if (ks < 2) {
-              issue_x_half(i + 1, buf ^ 1, ks);
-            } else if (ks == 2) {
-              issue_sz(i + 2, (u + 2) % 3);
-              load_w(i + 2, wreg[(u + 2) % 3]);
+          for (int rt = 0; rt < MT; ++rt) {
+            if constexpr (SGLK_ABL & 4) {
+              af[rt] = int4v{aoff[s], aoff[s] + rt, aoff[s] + 2, aoff[s] + 3};
+            } else {
+              af[rt] = *reinterpret_cast<const int4v*>(xt + rt * 8192 + aoff[s]);
             }
           }
-        }
-        // zero-point term with this group's block sums
-        {
-          const float* xp = xsumS + (XS_EXT ? (buf * 8 + wid) : (buf * 4 + kw)) * 64;
 #pragma unroll
-          for (int q = 0; q < MQ; ++q) {
-            const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 16 * q + 4 * g);
+          for (int ct = 0; ct < 2; ++ct) {
+            const uint32_t w = (uint32_t)wreg[ws][2 * ct + (s & 1)][s >> 1];
+            int4v bf;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-              R[t][q] = __builtin_elementwise_fma(xs4, float4v{nzo[t], nzo[t], nzo[t], nzo[t]}, R[t][q]);
+            for (int e = 0; e < 4; ++e) {
+              if constexpr (SGLK_ABL & 2) {
+                bf[e] = (int)(w | orc[ct]);
+              } else {
+                bf[e] = (int)(((w >> (4 * e)) & msk[ct]) | orc[ct]);
+              }
+            }
+#pragma unroll
+            for (int rt = 0; rt < MT; ++rt) {
+              if constexpr (SGLK_ABL & 1) {
+                asm volatile("" ::"v"(af[rt]), "v"(bf));
+              } else {
+                R[ct][rt] = AwqMagic<T>::mma32(af[rt], bf, R[ct][rt]);
+              }
+            }
+          }
+          // this stage's memory instructions go out between its k-steps, in the order the counted wait assumes:
+          // x(i+1) in two halves, then sz(i+2) and w(i+2)
+          if constexpr ((SGLK_ABL & 128) != 0) {
+            if (s == 4) {
+              issue_sz(i + 2, (u + 2) % 3);
+              if constexpr ((SGLK_ABL & 256) != 0) load_w(0, wreg[(u + 2) % 3]); else load_w(i + 2, wreg[(u + 2) % 3]);
+            }
+          } else if (s == 0 || (s == 2 && !(SGLK_ABL & 512))) {
+            if constexpr (SGLK_ABL & 8) {
+              issue_x_half(0, buf ^ 1, s >> 1);  // the same stage again: L1-resident after the first round
+            } else {
+              issue_x_half(i + 1, buf ^ 1, s >> 1);
+            }
+          } else if (s == 4) {
+            issue_sz(i + 2, (u + 2) % 3);
+            load_w(i + 2, wreg[(u + 2) % 3]);
           }
         }
+        if constexpr (!ZPM) {
+          // zero-point term with this group's block sums on the vector unit: register e of a tile is row
+          // (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+          for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 32 * rt + 8 * j + 4 * h);
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) R[ct][rt][4 * j + e] = fmaf(xs4[e], nzo[ct], R[ct][rt][4 * j + e]);
+            }
+        }
       }
-      stamp_in(i, 2);
+      SGLK_STAMP(2 + i);
       if (i + 1 >= nst) goto stages_done;  // block-uniform: the look-ahead loads are drained below
+      if constexpr ((SGLK_ABL & 64) != 0) {
+        if (i == 2) {
+          if constexpr (XS_EXT) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+          SGLK_STAMP(16);
+        }
+      }
       stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
-      stamp_in(i, 3);
-      __builtin_amdgcn_s_barrier();
+      if (i == 2) SGLK_STAMP(17);
+      if constexpr (!(SGLK_ABL & 32)) __builtin_amdgcn_s_barrier();
+      if (i == 2) SGLK_STAMP(18);
       asm volatile("" ::: "memory");
-      stamp_in(i, 4);
       if constexpr (!XS_EXT) {
-        if (!(abl & 1)) xsum_pass(buf ^ 1);
+        xsum_pass(buf ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
       }
-      stamp_in(i, 5);
     }
   }
 stages_done:
@@ -887,49 +942,61 @@ stages_done:
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  stamp(2);
-  // ---- add the four k-waves of each column chunk up through LDS: wave (kw, nw) finishes strip t = kw
-  float* red = reinterpret_cast<float*>(smem);  // [8 waves][16 regs x 4][64 lanes] = 128 KiB: the x stages
+  SGLK_STAMP(12);
+  // ---- add the four k-waves of each column chunk up through LDS.  red[wave][tile = 2 ct + rt][j][lane] holds
+  // registers 4 j .. 4 j + 3 of a wave's tile (128 KiB: the x stages); wave w then finishes the block's tile
+  // (column tile cc = w >> 1 of four, row tile w & 1).
+  float4v* red = reinterpret_cast<float4v*>(smem);
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[((wid * 16 + t * 4 + q) * 4 + r) * 64 + lane] = R[t][q][r] * s_cur[t];
+      for (int j = 0; j < 4; ++j) {
+        float4v v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = R[ct][rt][4 * j + e] * s_cur[ct];
+        red[((wid * 4 + 2 * ct + rt) * 4 + j) * 64 + lane] = v;
+      }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  SGLK_STAMP(22);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  SGLK_STAMP(23);
+  // sum of the four k-waves' registers 4 j .. 4 j + 3 of tile (column tile cc of the block, row tile rt), in k order
+  auto ksum = [&](int cc, int rt, int j) {
+    float4v a = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) a += red[((((cc >> 1) * 4 + k2) * 4 + 2 * (cc & 1) + rt) * 4 + j) * 64 + lane];
+    return a;
+  };
   if (act_mode) {
     // Gated-activation epilogue (single split only).  The tile's first 64 columns are gate columns, its last 64 the
     // matching up columns (the caller interleaved the weight that way), so out[m, 64*tile + j] =
     // round(round(silu(round(gate))) * round(up)): the values the unfused GEMM + silu_and_mul sequence stores.
-    // Wave (kw, nw) finishes strip kw for row tiles q = 2*nw, 2*nw + 1; it also leaves the block's row sums
-    // (for the next projection's zero-point term) in xsum_out, two tiles per 128-column block, by one atomic
-    // add per row and tile (two addends: order-independent).
-    float* rs = reinterpret_cast<float*>(smem + Wide::kSzOff);  // [4 strips][64 rows], the sz ring is idle now
-    const int ncol = blockIdx.x * 64 + 16 * kw + i16;
+    // Wave w finishes registers 8 hf .. 8 hf + 7 (hf = w & 1) of output tile (column tile cc2 = w >> 2, row tile
+    // rt = (w >> 1) & 1); the block's row sums (for the next projection's zero-point term) go to xsum_out, two
+    // blocks per 128-column group, by one atomic add per row and block (two addends: order-independent).
+    float* rs = reinterpret_cast<float*>(smem + Wide::kSzOff);  // [2 column tiles][64 rows], the sz ring is idle now
+    const int cc2 = wid >> 2, rt = (wid >> 1) & 1, hf = wid & 1;
+    const int ncol = blockIdx.x * 64 + 32 * cc2 + r32;
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const int q = 2 * nw + qq;
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = 2 * hf + jj;
+      const float4v gs = ksum(cc2, rt, j), us = ksum(cc2 + 2, rt, j);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float gsum = 0.f, usum = 0.f;
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) {
-          gsum += red[(((0 * 4 + k2) * 16 + kw * 4 + q) * 4 + r) * 64 + lane];
-          usum += red[(((1 * 4 + k2) * 16 + kw * 4 + q) * 4 + r) * 64 + lane];
-        }
-        const float gb = Conv<T>::to_f32(Conv<T>::from_f32(gsum));
-        const float ub = Conv<T>::to_f32(Conv<T>::from_f32(usum));
+      for (int e = 0; e < 4; ++e) {
+        const float gb = Conv<T>::to_f32(Conv<T>::from_f32(gs[e]));
+        const float ub = Conv<T>::to_f32(Conv<T>::from_f32(us[e]));
         const float sv = Conv<T>::to_f32(Conv<T>::from_f32(gb / (1.0f + __expf(-gb))));
         const uint16_t ob = Conv<T>::from_f32(sv * ub);
-        const int m = m0 + 16 * q + 4 * g + r;
-        if (m < M) out[(int64_t)m * out_stride + ncol] = ob;
+        const int row = 32 * rt + e + 8 * j + 4 * h;
+        if (m0 + row < M) out[(int64_t)(m0 + row) * out_stride + ncol] = ob;
         if (xsum_out) {
           float v = Conv<T>::to_f32(ob);
 #pragma unroll
-          for (int o2 = 8; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 16);
-          if (i16 == 0) rs[kw * 64 + 16 * q + 4 * g + r] = v;
+          for (int o2 = 16; o2 > 0; o2 >>= 1) v += __shfl_xor(v, o2, 32);
+          if (r32 == 0) rs[cc2 * 64 + row] = v;
         }
       }
     }
@@ -937,61 +1004,59 @@ stages_done:
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      if (tid < 64 && m0 + tid < M) {
-        const float v = ((rs[tid] + rs[64 + tid]) + rs[128 + tid]) + rs[192 + tid];
-        atomicAdd(&xsum_out[(int64_t)(blockIdx.x >> 1) * xs_out_stride + m0 + tid], v);
-      }
+      if (tid < 64 && m0 + tid < M)
+        atomicAdd(&xsum_out[(int64_t)(blockIdx.x >> 1) * xs_out_stride + m0 + tid], rs[tid] + rs[64 + tid]);
     }
     return;
   }
+  SGLK_STAMP(13);
+  const int cc = wid >> 1, frt = wid & 1;
   float4v fin[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float a = 0.f;
-#pragma unroll
-      for (int k2 = 0; k2 < 4; ++k2) a += red[(((nw * 4 + k2) * 16 + kw * 4 + q) * 4 + r) * 64 + lane];
-      fin[q][r] = a;
-    }
-  // lane (i16, g) of wave (kw, nw) now holds rows 16q + 4g + r of column n0 + 16*kw + i16
-  const int n = n0 + 16 * kw + i16;
-  stamp(3);
+  for (int j = 0; j < 4; ++j) fin[j] = ksum(cc, frt, j);
+  // lane (r, h) of wave w now holds rows 32 frt + e + 8 j + 4 h (fin[j][e]) of column blockIdx.x * 128 + 32 cc + r
+  const int n = blockIdx.x * 128 + 32 * cc + r32;
+  const int mrow = m0 + 32 * frt + 4 * h;
+  if constexpr ((SGLK_ABL & 64) != 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(fin[0]), "v"(fin[1]), "v"(fin[2]), "v"(fin[3]) : "memory");
+    SGLK_STAMP(15);
+  }
   if (partial_mode) {
     float* dst = partial + (int64_t)blockIdx.y * M * N;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 16 * q + 4 * g + r;
-        if (m < M) dst[(int64_t)m * N + n] = fin[q][r];
+      for (int e = 0; e < 4; ++e) {
+        const int m = mrow + 8 * j + e;
+        if (m < M) dst[(int64_t)m * N + n] = fin[j][e];
       }
-    stamp(4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SGLK_STAMP(14);
     return;
   }
   if (splits == 1) {
     const float bv = bias ? Conv<T>::to_f32(bias[n]) : 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 16 * q + 4 * g + r;
-        if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(fin[q][r] + bv);
+      for (int e = 0; e < 4; ++e) {
+        const int m = mrow + 8 * j + e;
+        if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(fin[j][e] + bv);
       }
-    stamp(4);
     return;
   }
-  // split-K: slab[tile][split] holds the block's 64 x 128 fp32 tile as [strip = nw*4+kw][q][r][lane].
-  // Slabs are written and read with agent-scope (write-through / cache-bypassing) accesses, so that no
+  // split-K: slab[tile][split] holds the block's 64 x 128 fp32 tile as [wave w][j][lane] float4.
+  // Slabs are written and read with 16-byte agent-scope (write-through / cache-bypassing) accesses, so that no
   // whole-cache write-back or invalidate is needed around the ticket.
   const int tile = blockIdx.z * gridDim.x + blockIdx.x;
-  float* slab = partial + ((int64_t)tile * splits + blockIdx.y) * Wide::kTileFloats;
+  float* const tslab = partial + (int64_t)tile * splits * Wide::kTileFloats;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(tslab, 0, splits * Wide::kTileFloats * 4, 0x00020000);
+  constexpr int kSc1 = 16;  // cache policy bit of the buffer instructions: agent scope
+  const int voff = ((wid * 4) * 64 + lane) * 16;
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      __hip_atomic_store(&slab[(((nw * 4 + kw) * 4 + q) * 4 + r) * 64 + lane], fin[q][r], __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+  for (int j = 0; j < 4; ++j)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, fin[j]), rsrc, voff + j * 1024,
+                                           (int)blockIdx.y * Wide::kTileFloats * 4, kSc1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
   __builtin_amdgcn_s_barrier();
   if (tid == 0) {
@@ -1001,55 +1066,38 @@ stages_done:
     *flag = last;
   }
   __syncthreads();
-  stamp(4);
   if (*flag == 0) return;
-  const float* tslab = partial + (int64_t)tile * splits * Wide::kTileFloats;
-  // thread -> 16 consecutive floats (one register row quarter): element e0 = 16 * tid
   {
-    const int e0 = 16 * tid;
-    float a[16];
+    float4v a[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) a[e] = 0.f;
-    // four slabs' worth of loads in flight at a time (each one is a trip to memory); the sum runs in slab order
-    for (int s0 = 0; s0 < splits; s0 += 4) {
-      unsigned long long v[4][8];
+    for (int j = 0; j < 4; ++j) a[j] = float4v{0.f, 0.f, 0.f, 0.f};
+    // two slabs' worth of loads in flight at a time (each one is a trip to memory); the sum runs in slab order
+    for (int s0 = 0; s0 < splits; s0 += 2) {
+      float4v v[2][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int s2 = min(s0 + j, splits - 1);
-        const unsigned long long* src =
-            reinterpret_cast<const unsigned long long*>(tslab + (int64_t)s2 * Wide::kTileFloats + e0);
+      for (int q = 0; q < 2; ++q) {
+        const int s2 = min(s0 + q, splits - 1);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[j][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < 4; ++j)
+          v[q][j] = __builtin_bit_cast(
+              float4v, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + j * 1024, s2 * Wide::kTileFloats * 4, kSc1));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float keep = (s0 + j < splits) ? 1.f : 0.f;
+      for (int q = 0; q < 2; ++q) {
+        const float keep = (s0 + q < splits) ? 1.f : 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          a[2 * e] += keep * __uint_as_float((uint32_t)v[j][e]);
-          a[2 * e + 1] += keep * __uint_as_float((uint32_t)(v[j][e] >> 32));
-        }
+        for (int j = 0; j < 4; ++j) a[j] += keep * v[q][j];
       }
     }
-    // element e0 + e: lane = (e0 + e) & 63, reg = e0 >> 6 -> (strip, q, r)
-    const int l0 = e0 & 63, reg = e0 >> 6;
-    const int r = reg & 3, q = (reg >> 2) & 3, strip = reg >> 4;
-    const int m = m0 + 16 * q + 4 * (l0 >> 4) + r;
-    const int nn = blockIdx.x * 128 + 16 * strip;  // l0 & 15 == 0: the 16 floats are the strip's 16 columns
-    if (m < M) {
-      short8 o0, o1;
+    const float bv = bias ? Conv<T>::to_f32(bias[n]) : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float b0 = bias ? Conv<T>::to_f32(bias[nn + e]) : 0.f;
-        const float b1 = bias ? Conv<T>::to_f32(bias[nn + 8 + e]) : 0.f;
-        o0[e] = (short)Conv<T>::from_f32(a[e] + b0);
-        o1[e] = (short)Conv<T>::from_f32(a[8 + e] + b1);
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = mrow + 8 * j + e;
+        if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(a[j][e] + bv);
       }
-      *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + nn) = o0;
-      *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + nn + 8) = o1;
-    }
   }
-  stamp(5);
 }
 
 struct GemmPlan {
@@ -1084,13 +1132,8 @@ static GemmPlan plan_awq_gemm(int M, int N, int K) {
 
 static constexpr int kMaxTiles = 4096;  // ticket words at the head of the workspace
 
-struct WidePlan {
-  bool ok;
-  int tiles, splits, stages_per_split, mblocks;
-};
-
 // The wide kernel needs K in whole 512-k stages, N in whole 128-column tiles and 128-k scale groups.
-static WidePlan plan_awq_wide(int M, int N, int K, int group_size, bool partial_mode = false) {
+WidePlan plan_awq_wide(int M, int N, int K, int group_size, bool partial_mode) {
   // 0: never, 1: where it is expected to be faster, 2: wherever the shape allows (read per call: a test hook)
   const char* env_wide_s = getenv("SGLK_AWQ_WIDE");
   const int env_wide = env_wide_s ? atoi(env_wide_s) : 1;
@@ -1210,7 +1253,6 @@ static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* pac
                            int K, int64_t x_stride, int64_t out_stride, int dtype, const float* xsum, int64_t xs_stride,
                            int partial_mode, hipStream_t s, int act_mode = 0, float* xsum_out = nullptr,
                            int64_t xs_out_stride = 0) {
-  static const int env_abl = getenv("SGLK_AWQ_ABL") ? atoi(getenv("SGLK_AWQ_ABL")) : 0;  // timing experiments only
   dim3 wgrid(N / 128, wp.splits, wp.mblocks);
 #define SGLK_WIDE_LAUNCH(XS, MQ)                                                                                   \
   {                                                                                                                \
@@ -1222,14 +1264,13 @@ static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* pac
     }                                                                                                              \
     hipLaunchKernelGGL((awq_gemm_wide_kernel<T, XS, MQ>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x,     \
                        packed, (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial,    \
-                       tickets, M, N, K, wp.stages_per_split, wp.splits, x_stride, out_stride, env_abl, xsum,      \
-                       xs_stride, partial_mode, act_mode, xsum_out, xs_out_stride);                                \
+                       tickets, M, N, K, wp.stages_per_split, wp.splits, x_stride, out_stride, xsum, xs_stride,    \
+                       partial_mode, act_mode, xsum_out, xs_out_stride);                                           \
   }
 #define SGLK_WIDE_LAUNCH_MQ(XS)            \
   {                                        \
-    if (M <= 16) SGLK_WIDE_LAUNCH(XS, 1)   \
-    else if (M <= 32) SGLK_WIDE_LAUNCH(XS, 2) \
-    else SGLK_WIDE_LAUNCH(XS, 4)           \
+    if (M <= 32) SGLK_WIDE_LAUNCH(XS, 1)   \
+    else SGLK_WIDE_LAUNCH(XS, 2)           \
   }
   SGLK_DISPATCH_HALF(dtype, T, {
     if (xsum) SGLK_WIDE_LAUNCH_MQ(true) else SGLK_WIDE_LAUNCH_MQ(false)
@@ -1362,6 +1403,16 @@ static int static_scratch(void** ptr) {
   *ptr = g_scratch_ptr[dev];
   return SGLK_OK;
 }
+
+#if SGLK_ABL & 64
+__attribute__((visibility("default"))) int sglk_debug_read_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(long long) * 256 * 24);
+}
+__attribute__((visibility("default"))) int sglk_debug_clear_stamps(void) {
+  static long long zeros[256 * 24];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros));
+}
+#endif
 
 int64_t sglk_awq_gemm_static_max_workspace_bytes(void) { return kStaticWsBytes; }
 

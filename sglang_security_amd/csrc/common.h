@@ -47,6 +47,7 @@ typedef short short4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef int int4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
 typedef int int2v __attribute__((ext_vector_type(2)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bfloat8 __attribute__((ext_vector_type(8)));

@@ -140,23 +140,33 @@ def test_attention_block_sums():
 
 
 def test_fused_decode_step_matches_unfused():
-    """Two decoders with identical weights and batch: one runs the layer fusion, one the plain op sequence."""
+    """Two decoders with identical weights and batch: one runs the layer fusion, one the plain op sequence.  Both are
+    fed the plain decoder's tokens after every step (a greedy pick between two logits one rounding apart may
+    legitimately differ, and the sequences would part there)."""
     from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
 
     cfg = LlamaConfig.tiny()
-    outs = []
+    decs = []
     for fused in (False, True):
         dec = LlamaDecoder(cfg, batch=6, pool_slots=1 + 64 + 6 * 24, max_ctx=96, device=DEV, seed=0)
         dec.setup_shared_prefix_batch(prefix_len=64, suffix_len=5)
         dec.enable_shared_prefix(True)
         assert dec.enable_fusion(fused) == fused
-        for _ in range(3):
-            dec.step()
+        decs.append(dec)
+    ref, fus = decs
+    for _ in range(3):
+        ref.step()
+        fus.step()
         torch.cuda.synchronize()
-        outs.append((dec.logits.float().cpu().clone(), dec.next_ids.cpu().clone(), dec.k_pool[1].float().cpu().clone()))
-    (l0, t0, k0), (l1, t1, k1) = outs
-    assert torch.isfinite(l1).all()
-    assert (l0 - l1).abs().max().item() < 0.05 * max(1.0, l0.abs().max().item())
+        l0, l1 = ref.logits.float().cpu(), fus.logits.float().cpu()
+        assert torch.isfinite(l1).all()
+        assert (l0 - l1).abs().max().item() < 0.05 * max(1.0, l0.abs().max().item())
+        # same pick wherever the plain decoder's pick is clear of the runner-up by more than the tolerance
+        top = l0.topk(2, dim=-1).values
+        clear = (top[:, 0] - top[:, 1]) > 0.1
+        assert torch.equal(ref.next_ids.cpu()[clear], fus.next_ids.cpu()[clear])
+        fus.input_ids.copy_(ref.input_ids)
+    k0, k1 = ref.k_pool[1].float().cpu(), fus.k_pool[1].float().cpu()
     assert (k0 - k1).abs().max().item() < 0.05 * max(1.0, k0.abs().max().item())
 
 

@@ -17,6 +17,8 @@ ap.add_argument("--iters", type=int, default=40)
 ap.add_argument("--dense", action="store_true")
 ap.add_argument("--copies", type=int, default=0, help="weight copies to rotate over (1: weights stay in the Infinity Cache)")
 ap.add_argument("--eager", action="store_true", help="plain launches, no graph (counter collection)")
+ap.add_argument("--fused", action="store_true", help="the forms the fused decode step launches: fp32 split-K partials with the "
+                "producer's block sums (qkv, o, down) and the gated-activation epilogue (gate_up)")
 ap.add_argument("--stamps", action="store_true", help="per-phase clock stamps of the wide AWQ kernel (run with SGLK_AWQ_ABL=16)")
 args = ap.parse_args()
 dev = "cuda"
@@ -43,13 +45,54 @@ for name, K, N in shapes:
     work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), ops.dense_gemm_workspace_bytes(M, N, K) if args.dense else 0,
                            256), dtype=torch.uint8, device=dev)
 
+    if args.fused:
+        xs = torch.zeros(K // 128, M, dtype=torch.float32, device=dev)
+        splits = ops.awq_gemm_partial_splits(M, N, K, 128)
+        part = torch.empty(max(splits, 1) * M * N, dtype=torch.float32, device=dev)
+        act = torch.empty(M, N // 2, dtype=torch.bfloat16, device=dev)
+        xs_out = torch.zeros(N // 256, M, dtype=torch.float32, device=dev)
+
     def run(i):
         w = ws[i % copies]
-        if args.dense:
+        if args.fused and name == "gate_up":
+            ops.awq_gemm_silu_mul(x, w[0], w[1], w[2], act, xs, xs_out)
+        elif args.fused:
+            ops.awq_gemm_partial(x, w[0], w[1], w[2], part, xs)
+        elif args.dense:
             ops.dense_gemm_nt(x, w[0], None, out, work)
         else:
             ops.awq_gemm(x, w[0], w[1], w[2], None, out, work)
 
+    if args.stamps and args.fused:
+        import ctypes
+        import numpy as np
+        from sglang_security_amd import _lib
+        L = ctypes.CDLL(_lib.LIB_PATH)
+        for i in range(3):
+            run(i)
+        torch.cuda.synchronize()
+        L.sglk_debug_clear_stamps()
+        run(3)
+        torch.cuda.synchronize()
+        buf = np.zeros(256 * 24, dtype=np.int64)
+        L.sglk_debug_read_stamps(buf.ctypes.data_as(ctypes.c_void_p))
+        t = buf.reshape(256, 24).astype(np.float64)
+        t = t[t[:, 0] != 0]
+        t0 = t[:, 0:1]  # per block: the clocks of different XCDs are not aligned
+        cols = ["start", "prologue"] + [f"st{k}" for k in range(10)] + ["drained", "reduced", "stored", "sums_read", "s2:w_landed", "s2:x_landed", "s2:barrier", "p:issued", "p:w0", "p:x0", "e:written", "e:barrier"]
+        msg = [f"{name}: blocks={t.shape[0]}"]
+        for k in range(24):
+            col = t[:, k]
+            ok = col != 0
+            if ok.any():
+                d = (col[ok] - t0[ok, 0]) / 100.0
+                msg.append(f"{cols[k]} {np.median(d):.2f}/{d.max():.2f}")
+        print("  ".join(msg), flush=True)
+        st = (t[:, 0] - t[:, 0].min()) / 100.0
+        print("   start by block id:", " ".join(f"{v:.2f}" for v in st[:24]), "...", " ".join(f"{v:.2f}" for v in st[-8:]), flush=True)
+        print("   start percentiles 0/1/5/25/50/95/100:", " ".join(f"{np.percentile(st, q):.2f}" for q in (0, 1, 5, 25, 50, 95, 100)),
+              flush=True)
+        continue
     if args.stamps:
         for i in range(3):
             run(i)
