@@ -586,9 +586,16 @@ SGLK_API int sglk_free_uncached(void* p);
 /* ------------------------------------------------------------------ R1-R4: radix tree (host) -- */
 
 /* Native prefix tree behind RadixCache (python/sglang/srt/mem_cache/radix_cache.py:77-653,
- * tree_node.py:28-79).  Host-side, no GPU.  Node handles are stable int64 ids (root = 0).
- * compat: 1 reproduces the fork's behaviour bit for bit (fuzzy key match with up to 11 mismatches,
- * private root, 1024-token chunks); 0 is the exact-match upstream behaviour. */
+ * tree_node.py:28-79).  Host-side, no GPU.
+ * Node handles are int64: (slot generation << 32) | slot index.  A node that leaves the tree (eviction, hit-rate
+ * release, reset, an orphaned subtree once unlocked) is destroyed and its slot's generation bumped, so a handle
+ * kept past its node -- a privacy verdict that arrives late, a request's last_node after a reset -- resolves
+ * to nothing: setters return SGLK_EINVAL, lock calls return 0 and change nothing.  sglk_radix_root gives the
+ * current root's handle (it changes at every reset).
+ * compat: 1 reproduces the fork's behaviour bit for bit (fuzzy key match with up to 11 mismatches, private
+ * root whose child an insert by another user overwrites, 1024-token chunks); 2 is the same with the slot leak
+ * of that overwrite closed (the orphaned subtree's slots go back to the free queue); 0 is the exact-match
+ * upstream behaviour. */
 SGLK_API int64_t sglk_radix_create(int compat_fork);
 SGLK_API void sglk_radix_destroy(int64_t tree);
 SGLK_API void sglk_radix_reset(int64_t tree);
@@ -614,6 +621,9 @@ SGLK_API int64_t sglk_radix_take_freed(int64_t tree, int64_t* out, int64_t cap);
 SGLK_API int64_t sglk_radix_evictable_size(int64_t tree);
 SGLK_API int64_t sglk_radix_protected_size(int64_t tree);
 SGLK_API int64_t sglk_radix_total_size(int64_t tree);
+SGLK_API int64_t sglk_radix_root(int64_t tree);
+/* nodes alive in host memory (reachable ones plus orphans still locked by a request) */
+SGLK_API int64_t sglk_radix_live_nodes(int64_t tree);
 /* SafeKV node state (tree_node.py:50-52; private_client.py:125-140 flips these asynchronously) */
 SGLK_API int sglk_radix_node_set_privacy(int64_t tree, int64_t node, int is_private, int need_check);
 SGLK_API int sglk_radix_node_get(int64_t tree, int64_t node, int64_t* fields /*[12]*/);

@@ -381,9 +381,17 @@ def gen_radix():
         rc.set_epoch(0)
         alloc = RL.FakeAllocator()
         judge = RL.ScriptedJudgeClient(decide)
-        tree = rc.RadixCache(None, alloc, page_size=1, private_judge_client=judge)
+        pool = RL.FakeReqPool()
+        tree = rc.RadixCache(pool, alloc, page_size=1, private_judge_client=judge)
         steps = []
         handles = {}
+        reqs = {}
+        next_slot = [100000]  # slots handed to requests (the scripted inserts use small numbers)
+
+        def take(n):
+            s0 = next_slot[0]
+            next_slot[0] += n
+            return torch.arange(s0, s0 + n, dtype=torch.int64)
         for op in script:
             rec = dict(op)
             kind = op["op"]
@@ -408,6 +416,42 @@ def gen_radix():
                 rec["ret"] = int(tree.dec_lock_ref(handles[op["handle"]]))
             elif kind == "evict":
                 tree.evict(op["n"])
+            elif kind in ("req_start", "req_chunk"):
+                # what Req.init_next_round_input + ScheduleBatch.prepare_for_extend do around the tree
+                # (schedule_batch.py:630-656,1275): match on all but the last token to fill, lock the node, give
+                # the rest fresh slots and write the request's row
+                if kind == "req_start":
+                    r = RL.FakeReq(op["rid"], op["tokens"], op.get("user"))
+                    r.req_pool_idx = op["row"]
+                    reqs[op["rid"]] = r
+                    r.fill_ids = r.origin_input_ids[: op.get("fill", len(r.origin_input_ids))]
+                    v, node = tree.match_prefix(rid=r.rid, user_id=r.user_id, key=r.fill_ids[:-1])
+                    r.prefix_indices, r.last_node = v, node
+                    tree.inc_lock_ref(node)
+                    pool.write((r.req_pool_idx, slice(0, len(v))), v.to(torch.int32))
+                else:
+                    r = reqs[op["rid"]]
+                    r.fill_ids = r.origin_input_ids[: op["fill"]]
+                have = len(r.prefix_indices)
+                new = take(len(r.fill_ids) - have)
+                pool.write((r.req_pool_idx, slice(have, len(r.fill_ids))), new.to(torch.int32))
+                rec["prefix"] = [int(t) for t in r.prefix_indices]
+            elif kind == "req_unfinished":
+                r = reqs[op["rid"]]
+                tree.cache_unfinished_req(r)
+                rec["prefix"] = [int(t) for t in r.prefix_indices]
+                rec["last_node_key"] = [int(t) for t in (r.last_node.key or [])]
+                rec["row"] = [int(t) for t in pool.req_to_token[r.req_pool_idx, : len(r.fill_ids)]]
+            elif kind == "req_finished":
+                r = reqs[op["rid"]]
+                r.output_ids = list(op["output"])
+                n_all = len(r.origin_input_ids) + len(r.output_ids) - 1
+                have = len(r.fill_ids)
+                if n_all > have:  # decode steps: one slot per generated token
+                    pool.write((r.req_pool_idx, slice(have, n_all)), take(n_all - have).to(torch.int32))
+                npool = len(pool.freed)
+                tree.cache_finished_req(r)
+                rec["pool_freed"] = pool.freed[npool:]
             elif kind == "set_public":
                 # what PrivateJudgeClient._response_task does (private_client.py:125-140)
                 for n in judge.nodes:
@@ -549,6 +593,42 @@ def gen_radix():
     ] + burst + [
         dict(op="unlock", handle="h"),
         dict(op="match", key=g + g3, user="0"),
+        dict(op="evict", n=1000),
+    ])
+    # 8. request life cycle (radix_cache.py:160-240), user "0": a chunked prefill caches its first chunk
+    #    (cache_unfinished_req: insert, re-match WITHOUT a user id, row rewritten with the tree's slots), two
+    #    requests with the same prompt run side by side and the second to finish frees its duplicate slots
+    slot[0] = 1
+    p1, p2 = toks(48), toks(20)
+    run("req_cycle_user0", [
+        dict(op="req_start", rid="a", row=1, tokens=p1 + p2 + [7], user="0", fill=40),
+        dict(op="req_unfinished", rid="a"),
+        dict(op="req_chunk", rid="a", fill=69),
+        dict(op="req_start", rid="b", row=2, tokens=p1 + p2 + [7], user="0"),
+        dict(op="req_start", rid="c", row=3, tokens=p1 + toks(9), user="0"),
+        dict(op="req_unfinished", rid="a"),
+        dict(op="req_finished", rid="a", output=[11, 12, 13]),
+        dict(op="req_finished", rid="b", output=[11, 12, 14, 15]),
+        dict(op="evict", n=10),
+        dict(op="req_finished", rid="c", output=[5]),
+        dict(op="match", key=p1 + p2 + [7, 11, 12], user="0"),
+        dict(op="evict", n=1000),
+    ])
+    # 9. the same with users other than "0": every insert stops at the private root and overwrites the child
+    #    (radix_cache.py:510-514,556); the user-less re-match of cache_unfinished_req still walks the new branch
+    slot[0] = 1
+    q1, q2 = toks(36), toks(12)
+    run("req_cycle_users", [
+        dict(op="req_start", rid="a", row=1, tokens=q1 + q2, user="alice", fill=30),
+        dict(op="req_unfinished", rid="a"),
+        dict(op="req_chunk", rid="a", fill=48),
+        dict(op="req_start", rid="b", row=2, tokens=q1 + toks(5), user="bob"),
+        dict(op="req_finished", rid="a", output=[3, 4]),
+        dict(op="req_start", rid="c", row=3, tokens=q1 + q2 + [3, 4], user="alice"),
+        dict(op="req_finished", rid="b", output=[9]),
+        dict(op="req_finished", rid="c", output=[8, 8]),
+        dict(op="match", key=q1 + q2, user="alice"),
+        dict(op="match", key=q1 + q2, user="bob"),
         dict(op="evict", n=1000),
     ])
     os.makedirs(OUT, exist_ok=True)

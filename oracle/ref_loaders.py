@@ -156,6 +156,37 @@ class FakeAllocator:
         self.freed.append(torch.as_tensor(idx).clone())
 
 
+class FakeReqPool:
+    """ReqToTokenPool stand-in (memory_pool.py:54-99): the int32 table, write() and free()."""
+
+    def __init__(self, rows=8, width=4096):
+        import torch
+
+        self.req_to_token = torch.zeros(rows, width, dtype=torch.int32)
+        self.freed = []
+
+    def write(self, indices, values):
+        self.req_to_token[indices] = values
+
+    def free(self, idx):
+        self.freed.append(int(idx))
+
+
+class FakeReq:
+    """The fields of managers/schedule_batch.py Req that cache_finished_req / cache_unfinished_req touch."""
+
+    def __init__(self, rid, tokens, user, text=""):
+        self.rid = rid
+        self.origin_input_ids = list(tokens)
+        self.output_ids = []
+        self.fill_ids = []
+        self.prefix_indices = []
+        self.last_node = None
+        self.req_pool_idx = None
+        self.user_id = user
+        self.origin_input_text = text
+
+
 def load_radix_cache():
     """Reference RadixCache / TreeNode with package plumbing stubbed; epoch is settable through
     the returned namespace's set_epoch()."""

@@ -115,6 +115,8 @@ _SIGS = {
     "sglk_radix_evictable_size": (i64, [i64]),
     "sglk_radix_protected_size": (i64, [i64]),
     "sglk_radix_total_size": (i64, [i64]),
+    "sglk_radix_root": (i64, [i64]),
+    "sglk_radix_live_nodes": (i64, [i64]),
     "sglk_radix_node_set_privacy": (i32, [i64, i64, i32, i32]),
     "sglk_radix_node_get": (i32, [i64, i64, p]),
     "sglk_radix_node_key": (i64, [i64, i64, p, p, i64]),

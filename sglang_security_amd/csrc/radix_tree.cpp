@@ -13,7 +13,14 @@
 //   * new nodes cut into chunks of 1024 tokens (radix_cache.py:536-541)
 //   * per-node hit / user counters rolled over per epoch and the entropy-triggered subtree release
 //     (radix_cache.py:377-411)
+// compat = 2: the fork's semantics with its slot leak closed: a subtree orphaned by the root overwrite gives its
+//   unlocked slots back (locked nodes do when their last lock goes) and leaves the size counters.
 // compat = 0: exact-match keys, no ownership gate, no chunking (upstream RadixCache semantics), same epoch LRU.
+//
+// Node handles are (slot generation << 32) | slot index.  A node that leaves the tree (eviction, hit-rate release,
+// reset, an orphaned subtree once unlocked) is destroyed and its slot's generation bumped, so host memory follows
+// the live tree and a handle kept past its node (a privacy verdict that arrives late, a request's last_node after
+// a reset) resolves to nothing instead of to whichever node took the slot over.
 //
 // User ids are int64 handles chosen by the host: -1 = None, 0 = the string "0" (== the root's integer owner
 // under str()), -2 = the literal string "None" (what str(None) compares equal to in radix_cache.py:513).
@@ -73,33 +80,113 @@ struct Node {
   int64_t hit_pre = 0;
   int64_t u_cnt_pre = 0;
   int64_t epoch = 0;
+  bool orphan = false;          // cut off from the root, kept only because a request still locks it
+  bool slots_returned = false;  // its slots went back to the pool when it left the tree
+};
+
+struct Slot {
+  std::unique_ptr<Node> node;
+  uint32_t gen = 0;
 };
 
 struct Tree {
-  bool compat = true;
+  int compat = 1;
   int64_t epoch = 0;
-  std::vector<std::unique_ptr<Node>> nodes;
+  std::vector<Slot> slots;
+  std::vector<uint32_t> free_idx;
+  std::vector<Node*> dead;   // left the tree during the current call: destroyed when the call ends
+  std::vector<Node*> grace;  // left the tree but handed to the caller as match_prefix's last node (the hit-rate
+                             // release can cut off the very node it returns, radix_cache.py:385-390): kept until
+                             // the next call that changes the tree, and beyond it for as long as it is locked
   Node* root = nullptr;
   int64_t evictable = 0, protected_ = 0;
   std::vector<int64_t> freed;
   std::mutex mu;  // the judge thread flips privacy bits while the scheduler thread walks the tree
 
   Node* make() {
-    nodes.emplace_back(new Node());
-    Node* n = nodes.back().get();
-    n->id = (int64_t)nodes.size() - 1;
+    uint32_t idx;
+    if (!free_idx.empty()) {
+      idx = free_idx.back();
+      free_idx.pop_back();
+    } else {
+      idx = (uint32_t)slots.size();
+      slots.emplace_back();
+    }
+    slots[idx].node.reset(new Node());
+    Node* n = slots[idx].node.get();
+    n->id = ((int64_t)slots[idx].gen << 32) | (int64_t)idx;
     n->users = std::make_shared<std::set<int64_t>>();
     n->epoch = epoch;  // tree_node.py:56
     return n;
   }
+  void release(Node* n) { dead.push_back(n); }
+  void flush_dead() {
+    for (Node* n : dead) {
+      const uint32_t idx = (uint32_t)(n->id & 0xFFFFFFFF);
+      slots[idx].node.reset();
+      slots[idx].gen += 1;
+      free_idx.push_back(idx);
+    }
+    dead.clear();
+  }
+  // start of every call that changes the tree: nodes kept for the previous caller go, unless locked meanwhile
+  void settle_grace() {
+    for (Node* n : grace) {
+      if (n->lock_ref > 0)
+        n->orphan = true;
+      else
+        release(n);
+    }
+    grace.clear();
+  }
   void reset() {
-    nodes.clear();
+    dead.clear();
+    grace.clear();
+    free_idx.clear();
+    for (size_t i = slots.size(); i-- > 0;) {
+      if (slots[i].node) {
+        slots[i].node.reset();
+        slots[i].gen += 1;
+      }
+      free_idx.push_back((uint32_t)i);  // slot 0 is handed out first: the root
+    }
     root = make();
     root->lock_ref = 1;
     evictable = protected_ = 0;
     freed.clear();
   }
-  Node* get(int64_t id) { return (id >= 0 && id < (int64_t)nodes.size()) ? nodes[(size_t)id].get() : nullptr; }
+  Node* get(int64_t id) {
+    const uint64_t idx = (uint64_t)id & 0xFFFFFFFFull;
+    if (id < 0 || idx >= slots.size()) return nullptr;
+    Slot& s = slots[(size_t)idx];
+    return (s.node && (int64_t)s.gen == (id >> 32)) ? s.node.get() : nullptr;
+  }
+  size_t live_nodes() const { return slots.size() - free_idx.size(); }
+
+  // A subtree that an overwrite cut off from the root (the fork's private-root quirk).  Unlocked nodes go now,
+  // locked ones when their last lock goes; with compat == 2 their slots return to the pool and their sizes leave
+  // the counters (compat == 1 keeps both, as the fork does).
+  void drop_orphan_node(Node* x) {
+    if (compat == 2 && !x->slots_returned) {
+      free_slots(x->value);
+      evictable -= (int64_t)x->value.size();
+    }
+    release(x);
+  }
+  void orphan_subtree(Node* top) {
+    std::vector<Node*> st{top};
+    while (!st.empty()) {
+      Node* x = st.back();
+      st.pop_back();
+      for (auto& it : x->children.items) st.push_back(it.second);
+      if (x->lock_ref > 0) {
+        x->orphan = true;  // a running request still walks up from here (never down: forget the children)
+        x->children.items.clear();
+      } else {
+        drop_orphan_node(x);
+      }
+    }
+  }
 
   // _key_match_page_size1 (radix_cache.py:52-62)
   int64_t key_match(const int32_t* a, int64_t na, const int32_t* b, int64_t nb) const {
@@ -172,7 +259,9 @@ struct Tree {
       if (x->lock_ref > 0) continue;
       for (auto& it : x->children.items) rel.push_back(it.second);
       free_slots(x->value);
+      x->slots_returned = true;
       delete_leaf(x);
+      release(x);
     }
   }
 
@@ -217,6 +306,11 @@ struct Tree {
       child->epoch = epoch;
     }
     *last = node;
+    auto it = std::find(dead.begin(), dead.end(), node);
+    if (it != dead.end()) {  // the release above cut off the node being returned
+      dead.erase(it);
+      grace.push_back(node);
+    }
     return (int64_t)out.size();
   }
 
@@ -258,7 +352,8 @@ struct Tree {
         nn->key.assign(key, key + n);
         nn->value.assign(val, val + n);
         nn->owner = user;
-        node->children.set(child_key, nn);  // may overwrite (and orphan) an existing child: the root quirk
+        if (Node* old = node->children.find(child_key)) orphan_subtree(old);  // the root quirk: overwritten child
+        node->children.set(child_key, nn);
         evictable += n;
         created.push_back(nn->id);
         node = nn;
@@ -328,6 +423,7 @@ struct Tree {
       evicted += (int64_t)x->value.size();
       free_slots(x->value);
       delete_leaf(x);
+      release(x);
       if (x->parent->children.empty()) {
         leaves.push_back(x->parent);
         siftdown(leaves, 0, leaves.size() - 1);
@@ -357,7 +453,9 @@ struct Tree {
         delta += (int64_t)n->value.size();
       }
       n->lock_ref -= 1;
-      n = n->parent;
+      Node* up = n->parent;
+      if (n->orphan && n->lock_ref == 0) drop_orphan_node(n);
+      n = up;
     }
     return delta;
   }
@@ -390,7 +488,7 @@ extern "C" {
 
 int64_t sglk_radix_create(int compat_fork) {
   Tree* t = new Tree();
-  t->compat = compat_fork != 0;
+  t->compat = compat_fork < 0 || compat_fork > 2 ? 1 : compat_fork;
   t->reset();
   return reinterpret_cast<int64_t>(t);
 }
@@ -410,8 +508,10 @@ int64_t sglk_radix_match_prefix(int64_t tree, const int32_t* key, int64_t key_le
   std::lock_guard<std::mutex> g(t->mu);
   std::vector<int64_t> out;
   Node* last = t->root;
+  t->settle_grace();
   const int64_t n = t->match(key, key_len, user_id, out, &last);
   if (last_node) *last_node = last->id;
+  t->flush_dead();
   const int64_t m = std::min(n, cap);
   if (m > 0 && out_slots) std::memcpy(out_slots, out.data(), sizeof(int64_t) * (size_t)m);
   return n;
@@ -422,7 +522,9 @@ int64_t sglk_radix_insert(int64_t tree, const int32_t* key, const int64_t* slots
   Tree* t = T(tree);
   std::lock_guard<std::mutex> g(t->mu);
   std::vector<int64_t> created;
+  t->settle_grace();
   const int64_t r = t->insert(key, slots, len, user_id, created);
+  t->flush_dead();
   if (n_new) *n_new = (int64_t)created.size();
   for (int64_t i = 0; i < (int64_t)created.size() && i < new_cap; ++i) new_nodes[i] = created[(size_t)i];
   return r;
@@ -431,17 +533,21 @@ int64_t sglk_radix_insert(int64_t tree, const int32_t* key, const int64_t* slots
 int64_t sglk_radix_inc_lock_ref(int64_t tree, int64_t node) {
   Tree* t = T(tree);
   std::lock_guard<std::mutex> g(t->mu);
-  return t->inc_lock(t->get(node));
+  return t->inc_lock(t->get(node));  // a stale handle resolves to nothing: no-op
 }
 int64_t sglk_radix_dec_lock_ref(int64_t tree, int64_t node) {
   Tree* t = T(tree);
   std::lock_guard<std::mutex> g(t->mu);
-  return t->dec_lock(t->get(node));
+  const int64_t d = t->dec_lock(t->get(node));
+  t->flush_dead();
+  return d;
 }
 void sglk_radix_evict(int64_t tree, int64_t num_tokens) {
   Tree* t = T(tree);
   std::lock_guard<std::mutex> g(t->mu);
+  t->settle_grace();
   t->evict(num_tokens);
+  t->flush_dead();
 }
 int64_t sglk_radix_take_freed(int64_t tree, int64_t* out, int64_t cap) {
   Tree* t = T(tree);
@@ -455,6 +561,14 @@ int64_t sglk_radix_take_freed(int64_t tree, int64_t* out, int64_t cap) {
 }
 int64_t sglk_radix_evictable_size(int64_t tree) { return T(tree)->evictable; }
 int64_t sglk_radix_protected_size(int64_t tree) { return T(tree)->protected_; }
+int64_t sglk_radix_root(int64_t tree) {
+  std::lock_guard<std::mutex> g(T(tree)->mu);
+  return T(tree)->root->id;
+}
+int64_t sglk_radix_live_nodes(int64_t tree) {
+  std::lock_guard<std::mutex> g(T(tree)->mu);
+  return (int64_t)T(tree)->live_nodes();
+}
 int64_t sglk_radix_total_size(int64_t tree) {
   std::lock_guard<std::mutex> g(T(tree)->mu);
   return T(tree)->total_size();

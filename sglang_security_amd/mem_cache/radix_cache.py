@@ -7,8 +7,11 @@ tree_node.py: same constructor, same BasePrefixCache methods (base_prefix_cache.
 may later set `node.private = False` / `node.need_check_privacy = False` (private_client.py:125-140) on the
 node objects it holds.
 
-`compat_fork=True` (default) reproduces the fork's behaviour bit for bit, quirks included; `False` gives the
-exact-match upstream semantics.  The epoch comes from `get_epoch` (reference: sglang.get_epoch,
+`compat_fork=True` reproduces the fork's behaviour bit for bit, quirks included -- among them a pool leak: an
+insert by any user other than "0" stops at the private root and overwrites the child with the same first token,
+whose slots are then never freed.  `compat_fork="fixed"` (the default) keeps the fork's semantics and closes that
+leak (the orphaned subtree's slots go back to the allocator, at once or when the last request using them ends);
+`False` gives the exact-match upstream semantics.  The epoch comes from `get_epoch` (reference: sglang.get_epoch,
 global_epoch.py), injectable for tests.
 """
 from __future__ import annotations
@@ -16,6 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 import time
+import weakref
 from typing import Callable, Dict, List, Optional, Tuple
 
 import numpy as np
@@ -64,7 +68,7 @@ def get_epoch() -> int:
 class TreeNode:
     """Handle on a native node; attribute names follow tree_node.py:28-79."""
 
-    __slots__ = ("_tree", "id", "prompt")
+    __slots__ = ("_tree", "id", "prompt", "__weakref__")
 
     def __init__(self, tree: "RadixCache", node_id: int):
         self._tree = tree
@@ -74,8 +78,14 @@ class TreeNode:
     def _fields(self):
         f = (C.c_int64 * 12)()
         if lib().sglk_radix_node_get(self._tree._h, self.id, f) != 0:
-            raise KeyError(f"no such node {self.id}")
+            raise KeyError(f"node {self.id} has left the tree")
         return list(f)
+
+    @property
+    def alive(self) -> bool:
+        """False once the node has been evicted, released or lost to a reset (the handle then names nothing)."""
+        f = (C.c_int64 * 12)()
+        return lib().sglk_radix_node_get(self._tree._h, self.id, f) == 0
 
     @property
     def parent(self) -> Optional["TreeNode"]:
@@ -92,6 +102,7 @@ class TreeNode:
 
     @private.setter
     def private(self, v: bool):
+        # on a node that has left the tree this changes nothing (the reference mutates a dead object there)
         lib().sglk_radix_node_set_privacy(self._tree._h, self.id, 1 if v else 0, -1)
 
     @property
@@ -150,7 +161,7 @@ class TreeNode:
 
 class RadixCache:
     def __init__(self, req_to_token_pool, token_to_kv_pool_allocator, page_size: int, private_judge_client,
-                 disable: bool = False, enable_kv_cache_events: bool = False, compat_fork: bool = True,
+                 disable: bool = False, enable_kv_cache_events: bool = False, compat_fork="fixed",
                  get_epoch_fn: Optional[Callable[[], int]] = None):
         if page_size != 1:
             raise NotImplementedError("the native tree implements page_size == 1 (the reference default, server_args.py:78)")
@@ -162,10 +173,13 @@ class RadixCache:
         self.private_judge_client = private_judge_client
         self.device = token_to_kv_pool_allocator.device if token_to_kv_pool_allocator else torch.device("cpu")
         self._get_epoch = get_epoch_fn or get_epoch
-        self._h = lib().sglk_radix_create(1 if compat_fork else 0)
+        mode = {True: 1, False: 0, "fixed": 2}.get(compat_fork)
+        if mode is None:
+            raise ValueError('compat_fork is True (the fork, bit for bit), "fixed" (its slot leak closed) or False (upstream)')
+        self._h = lib().sglk_radix_create(mode)
         self._users: Dict[str, int] = {"0": 0, "None": -2}
         self._user_names: Dict[int, object] = {0: "0", -2: "None", -1: None}
-        self._nodes: Dict[int, TreeNode] = {}
+        self._nodes = weakref.WeakValueDictionary()  # handles live as long as somebody holds them
         self.reset()
 
     def __del__(self):
@@ -222,7 +236,7 @@ class RadixCache:
     def reset(self):
         lib().sglk_radix_reset(self._h)
         self._nodes.clear()
-        self.root_node = self._node(0)
+        self.root_node = self._node(int(lib().sglk_radix_root(self._h)))
 
     def match_prefix(self, key: List[int], user_id: Optional[str] = None, **kwargs) -> Tuple[torch.Tensor, TreeNode]:
         if self.disable or len(key) == 0:
@@ -317,6 +331,10 @@ class RadixCache:
     def total_size(self) -> int:
         return int(lib().sglk_radix_total_size(self._h))
 
+    def live_nodes(self) -> int:
+        """Nodes held in host memory: the reachable tree plus orphans still locked by a running request."""
+        return int(lib().sglk_radix_live_nodes(self._h))
+
     def take_events(self):
         return []
 
@@ -327,7 +345,7 @@ class RadixCache:
         ids = (C.c_int64 * max(n, 1))()
         lib().sglk_radix_dump(self._h, ids, n)
         out = []
-        depth = {0: -1}
+        depth = {self.root_node.id: -1}
         for i in range(n):
             node = self._node(ids[i])
             f = node._fields()

@@ -182,7 +182,7 @@ class _Req:
 class PrefixCacheHarness:
     """One request at a time through match_prefix -> alloc -> extend -> first token -> cache_finished_req."""
 
-    def __init__(self, dec: LlamaDecoder, pool_tokens: int, max_ctx: int, judge=None, compat_fork: bool = True,
+    def __init__(self, dec: LlamaDecoder, pool_tokens: int, max_ctx: int, judge=None, compat_fork="fixed",
                  use_graph: bool = True, resident_bf16: bool = False):
         c = dec.cfg
         dev = dec.device

@@ -66,6 +66,8 @@ class PrivateJudgeClient:
         if parent is not None and not parent.need_check_privacy and parent.private:
             node.need_check_privacy = False
             return
+        if self.detector is None:
+            return  # nobody consumes the queue: the node simply stays private and unchecked
         text = self.judged_text(prompt)
         self.task_queue.put(PrivateNodeTask(node=node, task_type="update_private", context=text, prompt=text,
                                             request_id="", timestamp=time.time(), privacy=True))

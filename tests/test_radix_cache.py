@@ -24,6 +24,29 @@ class Alloc:
         self.freed.append(torch.as_tensor(idx).clone())
 
 
+class ReqPool:
+    """ReqToTokenPool stand-in (memory_pool.py:54-99 of the reference): the int32 table, write() and free()."""
+
+    def __init__(self, rows=8, width=4096):
+        self.req_to_token = torch.zeros(rows, width, dtype=torch.int32)
+        self.freed = []
+
+    def write(self, indices, values):
+        self.req_to_token[indices] = values
+
+    def free(self, idx):
+        self.freed.append(int(idx))
+
+
+class Req:
+    """The fields of the reference's Req that cache_finished_req / cache_unfinished_req touch."""
+
+    def __init__(self, rid, tokens, user):
+        self.rid, self.origin_input_ids, self.output_ids, self.fill_ids = rid, list(tokens), [], []
+        self.prefix_indices, self.last_node, self.req_pool_idx = [], None, None
+        self.user_id, self.origin_input_text = user, ""
+
+
 class Judge:
     def __init__(self):
         self.nodes = []
@@ -35,9 +58,16 @@ class Judge:
 @pytest.mark.parametrize("name", sorted(TRACES.keys()))
 def test_trace(name):
     epoch = [0]
-    alloc, judge = Alloc(), Judge()
-    tree = RadixCache(None, alloc, page_size=1, private_judge_client=judge, get_epoch_fn=lambda: epoch[0])
-    handles = {}
+    alloc, judge, pool = Alloc(), Judge(), ReqPool()
+    tree = RadixCache(pool, alloc, page_size=1, private_judge_client=judge, compat_fork=True,
+                      get_epoch_fn=lambda: epoch[0])
+    handles, reqs, next_slot = {}, {}, [100000]
+
+    def take(n):
+        s0 = next_slot[0]
+        next_slot[0] += n
+        return torch.arange(s0, s0 + n, dtype=torch.int64)
+
     for i, st in enumerate(TRACES[name]):
         kind = st["op"]
         nfreed = len(alloc.freed)
@@ -53,7 +83,7 @@ def test_trace(name):
                 v, node = tree.match_prefix(st["key"])
             assert v.dtype == torch.int64
             assert v.tolist() == st["ret"], (name, i, "matched slots")
-            assert (node.key if node.id != 0 else []) == st["last_node_key"], (name, i, "last node")
+            assert (node.key if node != tree.root_node else []) == st["last_node_key"], (name, i, "last node")
             if "handle" in st:
                 handles[st["handle"]] = node
         elif kind == "lock":
@@ -62,6 +92,39 @@ def test_trace(name):
             assert tree.dec_lock_ref(handles[st["handle"]]) == st["ret"]
         elif kind == "evict":
             tree.evict(st["n"])
+        elif kind in ("req_start", "req_chunk"):
+            # the scheduler's steps around the tree (schedule_batch.py:630-656,1275 of the reference)
+            if kind == "req_start":
+                r = Req(st["rid"], st["tokens"], st.get("user"))
+                r.req_pool_idx = st["row"]
+                reqs[st["rid"]] = r
+                r.fill_ids = r.origin_input_ids[: st.get("fill", len(r.origin_input_ids))]
+                v, node = tree.match_prefix(rid=r.rid, user_id=r.user_id, key=r.fill_ids[:-1])
+                r.prefix_indices, r.last_node = v, node
+                tree.inc_lock_ref(node)
+                pool.write((r.req_pool_idx, slice(0, len(v))), v.to(torch.int32))
+            else:
+                r = reqs[st["rid"]]
+                r.fill_ids = r.origin_input_ids[: st["fill"]]
+            have = len(r.prefix_indices)
+            pool.write((r.req_pool_idx, slice(have, len(r.fill_ids))), take(len(r.fill_ids) - have).to(torch.int32))
+            assert [int(t) for t in r.prefix_indices] == st["prefix"], (name, i, "matched prefix")
+        elif kind == "req_unfinished":
+            r = reqs[st["rid"]]
+            tree.cache_unfinished_req(r)
+            assert [int(t) for t in r.prefix_indices] == st["prefix"], (name, i, "prefix after cache_unfinished_req")
+            assert (r.last_node.key if r.last_node != tree.root_node else []) == st["last_node_key"], (name, i)
+            assert pool.req_to_token[r.req_pool_idx, : len(r.fill_ids)].tolist() == st["row"], (name, i, "row")
+        elif kind == "req_finished":
+            r = reqs[st["rid"]]
+            r.output_ids = list(st["output"])
+            n_all = len(r.origin_input_ids) + len(r.output_ids) - 1
+            have = len(r.fill_ids)
+            if n_all > have:
+                pool.write((r.req_pool_idx, slice(have, n_all)), take(n_all - have).to(torch.int32))
+            npool = len(pool.freed)
+            tree.cache_finished_req(r)
+            assert pool.freed[npool:] == st["pool_freed"], (name, i, "request row freed")
         elif kind == "set_public":
             for n in judge.nodes:
                 if n.need_check_privacy and len(n.key) >= st.get("min_len", 0):
@@ -79,7 +142,7 @@ def test_trace(name):
 def test_empty_and_disabled():
     tree = RadixCache(None, Alloc(), 1, Judge(), get_epoch_fn=lambda: 0)
     v, n = tree.match_prefix([])
-    assert v.numel() == 0 and n.id == 0
+    assert v.numel() == 0 and n == tree.root_node
     assert tree.insert([], torch.zeros(0, dtype=torch.int64)) == 0
     off = RadixCache(None, Alloc(), 1, Judge(), disable=True, get_epoch_fn=lambda: 0)
     assert off.insert([1, 2, 3], torch.arange(3)) == 0
@@ -159,3 +222,90 @@ def test_privacy_hook_end_to_end():
     assert PrivateJudgeClient.judged_text("a\nAssistant: b\nc") == "hello, you are an simple assistant"
     assert PrivateJudgeClient.judged_text("only one line") == "only one line"
     judge.close()
+
+
+def test_stale_handle_after_reset_names_nothing():
+    """A privacy verdict that arrives after reset() must not touch the node that took over the slot: handles carry a
+    generation, and a stale one resolves to nothing (no-op setters, no-op lock calls)."""
+    judge = Judge()
+    tree = RadixCache(None, Alloc(), 1, judge, compat_fork=True, get_epoch_fn=lambda: 0)
+    tree.insert(list(range(10, 40)), torch.arange(30), user_id="0")
+    old = judge.nodes[-1]
+    old_root = tree.root_node
+    assert old.private and old.alive
+    tree.reset()
+    assert not old.alive and not old_root.alive and tree.root_node != old_root
+    tree.insert(list(range(50, 90)), torch.arange(40), user_id="0")
+    new = judge.nodes[-1]
+    assert (new.id & 0xFFFFFFFF) == (old.id & 0xFFFFFFFF) and new.id != old.id  # same slot, next generation
+    old.private = False            # the late verdict
+    old.need_check_privacy = False
+    assert new.private and new.need_check_privacy
+    before = (tree.evictable_size(), tree.protected_size())
+    assert tree.inc_lock_ref(old) == 0 and tree.dec_lock_ref(old) == 0
+    assert (tree.evictable_size(), tree.protected_size()) == before
+    with pytest.raises(KeyError):
+        _ = old.key
+
+
+def test_evicted_nodes_release_host_memory():
+    """Host memory follows the live tree: after many insert / evict rounds the node count is that of the tree, not
+    of everything ever inserted."""
+    import random
+
+    rng = random.Random(4)
+    for mode in (True, "fixed", False):
+        tree = RadixCache(None, Alloc(), 1, Judge(), compat_fork=mode, get_epoch_fn=lambda: 0)
+        nxt = 1
+        for _ in range(300):
+            key = [rng.randrange(50000) for _ in range(rng.randrange(5, 80))]
+            tree.insert(key, torch.arange(nxt, nxt + len(key)), user_id="0")
+            nxt += len(key)
+            if tree.evictable_size() > 400:
+                tree.evict(300)
+        assert tree.live_nodes() == len(tree.dump()) + 1  # + the root
+        assert tree.live_nodes() < 60
+        tree.evict(10 ** 9)
+        assert tree.live_nodes() == 1 and tree.total_size() == 0
+
+
+def test_fixed_mode_returns_orphaned_slots():
+    """compat_fork="fixed": the child that another user's insert overwrites at the private root gives its slots back
+    (at once when unlocked, at the last unlock otherwise) and leaves the size counters; compat_fork=True keeps the
+    fork's leak (evictable_size() drifts away from total_size())."""
+    a = list(range(100, 130))
+    # the fork, bit for bit: the overwritten child's 30 slots stay counted and are never freed
+    alloc = Alloc()
+    tree = RadixCache(None, alloc, 1, Judge(), compat_fork=True, get_epoch_fn=lambda: 0)
+    tree.insert(a, torch.arange(1, 31), user_id="alice")
+    tree.insert(a, torch.arange(31, 61), user_id="alice")
+    assert tree.evictable_size() == 60 and tree.total_size() == 30 and not alloc.freed
+    # leak closed
+    alloc = Alloc()
+    tree = RadixCache(None, alloc, 1, Judge(), get_epoch_fn=lambda: 0)
+    tree.insert(a, torch.arange(1, 31), user_id="alice")
+    tree.insert(a, torch.arange(31, 61), user_id="alice")
+    assert tree.evictable_size() == 30 and tree.total_size() == 30
+    tree.evict(0)  # drains the free queue
+    assert sorted(int(t) for f in alloc.freed for t in f) == list(range(1, 31))
+    # a locked orphan returns its slots when the request lets go
+    alloc = Alloc()
+    tree = RadixCache(None, alloc, 1, Judge(), get_epoch_fn=lambda: 0)
+    tree.insert(a, torch.arange(1, 31), user_id="alice")
+    v, node = tree.match_prefix(a, user_id="alice")
+    assert len(v) == 30
+    tree.inc_lock_ref(node)
+    tree.insert(a, torch.arange(31, 61), user_id="bob")
+    assert node.alive and tree.protected_size() == 30 and tree.evictable_size() == 30
+    tree.dec_lock_ref(node)
+    tree.evict(0)
+    assert not node.alive and tree.protected_size() == 0 and tree.evictable_size() == 30 == tree.total_size()
+    assert sorted(int(t) for f in alloc.freed for t in f) == list(range(1, 31))
+
+
+@pytest.mark.gpu
+def test_traces_on_the_gpu_box():
+    """The trace suite again under the gpu marker: the native tree is host code, but this puts the bit-exact radix
+    replay into the same record as the device kernels."""
+    for name in sorted(TRACES.keys()):
+        test_trace(name)
