@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--tp", action="store_true",
                     help="the ranks form ONE tensor-parallel group (use with --model llama3-70b-tp8-rank --gpus 8): "
                          "peer-to-peer all-reduce after o / down, value = tokens/s of the one sharded model")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the device group: nccl (= RCCL, one rank per GPU) or gloo (rehearsal "
+                         "with several ranks sharing one GPU; ranks then map to GPU rank %% device_count)")
     ap.add_argument("--attn", default="auto", choices=["auto", "per_request", "shared_prefix"])
     ap.add_argument("--tiny", action="store_true", help="2-layer toy model (plumbing check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -180,24 +183,43 @@ def gemm_roofline(dec, cfg, B, stream):
                 ts.append(a.elapsed_time(b) * 1e3 / cfg.layers)
             per[name] = sorted(ts)[1]
     avg_us = sum(per.values()) / len(per)
-    # algorithmic bytes per launch: one layer's int4 weights + scales + zeros + bf16 in/out activations of its
-    # four projections, / 4 launches
+    # algorithmic bytes per launch: one layer's weights (+ scales and zeros) + the 16-bit input and output activations
+    # of its four projections, / 4 launches
     shapes = ((cfg.hidden, dec.q_size + 2 * dec.kv_size), (dec.q_size, cfg.hidden), (cfg.hidden, 2 * cfg.inter),
               (cfg.inter, cfg.hidden))
     act = 2 * B * sum(k + n for k, n in shapes)
     bytes_per_launch = (dec.layer_weight_bytes() + act) / 4.0
     ach = bytes_per_launch / (avg_us * 1e-6) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("awq_gemm_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    return {"bound": "hbm", "kernel": "awq_gemm_wide_kernel (fused int4 dequant + MFMA GEMM, M=64; 4 launches per layer)",
-            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": traffic,
+    kernel = {"awq": f"awq_gemm_wide_kernel (fused int4 dequant + MFMA GEMM, M={B}; 4 launches per layer)",
+              "fp8": f"fp8_scaled_mm kernel (e4m3 x e4m3 MFMA GEMM with per-token and per-channel scales, M={B}; 4 per layer)",
+              "bf16": f"dense_gemm_nt kernel (bf16 MFMA GEMM, M={B}; 4 per layer)"}[cfg.quant]
+    return {"bound": "hbm", "kernel": kernel,
+            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+            "traffic": pmc_traffic(cfg, B),
             "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(bytes_per_launch),
             "per_projection_us": {k: round(v, 2) for k, v in per.items()}}
+
+
+def pmc_traffic(cfg, B):
+    """HBM bytes per launch of the dominant kernel from the hardware counters.  Counters cannot be read inside this
+    process, so the figure comes from a committed collection (profiles/*_pmc_traffic.json) and is reported only when
+    that file says it was collected on the kernel source this tree holds (sha256 of awq.hip) for this workload;
+    otherwise null."""
+    import glob
+    import hashlib
+
+    if cfg.quant != "awq":
+        return None
+    try:
+        src = os.path.join(ROOT, "sglang_security_amd", "csrc", "awq.hip")
+        digest = hashlib.sha256(open(src, "rb").read()).hexdigest()
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            rec = json.load(open(path))
+            if rec.get("awq_hip_sha256") == digest and rec.get("hidden") == cfg.hidden and rec.get("batch") == B:
+                return rec.get("awq_gemm_hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
 
 
 def extend_ttft(cfg, B, prefix, suffix, dev):
@@ -244,12 +266,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    if args.dist_backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from sglang_security_amd.benchlib import aggregate
     from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
@@ -270,19 +297,24 @@ def main():
     dec = LlamaDecoder(cfg, B, slots, max_ctx, device=dev, max_kv_splits=args.kv_splits)
     dec.cu_count = torch.cuda.get_device_properties(dev).multi_processor_count
     tp = args.tp and world > 1
-    fused = (not args.no_fusion) and not tp and dec.enable_fusion(True)
+    fused = (not args.no_fusion) and dec.enable_fusion(True)
+    collective = None
     if tp:
-        import torch.distributed as dist
-        from sglang_security_amd.distributed.custom_all_reduce import CustomAllreduce
+        from sglang_security_amd.distributed import parallel_state
 
-        comm = CustomAllreduce(dist.new_group(backend="gloo"), dev)  # handles travel over a CPU group
-        if comm.disabled:
-            raise SystemExit(f"--tp: the peer-to-peer all-reduce does not support {world} ranks")
-        dec.enable_tp(comm)
+        # peer-to-peer kernels where they apply (2/4/6/8 ranks, < 16 MiB), the device group's collectives (RCCL under
+        # "nccl") everywhere else
+        group = parallel_state.initialize_model_parallel(world, backend=args.dist_backend, local_rank=local)
+        dec.enable_tp(group)
+        p2p = group.ca_comm is not None and not group.ca_comm.disabled
+        collective = "peer-to-peer kernels (RCCL for what they decline)" if p2p else f"{args.dist_backend} collectives"
+        if not p2p and args.dist_backend != "nccl":
+            args.no_graph = True  # host-staged collectives cannot be captured
 
     elapsed, graphed, attn_mode, stream = measure_decode(dec, args, dev, world, True, args.attn)
+    dec.check_tp_health()
     agg = aggregate(B, args.steps, 1 if tp else world, elapsed)
-    roof = gemm_roofline(dec, cfg, B, stream) if cfg.quant == "awq" else None
+    roof = gemm_roofline(dec, cfg, B, stream)
 
     wname = {"awq": "AWQ int4", "bf16": "bf16", "fp8": "fp8 w8a8"}[cfg.quant]
     wdesc = {"awq": "awq (int4 weights, G=128; bf16 activations and KV)",
@@ -300,6 +332,8 @@ def main():
                                f"{args.prefix + args.suffix}+step, greedy, random-init weights",
                    "attention": attn_mode, "layer_fusion": bool(fused), "graph": graphed, "parallelism": f"tp{world}" if tp else f"replicas x{world}", "layers": cfg.layers},
     }
+    if collective:
+        out["config"]["collective"] = collective
     # fraction of the HBM roofline for the whole step (unique bytes: weights + lm_head + KV with the prefix once)
     if not args.tiny:
         kv_tok = 2 * cfg.kv_heads * cfg.head_dim * 2 * cfg.layers

@@ -31,6 +31,7 @@ extern "C" {
 #define SGLK_EINVAL (-1)  /* bad shape / alignment / dtype: the reference raises RuntimeError here */
 #define SGLK_EHIP (-2)    /* a HIP runtime call failed */
 #define SGLK_EUNSUP (-3)  /* valid request this build has no kernel for */
+#define SGLK_ESTUCK (-4)  /* an all-reduce communicator whose peer never reached a barrier: see sglk_ar_stuck */
 
 SGLK_API const char* sglk_last_error(void);
 SGLK_API int sglk_version(void);
@@ -570,9 +571,17 @@ SGLK_API int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t 
  * (all_reduce_unreg, custom_all_reduce.hip:97-117) */
 SGLK_API int sglk_ar_all_reduce_unreg(int64_t fa, const void* inp, void* reg_buffer, void* out,
                                       int64_t numel, int dtype, int algo, void* stream);
-/* Number of thread blocks whose barrier wait gave up (a peer never arrived); synchronises.
- * No counterpart in the reference, whose barrier spins forever. */
+/* out[r] = rank r's registered `inp` (bytes_per_rank bytes each, a multiple of 16), in rank order: the peer-to-peer
+ * form of the all-gather GroupCoordinator.all_gather issues for vocab-parallel logits
+ * (python/sglang/srt/distributed/parallel_state.py:489-540), usable inside HIP graphs. */
+SGLK_API int sglk_ar_all_gather(int64_t fa, const void* inp, void* out, int64_t bytes_per_rank, void* stream);
+/* Failure handling; no counterpart in the reference, whose barrier spins forever.  A barrier wait that sees no
+ * peer within the time limit (default 30 s, or SGLK_AR_TIMEOUT_MS at init, or sglk_ar_set_timeout_ms) fills the
+ * output with NaN instead of a sum and raises a host-pinned word.  sglk_ar_stuck reads that word (1 = failed;
+ * does not synchronise: call it after the stream has been synchronised to judge the work before).  A failed
+ * communicator poisons every later output and its host entry points return SGLK_ESTUCK; make a new one. */
 SGLK_API int sglk_ar_stuck(int64_t fa);
+SGLK_API int sglk_ar_set_timeout_ms(int64_t fa, int64_t ms);
 /* IPC plumbing (hipIpcGetMemHandle / hipIpcOpenMemHandle / uncached allocation):
  * allocate_meta_buffer, get_meta_buffer_ipc_handle (custom_all_reduce.hip:146-170).
  * The handle names the allocation that holds dev_ptr; *offset_out is dev_ptr's offset in it. */

@@ -96,6 +96,8 @@ _SIGS = {
     "sglk_ar_all_reduce": (i32, [i64, p, p, i64, i32, i32, p]),
     "sglk_ar_all_reduce_unreg": (i32, [i64, p, p, p, i64, i32, i32, p]),
     "sglk_ar_stuck": (i32, [i64]),
+    "sglk_ar_set_timeout_ms": (i32, [i64, i64]),
+    "sglk_ar_all_gather": (i32, [i64, p, p, i64, p]),
     "sglk_ipc_handle_bytes": (i32, []),
     "sglk_ipc_get_handle": (i32, [p, p, p]),
     "sglk_ipc_open_handle": (p, [p]),

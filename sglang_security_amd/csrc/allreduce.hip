@@ -15,8 +15,15 @@
 //
 // Barriers: per (block, peer) 32-bit tickets in uncached memory.  Barrier number n of block b writes n
 // into slot [n & 1][b][my rank] of every peer and waits for n in its own slots; two slot sets keep a
-// fast rank's next barrier from overwriting a ticket a slow rank has not read yet.  A wait gives up
-// after a bounded number of polls and raises the block's `stuck` word instead of hanging the GPU.
+// fast rank's next barrier from overwriting a ticket a slow rank has not read yet.
+//
+// A wait that sees no peer within the communicator's time limit (wall clock, 100 MHz counter) does not hang the GPU
+// and does not return a sum either: the block records itself in `stuck`, raises the rank's sticky `failed` word and
+// a word in host-pinned memory, and fills its share of the output with NaN (all bits set).  Every later launch on
+// that communicator poisons its output at once without waiting, and the host entry points return SGLK_ESTUCK as
+// soon as they see the host word.  Peers waiting for the failed rank time out the same way, so the failure reaches
+// every rank.  Recovery is a new communicator.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -29,12 +36,19 @@ namespace {
 constexpr int kMaxRanks = 8;
 constexpr int kMaxBlocks = 64;
 constexpr int kThreads = 512;
-constexpr uint32_t kMaxPolls = 1u << 24;
+constexpr int64_t kDefaultTimeoutMs = 30000;
+constexpr int64_t kTicksPerMs = 100000;  // s_memrealtime counts at 100 MHz
 
 struct Signal {
   alignas(128) uint32_t ticket[kMaxBlocks];                // barriers this block has passed (owner only)
   alignas(128) uint32_t slot[2][kMaxBlocks][kMaxRanks];    // written by peers
-  alignas(128) uint32_t stuck[kMaxBlocks];                 // non-zero: a wait timed out
+  alignas(128) uint32_t stuck[kMaxBlocks];                 // non-zero: a wait of this block timed out
+  alignas(128) uint32_t failed;                            // sticky: some wait on this rank timed out
+};
+
+struct Watch {
+  uint32_t* host_flag;  // host-pinned word, device address
+  uint64_t ticks;       // time limit of one wait
 };
 
 struct Peers {
@@ -44,9 +58,13 @@ struct Inputs {
   const void* ptr[kMaxRanks];
 };
 
+// False (for the whole block) when a peer did not arrive in time or the communicator has failed before.
 template <bool RELEASE_ACQUIRE>
-__device__ __forceinline__ void barrier_all(const Peers& peers, Signal* self, int rank, int world) {
-  if (RELEASE_ACQUIRE) __syncthreads();  // all of the block's prior stores are issued
+__device__ __forceinline__ bool barrier_all(const Peers& peers, Signal* self, int rank, int world, const Watch& watch) {
+  __shared__ uint32_t bad;
+  if (threadIdx.x == 0) bad = __hip_atomic_load(&self->failed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();  // also: all of the block's prior stores are issued
+  if (bad) return false;
   const uint32_t n = self->ticket[blockIdx.x] + 1;
   if ((int)threadIdx.x < world) {
     uint32_t* remote = &peers.sig[threadIdx.x]->slot[n & 1][blockIdx.x][rank];
@@ -55,22 +73,34 @@ __device__ __forceinline__ void barrier_all(const Peers& peers, Signal* self, in
     else
       __hip_atomic_store(remote, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t* mine = &self->slot[n & 1][blockIdx.x][threadIdx.x];
+    const uint64_t t0 = wall_clock64();
     uint32_t polls = 0;
     while (true) {
       const uint32_t v = RELEASE_ACQUIRE ? __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
                                          : __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       // tickets only grow; a peer that is already one barrier ahead wrote the other slot set
       if (v == n) break;
-      if (++polls > kMaxPolls) {
+      if ((++polls & 63u) == 0 && wall_clock64() - t0 > watch.ticks) {
         self->stuck[blockIdx.x] = n;
+        __hip_atomic_store(&self->failed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(watch.host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        bad = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
     }
   }
   __syncthreads();
+  if (bad) return false;
   if (threadIdx.x == 0) self->ticket[blockIdx.x] = n;
   __syncthreads();
+  return true;
+}
+
+// all bits set: NaN in fp32, fp16 and bf16
+__device__ __forceinline__ void poison(void* out, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
 }
 
 template <typename T>
@@ -112,23 +142,23 @@ __device__ __forceinline__ uint4 reduce_vec(const Inputs& in, int world, int64_t
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads) allreduce_one_stage(Inputs in, Peers peers, Signal* self, void* out, int rank,
-                                                                int world, int64_t nvec) {
-  barrier_all<true>(peers, self, rank, world);
+                                                                int world, int64_t nvec, Watch watch) {
+  if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
     reinterpret_cast<uint4*>(out)[i] = reduce_vec<T>(in, world, i);
-  barrier_all<false>(peers, self, rank, world);
+  if (!barrier_all<false>(peers, self, rank, world, watch)) poison(out, nvec);
 }
 
 template <typename T>
 __global__ void __launch_bounds__(kThreads) allreduce_two_stage(Inputs in, Peers peers, Signal* self, void* out, int rank,
-                                                                int world, int64_t nvec) {
+                                                                int world, int64_t nvec, Watch watch) {
   const int64_t part = nvec / world;  // the last rank also takes the remainder
   const int64_t lo = part * rank, hi = rank == world - 1 ? nvec : lo + part;
   uint4* stage = reinterpret_cast<uint4*>(self + 1);
-  barrier_all<true>(peers, self, rank, world);
+  if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
   for (int64_t i = lo + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kThreads)
     stage[i - lo] = reduce_vec<T>(in, world, i);
-  barrier_all<true>(peers, self, rank, world);
+  if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
   for (int r = 0; r < world; ++r) {
     // start with the own slice and walk the ring so that the links are used evenly
     const int src = (rank + r) % world;
@@ -139,6 +169,20 @@ __global__ void __launch_bounds__(kThreads) allreduce_two_stage(Inputs in, Peers
   }
 }
 
+// out[r * nvec + i] = rank r's input vector i: every rank's registered input, concatenated in rank order.
+__global__ void __launch_bounds__(kThreads) allgather_kernel(Inputs in, Peers peers, Signal* self, void* out, int rank,
+                                                             int world, int64_t nvec, Watch watch) {
+  if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec * world);
+  for (int r = 0; r < world; ++r) {
+    const int src = (rank + r) % world;
+    const uint4* from = reinterpret_cast<const uint4*>(in.ptr[src]);
+    uint4* to = reinterpret_cast<uint4*>(out) + (int64_t)src * nvec;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
+      to[i] = from[i];
+  }
+  if (!barrier_all<false>(peers, self, rank, world, watch)) poison(out, nvec * world);
+}
+
 struct Comm {
   int rank = 0, world = 1, full_xgmi = 1;
   int64_t staging_bytes = 0;
@@ -146,7 +190,21 @@ struct Comm {
   Signal* self = nullptr;
   std::map<const void*, Inputs> buffers;
   std::mutex mu;
+  uint32_t* host_flag = nullptr;  // pinned; the kernels write it through watch.host_flag
+  Watch watch{};
+  ~Comm() {
+    if (host_flag) (void)hipHostFree(host_flag);
+  }
 };
+
+int check_alive(Comm* c, const char* what) {
+  if (__atomic_load_n(c->host_flag, __ATOMIC_RELAXED) != 0)
+    return fail(SGLK_ESTUCK,
+                "%s: a peer did not reach a barrier within the time limit on this communicator; its outputs since "
+                "then are NaN-filled and it takes no more work (make a new one on every rank)",
+                what);
+  return SGLK_OK;
+}
 
 }  // namespace
 }  // namespace sglk
@@ -174,7 +232,32 @@ int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi,
   c->staging_bytes = staging_bytes;
   for (int r = 0; r < world; ++r) c->peers.sig[r] = reinterpret_cast<Signal*>(meta_ptrs[r]);
   c->self = c->peers.sig[rank];
+  void* dev_view = nullptr;
+  hipError_t e = hipHostMalloc((void**)&c->host_flag, sizeof(uint32_t), hipHostMallocMapped);
+  if (e == hipSuccess) {
+    *c->host_flag = 0;
+    e = hipHostGetDevicePointer(&dev_view, c->host_flag, 0);
+  }
+  if (e != hipSuccess) {
+    fail(SGLK_EHIP, "ar_init: pinned status word: %s", hipGetErrorString(e));
+    delete c;
+    return 0;
+  }
+  c->watch.host_flag = static_cast<uint32_t*>(dev_view);
+  int64_t ms = kDefaultTimeoutMs;
+  if (const char* env = getenv("SGLK_AR_TIMEOUT_MS")) {
+    const long long v = atoll(env);
+    if (v > 0) ms = v;
+  }
+  c->watch.ticks = (uint64_t)ms * kTicksPerMs;
   return (int64_t) reinterpret_cast<intptr_t>(c);
+}
+
+int sglk_ar_set_timeout_ms(int64_t fa, int64_t ms) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c && ms > 0, "ar_set_timeout_ms: null handle or non-positive time");
+  c->watch.ticks = (uint64_t)ms * kTicksPerMs;
+  return SGLK_OK;
 }
 
 int sglk_ar_dispose(int64_t fa) {
@@ -202,6 +285,7 @@ int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, in
   SGLK_CHECK(numel >= 0, "ar_all_reduce: negative size");
   SGLK_CHECK(dtype == SGLK_F32 || dtype == SGLK_F16 || dtype == SGLK_BF16, "ar_all_reduce: unsupported dtype %d", dtype);
   if (numel == 0) return SGLK_OK;
+  if (int rc = check_alive(c, "ar_all_reduce")) return rc;
   const int64_t bytes = numel * elem_size(dtype);
   // custom_all_reduce_hip.cuh:480-484: the payload must be a whole number of 16-byte packs
   SGLK_CHECK(bytes % 16 == 0, "ar_all_reduce: byte size %lld is not a multiple of 16", (long long)bytes);
@@ -235,11 +319,34 @@ int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, in
   SGLK_DISPATCH_FLOAT(dtype, T, {
     if (algo == 1)
       hipLaunchKernelGGL((allreduce_one_stage<T>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,
-                         c->rank, c->world, nvec);
+                         c->rank, c->world, nvec, c->watch);
     else
       hipLaunchKernelGGL((allreduce_two_stage<T>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,
-                         c->rank, c->world, nvec);
+                         c->rank, c->world, nvec, c->watch);
   });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_ar_all_gather(int64_t fa, const void* inp, void* out, int64_t bytes_per_rank, void* stream) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c && inp && out, "ar_all_gather: null argument");
+  SGLK_CHECK(bytes_per_rank >= 0, "ar_all_gather: negative size");
+  if (bytes_per_rank == 0) return SGLK_OK;
+  if (int rc = check_alive(c, "ar_all_gather")) return rc;
+  SGLK_CHECK(bytes_per_rank % 16 == 0, "ar_all_gather: byte size %lld is not a multiple of 16", (long long)bytes_per_rank);
+  SGLK_CHECK(aligned16(inp) && aligned16(out), "ar_all_gather: buffers must be 16-byte aligned");
+  Inputs in;
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    auto it = c->buffers.find(inp);
+    SGLK_CHECK(it != c->buffers.end(), "ar_all_gather: input %p is not a registered buffer", inp);
+    in = it->second;
+  }
+  const int64_t nvec = bytes_per_rank / 16;
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, (nvec + kThreads - 1) / kThreads));
+  hipLaunchKernelGGL(allgather_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, in, c->peers, c->self, out,
+                     c->rank, c->world, nvec, c->watch);
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
@@ -256,11 +363,7 @@ int sglk_ar_all_reduce_unreg(int64_t fa, const void* inp, void* reg_buffer, void
 int sglk_ar_stuck(int64_t fa) {
   Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
   if (!c) return fail(SGLK_EINVAL, "ar_stuck: null handle");
-  uint32_t host[kMaxBlocks];
-  SGLK_HIP(hipMemcpy(host, c->self->stuck, sizeof(host), hipMemcpyDeviceToHost));
-  int n = 0;
-  for (int i = 0; i < kMaxBlocks; ++i) n += host[i] != 0;
-  return n;
+  return __atomic_load_n(c->host_flag, __ATOMIC_RELAXED) != 0 ? 1 : 0;
 }
 
 // ---- IPC plumbing --------------------------------------------------------------------------------------

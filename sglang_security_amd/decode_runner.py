@@ -269,23 +269,25 @@ class LlamaDecoder:
     def gemm_sweep(self, name: str):
         """Launch projection `name` of every layer back to back, in the form the decode step uses (timing aid)."""
         c = self.cfg
+        tp = getattr(self, "tp_group", None) is not None
+        src = {"qkv": self.hidden, "o": self.attn_out, "gate_up": self.hidden, "down": self.act}[name]
+        row_out = self.tp_buf if tp else self.hidden
+        dst = {"qkv": self.qkv, "o": row_out, "gate_up": self.gate_up, "down": row_out}[name]
+        xs = {"qkv": self.xs_hidden, "o": self.xs_attn, "gate_up": self.xs_hidden, "down": self.xs_act}[name]
         for L in self.layers:
             w = L[name]
             if not self.fused:
-                src = {"qkv": self.hidden, "o": self.attn_out, "gate_up": self.hidden, "down": self.act}[name]
-                dst = {"qkv": self.qkv, "o": self.hidden, "gate_up": self.gate_up, "down": self.hidden}[name]
-                self._linear(name, w, src, dst)
-            elif name == "qkv":
-                ops.awq_gemm_partial(self.hidden, w.packed, w.scales, w.qzeros, self.partial, self.xs_hidden)
-            elif name == "o":
-                ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, self.partial, self.xs_attn)
+                if c.quant == "fp8" and getattr(self, "fp8_fold_quant", True):
+                    self._fp8_mm(name, w, dst)
+                else:
+                    self._linear(name, w, src, dst)
             elif name == "gate_up" and getattr(self, "fused_act", False):
                 il = L["gate_up_il"]
                 ops.awq_gemm_silu_mul(self.hidden, il[0], il[1], il[2], self.act, self.xs_hidden, self.xs_act)
-            elif name == "gate_up":
-                ops.awq_gemm_xs(self.hidden, w.packed, w.scales, w.qzeros, self.xs_hidden, self.gate_up, self.workspace)
+            elif name == "gate_up" or (tp and name != "qkv"):
+                ops.awq_gemm_xs(src, w.packed, w.scales, w.qzeros, xs, dst, self.workspace)
             else:
-                ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, self.partial, self.xs_act)
+                ops.awq_gemm_partial(src, w.packed, w.scales, w.qzeros, self.partial, xs)
 
     def step_fused(self):
         c = self.cfg
@@ -297,22 +299,32 @@ class LlamaDecoder:
         q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
         o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
         P, S = self.partial, self.part_splits
+        tp = getattr(self, "tp_group", None)
         for li, L in enumerate(self.layers):
             if li == 0:
                 self.residual.copy_(self.hidden)
                 ops.fused_add_rmsnorm_ex(self.hidden, None, L["ln1"], c.eps, xsum_out=self.xs_hidden)
-            else:  # consumes the previous layer's down-projection partials
+            elif tp is None:  # consumes the previous layer's down-projection partials
                 ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln1"], c.eps, partials=P, splits=S["down"],
                                          xsum_out=self.xs_hidden)
+            else:
+                ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln1"], c.eps, xsum_out=self.xs_hidden)
             w = L["qkv"]
             self._timed("qkv", lambda: ops.awq_gemm_partial(self.hidden, w.packed, w.scales, w.qzeros, P, self.xs_hidden))
             ops.rope_and_store_kv_partial(self.qkv, P, S["qkv"], self.cos_sin, self.positions, self.k_pool[li],
                                           self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
             self.attention(li, q_view, o_view, sm_scale, xsum_out=self.xs_attn)
             w = L["o"]
-            self._timed("o", lambda: ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, P, self.xs_attn))
-            ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, partials=P, splits=S["o"],
-                                     xsum_out=self.xs_hidden, zero_out=self.xs_act if self.fused_act else None)
+            if tp is None:
+                self._timed("o", lambda: ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, P, self.xs_attn))
+                ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, partials=P, splits=S["o"],
+                                         xsum_out=self.xs_hidden, zero_out=self.xs_act if self.fused_act else None)
+            else:  # row-parallel: this rank's product (split-K closed inside the GEMM), the sum over ranks, the consumer
+                self._timed("o", lambda: ops.awq_gemm_xs(self.attn_out, w.packed, w.scales, w.qzeros, self.xs_attn,
+                                                         self.tp_buf, self.workspace))
+                self._tp_sum()
+                ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, xsum_out=self.xs_hidden,
+                                         zero_out=self.xs_act if self.fused_act else None)
             if self.fused_act:
                 il = L["gate_up_il"]
                 self._timed("gate_up", lambda: ops.awq_gemm_silu_mul(self.hidden, il[0], il[1], il[2], self.act,
@@ -323,8 +335,16 @@ class LlamaDecoder:
                                                                self.gate_up, self.workspace))
                 ops.act_and_mul_xs(self.act, self.gate_up, 0, self.xs_act)
             w = L["down"]
-            self._timed("down", lambda: ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, P, self.xs_act))
-        ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])
+            if tp is None:
+                self._timed("down", lambda: ops.awq_gemm_partial(self.act, w.packed, w.scales, w.qzeros, P, self.xs_act))
+            else:
+                self._timed("down", lambda: ops.awq_gemm_xs(self.act, w.packed, w.scales, w.qzeros, self.xs_act,
+                                                            self.tp_buf, self.workspace))
+                self._tp_sum()
+        if tp is None:
+            ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])
+        else:
+            ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps)
         ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
         self._sample()
 
@@ -350,8 +370,8 @@ class LlamaDecoder:
         sm_scale = 1.0 / math.sqrt(c.head_dim)
         q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
         o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
-        comm = getattr(self, "tp_comm", None)
-        row_out = self.hidden if comm is None else self.tp_buf
+        tp = getattr(self, "tp_group", None)
+        row_out = self.hidden if tp is None else self.tp_buf
         for li, L in enumerate(self.layers):
             if li == 0:
                 self.residual.copy_(self.hidden)
@@ -364,14 +384,14 @@ class LlamaDecoder:
             self.attention(li, q_view, o_view, sm_scale)
             ops.per_token_quant_fp8(self.attn_out, self._xq(self.q_size), self.x_s)
             self._fp8_mm("o", L["o"], row_out)
-            if comm is not None:
-                comm.all_reduce_reg(self.tp_buf, self.hidden)
+            if tp is not None:
+                self._tp_sum()
             ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln2"], self._xq(c.hidden), self.x_s, c.eps)
             self._fp8_mm("gate_up", L["gate_up"], self.gate_up)
             ops.silu_and_mul_quant_fp8(self.gate_up, self._xq(c.inter), self.x_s)
             self._fp8_mm("down", L["down"], row_out)
-            if comm is not None:
-                comm.all_reduce_reg(self.tp_buf, self.hidden)
+            if tp is not None:
+                self._tp_sum()
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)
         ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
         self._sample()
@@ -408,43 +428,49 @@ class LlamaDecoder:
         ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
         self._sample()
 
-    def enable_tp(self, comm) -> None:
-        """Tensor parallelism over the ranks of `comm` (a distributed.CustomAllreduce): this decoder holds one rank's
-        shard (llama.py:72-86,145-160), the row-parallel projections (o, down) write their partial sums into a
-        registered buffer and the peer-to-peer all-reduce leaves the sum in `hidden`; the vocab-parallel lm_head
-        (vocab_parallel_embedding.py) is followed by an exchange of every rank's best (logit, token) pair.  Plain op
-        sequence only (the layer fusion hands split-K partials to the next kernel, not to a collective)."""
-        assert not self.fused, "tensor parallelism runs the plain op sequence"
-        self.tp_comm = comm
-        self.tp_rank, self.tp_world = comm.rank, comm.world_size
+    def enable_tp(self, group) -> None:
+        """Tensor parallelism over `group` (a distributed.parallel_state.GroupCoordinator): this decoder holds one
+        rank's shard (llama.py:72-86,145-160).  The row-parallel projections (o, down) write this rank's product into a
+        buffer registered with the group's peer-to-peer communicator and the all-reduce leaves the sum in `hidden`
+        (linear.py RowParallelLinear -> tensor_model_parallel_all_reduce); the vocab-parallel lm_head is followed by an
+        all-gather of every rank's logits (logits_processor.py -> tensor_model_parallel_all_gather), so every rank
+        samples from the full row.  When the communicator declines a tensor or has been disabled, the group's RCCL
+        collectives take over (parallel_state.py:436-461).  Works with the plain op sequence, the fp8 sequence and
+        the fused layer path (there the split-K reduction closes inside the GEMM before the collective)."""
+        self.tp_group = group
+        self.tp_rank, self.tp_world = group.rank_in_group, group.world_size
         self.tp_buf = torch.empty_like(self.hidden)
-        comm.register_buffer(self.tp_buf)
-        # [B, world, 2] fp32: slot r holds rank r's best logit and its global token id; the other slots are zero
-        self.tp_best = torch.zeros(self.B, self.tp_world, 2, dtype=torch.float32, device=self.device)
-        comm.register_buffer(self.tp_best)
-        self.tp_best_all = torch.empty_like(self.tp_best)
+        self.tp_buf_registered = group.register_buffer(self.tp_buf)
+        self.tp_logits_registered = group.register_buffer(self.logits)
+        self.logits_all = torch.empty(self.tp_world, self.B, self.cfg.vocab, dtype=self.dtype, device=self.device)
+        self.logits_full = torch.empty(self.B, self.tp_world * self.cfg.vocab, dtype=self.dtype, device=self.device)
+
+    def _tp_sum(self):
+        self.tp_group.all_reduce_into(self.tp_buf, self.hidden, registered=self.tp_buf_registered)
+
+    def check_tp_health(self) -> None:
+        """After the step's synchronise: raises if a peer never reached an all-reduce barrier (outputs are NaN then)."""
+        tp = getattr(self, "tp_group", None)
+        if tp is not None:
+            tp.check_health()
 
     def _row_parallel(self, name, w, x):
         """o / down: the local product, then the sum over the TP ranks (linear.py RowParallelLinear)."""
-        comm = getattr(self, "tp_comm", None)
-        if comm is None:
+        if getattr(self, "tp_group", None) is None:
             self._linear(name, w, x, self.hidden)
             return
         self._linear(name, w, x, self.tp_buf)
-        comm.all_reduce_reg(self.tp_buf, self.hidden)
+        self._tp_sum()
 
     def _sample(self):
         """Greedy token over the (vocab-parallel) logits."""
-        comm = getattr(self, "tp_comm", None)
-        if comm is None:
+        tp = getattr(self, "tp_group", None)
+        if tp is None:
             ops.argmax(self.logits, self.next_ids)
         else:
-            val, idx = torch.max(self.logits.float(), dim=-1)
-            self.tp_best[:, self.tp_rank, 0] = val
-            self.tp_best[:, self.tp_rank, 1] = (idx + self.tp_rank * self.cfg.vocab).float()  # ids < 2^24: exact in fp32
-            comm.all_reduce_reg(self.tp_best, self.tp_best_all)
-            win = torch.argmax(self.tp_best_all[:, :, 0], dim=-1, keepdim=True)
-            self.next_ids.copy_(torch.gather(self.tp_best_all[:, :, 1], 1, win).squeeze(1).long())
+            tp.all_gather_into_tensor(self.logits_all, self.logits, registered=self.tp_logits_registered)
+            self.logits_full.view(self.B, self.tp_world, self.cfg.vocab).copy_(self.logits_all.permute(1, 0, 2))
+            ops.argmax(self.logits_full, self.next_ids)
             # this rank's embedding shard stands in for the whole table (synthetic weights): fold the id into it
             torch.remainder(self.next_ids, self.cfg.vocab, out=self.input_ids)
             return

@@ -26,9 +26,11 @@ class CustomAllreduce:
     _SUPPORTED_WORLD_SIZES = [2, 4, 6, 8]
     _MAX_CAR_SIZE = 2 * 8192 * 1024  # the ROCm value (custom_all_reduce.py:148-151)
 
-    def __init__(self, group, device, max_size: int = _MAX_CAR_SIZE, full_xgmi: bool = True) -> None:
+    def __init__(self, group, device, max_size: int = _MAX_CAR_SIZE, full_xgmi: bool = True,
+                 timeout_ms: Optional[int] = None) -> None:
         self._ptr = 0
         self.disabled = True
+        self.failed = False
         self._opened: List[int] = []
         self._meta = 0
         if dist.get_backend(group) == "nccl":
@@ -58,6 +60,8 @@ class CustomAllreduce:
         self._ptr = L.sglk_ar_init(arr, self.rank, self.world_size, 1 if full_xgmi else 0, max_size)
         if not self._ptr:
             check(-1, "ar_init")
+        if timeout_ms is not None:
+            check(L.sglk_ar_set_timeout_ms(self._ptr, int(timeout_ms)), "ar_set_timeout_ms")
         # the staging input buffer for tensors that are not registered themselves
         self.buffer = torch.empty(max_size, dtype=torch.uint8, device=device)
         self.register_buffer(self.buffer)
@@ -127,21 +131,58 @@ class CustomAllreduce:
             return None
         return self.all_reduce_unreg(input)
 
+    def all_gather_reg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Every rank's registered `inp`, stacked in rank order: out is [world_size, *inp.shape]."""
+        if out is None:
+            out = torch.empty((self.world_size,) + tuple(inp.shape), dtype=inp.dtype, device=inp.device)
+        if out.numel() != self.world_size * inp.numel() or out.dtype != inp.dtype or not out.is_contiguous():
+            raise SglkError("all_gather_reg: out must be a contiguous [world_size, *inp.shape] tensor of inp's dtype")
+        check(lib().sglk_ar_all_gather(self._ptr, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
+                                       torch.cuda.current_stream().cuda_stream), "ar_all_gather")
+        return out
+
+    def should_custom_ag(self, inp: torch.Tensor) -> bool:
+        if self.disabled:
+            return False
+        size = inp.numel() * inp.element_size()
+        return size % 16 == 0 and is_weak_contiguous(inp) and size * self.world_size <= 8 * self.max_size
+
+    # ---- failure handling ---------------------------------------------------------------------------
     def stuck_blocks(self) -> int:
+        """1 once a barrier wait on this rank has timed out (a host-pinned word the kernels raise; no synchronise)."""
         return int(lib().sglk_ar_stuck(self._ptr)) if self._ptr else 0
+
+    def check_health(self) -> None:
+        """Call after the stream has been synchronised (the end of a decode step, before results leave the GPU).
+        A peer that never reached a barrier has left NaN-filled outputs behind: this raises SglkError and disables
+        the communicator, so that should_custom_ar() declines and the caller's fallback collective takes over."""
+        if self._ptr and not self.failed and self.stuck_blocks():
+            self.failed = True
+            self.disabled = True
+        if self.failed:
+            raise SglkError(
+                f"peer-to-peer all-reduce: rank {self.rank} waited for a peer longer than the time limit; outputs since "
+                "then are NaN-filled and this communicator is disabled")
 
     def close(self):
         L = lib()
+        failed = False
         if self._ptr:
             torch.cuda.synchronize()
+            failed = not self.failed and bool(self.stuck_blocks())
             L.sglk_ar_dispose(self._ptr)
             self._ptr = 0
+            self.disabled = True
         for p in self._opened:
             L.sglk_ipc_close(p)
         self._opened = []
         if self._meta:
             L.sglk_free_uncached(self._meta)
             self._meta = 0
+        if failed:
+            self.failed = True
+            raise SglkError(f"peer-to-peer all-reduce: rank {self.rank} had a barrier time-out that nobody checked for; "
+                            "results computed through this communicator are NaN-filled")
 
     def __del__(self):
         try:
