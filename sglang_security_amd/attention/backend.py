@@ -2,12 +2,19 @@
 (python/sglang/srt/layers/attention/triton_backend.py:151-836) for the paths RadixAttention takes with a radix
 cache: decode over paged KV, extend over a cached prefix, metadata at fixed addresses for graph replay.
 
+Speculative batches are served as the reference serves them: a decode batch whose `spec_info` brings its own
+kv_indptr / kv_indices (draft decode), target-verify batches (the draft tree's `custom_mask`, one row of
+seq_len + num_draft_tokens mask bytes per draft token, `mask_indptr` built here) and draft-extend batches
+(`spec_info.generate_attn_arg_prefill`), all through the masked extend kernel.
+
 It reads the same fields of the objects the reference passes around:
   model_runner : .device, .req_to_token_pool.req_to_token, .token_to_kv_pool, .model_config.num_attention_heads,
                  .model_config.get_num_kv_heads(tp), .model_config.head_dim (v_head_dim optional), .tp_size,
                  .server_args.triton_attention_num_kv_splits
-  forward_batch: .forward_mode.is_decode_or_idle() / is_extend(), .batch_size, .req_pool_indices, .seq_lens,
-                 .seq_lens_sum, .out_cache_loc, .extend_prefix_lens, .extend_seq_lens, .token_to_kv_pool
+  forward_batch: .forward_mode.is_decode_or_idle() / is_target_verify() / is_draft_extend(), .batch_size,
+                 .req_pool_indices, .seq_lens, .seq_lens_sum, .out_cache_loc, .extend_prefix_lens, .extend_seq_lens,
+                 .token_to_kv_pool, .spec_info (.kv_indptr, .kv_indices, .custom_mask, .accept_length,
+                 .generate_attn_arg_prefill)
   layer        : .layer_id, .tp_q_head_num, .tp_k_head_num, .qk_head_dim, .v_head_dim, .scaling, .logit_cap
 
 One extension: when `forward_batch.prefix_groups = (group_indptr, prefix_lens)` is set (the radix-tree hit the
@@ -49,6 +56,8 @@ class SglkAttnBackend:
         self.kv_indptr = kv_indptr_buf if kv_indptr_buf is not None else torch.zeros(
             (max_bs + 1,), dtype=torch.int32, device=self.device)
         self.qo_indptr = torch.zeros((max_bs + 1,), dtype=torch.int32, device=self.device)
+        self.mask_indptr = torch.zeros((max_bs + 1,), dtype=torch.int64, device=self.device)  # triton_backend.py:208-210
+        self.num_draft_tokens = getattr(model_runner.server_args, "speculative_num_draft_tokens", None)
         cfg = model_runner.model_config
         tp = getattr(model_runner, "tp_size", 1)
         self.num_head = cfg.num_attention_heads // tp
@@ -82,21 +91,62 @@ class SglkAttnBackend:
         return torch.empty(n // 4, dtype=torch.float32, device=self.device)
 
     def init_forward_metadata(self, forward_batch):
-        """triton_backend.py:271-446 (no speculative decoding, no sliding window, no custom mask)."""
+        """triton_backend.py:271-446 (no sliding window)."""
         bs = forward_batch.batch_size
         kv_indptr = self.kv_indptr
-        if forward_batch.forward_mode.is_decode_or_idle():
-            ops.kv_indptr_cumsum(forward_batch.seq_lens, kv_indptr)
-            kv_indptr = kv_indptr[: bs + 1]
-            kv_indices = torch.empty(forward_batch.seq_lens_sum, dtype=torch.int32, device=self.device)
-            ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
-                                  None, kv_indices)
+        spec_info = getattr(forward_batch, "spec_info", None)
+        mode = forward_batch.forward_mode
+        is_mode = lambda name: bool(getattr(mode, name, lambda: False)())
+        if mode.is_decode_or_idle():
+            if spec_info is None:
+                ops.kv_indptr_cumsum(forward_batch.seq_lens, kv_indptr)
+                kv_indptr = kv_indptr[: bs + 1]
+                kv_indices = torch.empty(forward_batch.seq_lens_sum, dtype=torch.int32, device=self.device)
+                ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
+                                      None, kv_indices)
+            else:  # draft decode: topk rows per request, indices prepared by the draft worker (:317-319)
+                kv_indptr, kv_indices = spec_info.kv_indptr, spec_info.kv_indices
+                bs = kv_indptr.shape[0] - 1
             attn_logits, attn_lse, num_kv_splits = self._decode_buffers(bs)
             self.get_num_kv_splits(num_kv_splits, forward_batch.seq_lens)
-            groups = getattr(forward_batch, "prefix_groups", None)
+            groups = getattr(forward_batch, "prefix_groups", None) if spec_info is None else None
             self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
                                                     None, prefix_groups=groups,
                                                     shared_workspace=self._shared_workspace(bs) if groups else None)
+            return
+        if is_mode("is_target_verify"):
+            # :338-374: every request scores num_draft_tokens tree nodes against its whole cached sequence; the tree's
+            # ancestor mask holds, per draft token, one byte per cached token and per draft token
+            if spec_info is None or self.num_draft_tokens is None:
+                raise SglkError("target-verify batch without spec_info / speculative_num_draft_tokens")
+            bs = len(forward_batch.req_pool_indices)
+            nd = int(self.num_draft_tokens)
+            qo_indptr = torch.arange(0, (1 + bs) * nd, step=nd, dtype=torch.int32, device=self.device)
+            ops.kv_indptr_cumsum(forward_batch.seq_lens, kv_indptr)
+            kv_indptr = kv_indptr[: bs + 1]
+            kv_indices = torch.empty(max(int(forward_batch.seq_lens_sum), 1), dtype=torch.int32, device=self.device)
+            ops.create_kv_indices(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
+                                  None, kv_indices)
+            seq_mask_len = nd * (forward_batch.seq_lens.to(torch.int64) + nd)
+            mask_indptr = self.mask_indptr
+            mask_indptr[1: bs + 1] = torch.cumsum(seq_mask_len[:bs], dim=0)
+            self.forward_metadata = ForwardMetadata(None, None, nd, None, kv_indptr, kv_indices, qo_indptr,
+                                                    custom_mask=spec_info.custom_mask, mask_indptr=mask_indptr[: bs + 1])
+            return
+        if is_mode("is_draft_extend"):
+            # :375-391
+            kv_indices, kv_indptr, qo_indptr, custom_mask = spec_info.generate_attn_arg_prefill(
+                forward_batch.req_pool_indices, forward_batch.seq_lens, None, self.req_to_token)
+            max_extend_len = int(torch.max(spec_info.accept_length).item())
+            mask_indptr = None
+            if custom_mask is not None:
+                # without mask offsets the kernel cannot address the mask: rows of (prefix + extend) bytes per new token
+                ext = (qo_indptr[1:] - qo_indptr[:-1]).to(torch.int64)
+                pre = (kv_indptr[1:] - kv_indptr[:-1]).to(torch.int64)
+                mask_indptr = torch.zeros(ext.numel() + 1, dtype=torch.int64, device=self.device)
+                mask_indptr[1:] = torch.cumsum(ext * (pre + ext), dim=0)
+            self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr,
+                                                    custom_mask=custom_mask, mask_indptr=mask_indptr)
             return
         # extend: the prefix part comes from the pool through kv_indices, the new part is contiguous
         ops.kv_indptr_cumsum(forward_batch.extend_prefix_lens, kv_indptr)

@@ -81,6 +81,12 @@ class TokenToKVPoolAllocator:
         self.is_not_in_free_group = False
         self.free_group = []
 
+    def backup_state(self):
+        return self.free_slots
+
+    def restore_state(self, free_slots):
+        self.free_slots = free_slots
+
     def free_group_end(self):
         self.is_not_in_free_group = True
         if self.free_group:

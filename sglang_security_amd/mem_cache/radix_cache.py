@@ -338,6 +338,20 @@ class RadixCache:
     def take_events(self):
         return []
 
+    def all_values_flatten(self) -> torch.Tensor:
+        """radix_cache.py:320-329: every cached slot, parents before children."""
+        vals = [torch.tensor(d["value"], dtype=torch.int64) for d in self.dump()]
+        out = torch.cat(vals) if vals else torch.empty(0, dtype=torch.int64)
+        return out.to(self.device) if self.device is not None else out
+
+    def pretty_print(self) -> None:
+        """radix_cache.py:242-244,566-582: one line per node (key length, first ten tokens, lock count), then the size."""
+        root_key = self.root_node.key
+        print("", len(root_key), root_key[:10], f"r={self.root_node.lock_ref}")
+        for d in self.dump():
+            print(" " * (2 * (d["depth"] + 1)), len(d["key"]), d["key"][:10], f"r={d['lock_ref']}")
+        print(f"#tokens: {self.total_size()}")
+
     # ---- introspection used by the tests -----------------------------------------------------------
     def dump(self):
         """Pre-order structural dump, children ordered by first token."""

@@ -4,8 +4,9 @@ times it the way the fork's timing experiment does.
 Per layer this is the reference's extend forward (python/sglang/srt/models/llama.py:245-267;
 model_executor/model_runner.py:1151-1164 forward_extend): norm, qkv projection, rotary + KV-pool write, extend
 attention over the cached prefix (through kv_indices) and the new tokens (causal), o projection, norm, gated MLP.
-The AWQ projections follow the reference's own switch (layers/quantization/awq.py: 256 tokens or more are
-multiplied by the dequantised weight with a plain GEMM, fewer go through the fused int4 kernel).
+The reference always dequantises an AWQ weight and multiplies with a plain GEMM (layers/quantization/awq.py:197-215).
+Here fewer than DEQUANT_GEMM_MIN_TOKENS rows go through the fused int4 kernel and only larger batches take the
+dequantise-then-GEMM route; the threshold is this package's own choice, not the reference's.
 
 `PrefixCacheHarness` is the scheduler's part around it, reduced to one request at a time: match_prefix with the
 sender's user id, slot allocation, req_to_token row, extend of the unmatched tail, cache_finished_req
@@ -26,7 +27,7 @@ from .decode_runner import LlamaDecoder, _AwqLinear, _DenseLinear, _Fp8Linear
 from .mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
 from .mem_cache.radix_cache import RadixCache
 
-DEQUANT_GEMM_MIN_TOKENS = 256  # awq.py FP16_MATMUL_HEURISTIC_CONDITION
+DEQUANT_GEMM_MIN_TOKENS = 256  # this package's heuristic: where re-reading int4 weights per 64-row tile stops paying
 
 
 class LlamaPrefill:
@@ -247,7 +248,7 @@ def ttft_experiment(dec: LlamaDecoder, prefix_len: int, suffix_len: int, pool_to
     rand = lambda n: torch.randint(0, vocab, (n,), generator=g).tolist()
     out = {}
     for mode, is_private in (("public", False), ("private", True)):
-        judge = PrivateJudgeClient(lambda text, p=is_private: p, num_workers=1)
+        judge = PrivateJudgeClient(detector=lambda text, p=is_private: p, num_workers=1)
         h = PrefixCacheHarness(dec, pool_tokens, prefix_len + suffix_len + 8, judge, resident_bf16=resident_bf16)
         cold, other, owner, hits = [], [], [], []
         for r in range(repeats + 1):                     # round 0 warms kernels, GEMM heuristics and the allocator

@@ -33,10 +33,13 @@ class PrivateNodeTask:
 
 
 class PrivateJudgeClient:
-    def __init__(self, detector: Optional[Callable[[str], bool]] = None, num_workers: int = 1,
-                 batch_timeout: float = 0.05):
-        """detector(text) -> True when the text is private.  None: everything stays private (the fork's default
-        when no detector answers: new nodes are private with need_check_privacy set, tree_node.py:50-52)."""
+    def __init__(self, server_args=None, port_args=None, detector: Optional[Callable[[str], bool]] = None,
+                 num_workers: int = 1, batch_timeout: float = 0.05):
+        """server_args / port_args: the reference's constructor arguments (private_client.py:32-35), kept for callers
+        written against it; the detector service they configure there is control plane and is supplied here as
+        `detector(text) -> True when the text is private`.  None: everything stays private (the fork's default when no
+        detector answers: new nodes are private with need_check_privacy set, tree_node.py:50-52)."""
+        self.server_args, self.port_args = server_args, port_args
         self.detector = detector
         self.batch_timeout = batch_timeout
         self.running = True
@@ -61,7 +64,7 @@ class PrivateJudgeClient:
             text = _PLACEHOLDER
         return text
 
-    def update_privacy(self, node, context: str = "", prompt: str = "") -> None:
+    def update_privacy(self, node, context: str, prompt: str) -> None:
         parent = node.parent
         if parent is not None and not parent.need_check_privacy and parent.private:
             node.need_check_privacy = False

@@ -296,3 +296,137 @@ def test_mla_pool_and_decode():
     ops.decode_attention_fwd(q.to(DEV), kb, vb, o, ptr.to(DEV), ind, al, lse, torch.tensor([2, 1], dtype=torch.int32, device=DEV),
                              4, sm, 0.0)
     assert (o.float().cpu() - want).abs().max().item() < 2e-2
+
+
+class _SpecMode:
+    def __init__(self, name):
+        self._n = name
+
+    def is_decode_or_idle(self):
+        return self._n == "decode"
+
+    def is_target_verify(self):
+        return self._n == "target_verify"
+
+    def is_draft_extend(self):
+        return self._n == "draft_extend"
+
+    def is_extend(self):
+        return self._n != "decode"
+
+
+def test_backend_target_verify_uses_the_tree_mask():
+    """A target-verify batch through init_forward_metadata / forward_extend (triton_backend.py:338-374): the backend
+    builds qo_indptr, kv_indptr / kv_indices over the cached sequences and mask_indptr from seq_lens, takes custom_mask
+    from spec_info, and the draft tokens attend the prefix plus their ancestors only."""
+    import oracle
+    from sglang_security_amd.attention import SglkAttnBackend
+
+    Hq, Hkv, D, B, nd = 8, 2, 128, 3, 4
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    mr.server_args.speculative_num_draft_tokens = nd
+    g = torch.Generator().manual_seed(11)
+    lens = [20, 7, 33]
+    for b, L in enumerate(lens):
+        r2t.req_to_token[b, :L] = alloc.alloc(L).int()
+    new_loc = alloc.alloc(B * nd)
+    for buf in (kv.k_buffer[0], kv.v_buffer[0]):
+        buf.copy_(torch.randn(buf.shape, generator=g).to(torch.bfloat16))
+    # per request a chain 0 <- 1 <- 2 and a sibling 3 of node 1 (parent 0): ancestor masks over the draft tokens
+    anc = torch.tensor([[1, 0, 0, 0], [1, 1, 0, 0], [1, 1, 1, 0], [1, 0, 0, 1]], dtype=torch.bool)
+    rows = []
+    for L in lens:
+        rows.append(torch.cat([torch.ones(nd, L, dtype=torch.bool), anc], dim=1).reshape(-1))
+    custom_mask = torch.cat(rows).to(DEV)
+    seq_lens = torch.tensor(lens, device=DEV)
+    spec = types.SimpleNamespace(custom_mask=custom_mask)
+    fb = types.SimpleNamespace(forward_mode=_SpecMode("target_verify"), batch_size=B * nd,
+                               req_pool_indices=torch.arange(B, device=DEV), seq_lens=seq_lens, seq_lens_sum=sum(lens),
+                               out_cache_loc=new_loc, token_to_kv_pool=kv, spec_info=spec)
+    be = SglkAttnBackend(mr)
+    be.init_forward_metadata(fb)
+    md = be.forward_metadata
+    assert md.qo_indptr.tolist() == [0, nd, 2 * nd, 3 * nd] and md.max_extend_len == nd
+    assert md.kv_indptr.tolist() == [0, 20, 27, 60]
+    assert md.mask_indptr.tolist() == [0, nd * 24, nd * 24 + nd * 11, nd * 24 + nd * 11 + nd * 37]
+    assert md.custom_mask is custom_mask
+    q = torch.randn(B * nd, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    k = torch.randn(B * nd, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(B * nd, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    layer = _layer(0, Hq, Hkv, D)
+    o = be.forward(q, k, v, layer, fb)
+    want = oracle.extend_attention_masked(
+        q.cpu().view(-1, Hq, D), k.cpu().view(-1, Hkv, D), v.cpu().view(-1, Hkv, D), kv.k_buffer[0].cpu(),
+        kv.v_buffer[0].cpu(), md.qo_indptr.cpu(), md.kv_indptr.cpu(), md.kv_indices.cpu(),
+        custom_mask.cpu().to(torch.uint8), md.mask_indptr.cpu(), True, layer.scaling)
+    torch.testing.assert_close(o.float().cpu().view(-1, Hq, D), want, rtol=2e-2, atol=2e-2)
+    # node 3 must not see node 1: changing node 1's key / value leaves node 3's output alone and moves node 2's
+    k2, v2 = k.clone(), v.clone()
+    k2.view(B, nd, -1)[:, 1] += 1.0
+    v2.view(B, nd, -1)[:, 1] += 1.0
+    o2 = be.forward(q, k2, v2, layer, fb, save_kv_cache=False)
+    a, b2 = o.view(B, nd, -1), o2.view(B, nd, -1)
+    assert torch.equal(a[:, 3], b2[:, 3]) and torch.equal(a[:, 0], b2[:, 0])
+    assert not torch.equal(a[:, 2], b2[:, 2])
+
+
+def test_backend_draft_decode_and_draft_extend_take_spec_info_indices():
+    """Draft decode reads kv_indptr / kv_indices from spec_info (triton_backend.py:317-319: topk rows per request);
+    draft extend asks spec_info.generate_attn_arg_prefill for its arguments (:375-391)."""
+    import oracle
+    from sglang_security_amd.attention import SglkAttnBackend
+
+    Hq, Hkv, D, B, topk = 8, 2, 128, 2, 2
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    g = torch.Generator().manual_seed(12)
+    for buf in (kv.k_buffer[0], kv.v_buffer[0]):
+        buf.copy_(torch.randn(buf.shape, generator=g).to(torch.bfloat16))
+    lens = [9, 14]
+    # topk branches per request: the shared sequence plus one private slot each
+    per_row, ptr = [], [0]
+    for b, L in enumerate(lens):
+        shared = alloc.alloc(L).int()
+        for t in range(topk):
+            per_row.append(torch.cat([shared, alloc.alloc(1).int()]))
+            ptr.append(ptr[-1] + L + 1)
+    spec = types.SimpleNamespace(kv_indptr=torch.tensor(ptr, dtype=torch.int32, device=DEV),
+                                 kv_indices=torch.cat(per_row).to(DEV))
+    fb = types.SimpleNamespace(forward_mode=_SpecMode("decode"), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                               seq_lens=torch.tensor(lens, device=DEV), seq_lens_sum=sum(lens),
+                               out_cache_loc=None, token_to_kv_pool=kv, spec_info=spec)
+    be = SglkAttnBackend(mr)
+    be.init_forward_metadata(fb)
+    md = be.forward_metadata
+    assert md.kv_indptr is spec.kv_indptr and md.num_kv_splits.shape[0] == B * topk
+    q = torch.randn(B * topk, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    layer = _layer(0, Hq, Hkv, D)
+    o = be.forward(q, None, None, layer, fb, save_kv_cache=False)
+    want = oracle.decode_attention(q.cpu().view(-1, Hq, D), kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu(), spec.kv_indptr.cpu(),
+                                   spec.kv_indices.cpu(), torch.ones(B * topk, dtype=torch.int32), layer.scaling)
+    assert (o.float().cpu().view(-1, Hq, D) - want).abs().max().item() < 2e-2
+
+    # draft extend: 2 and 3 accepted tokens on top of the cached sequences, plain causal (no mask)
+    acc = torch.tensor([2, 3], device=DEV)
+    pre_idx = torch.cat([per_row[0][: lens[0]], per_row[2][: lens[1]]]).to(DEV)
+
+    def gen_args(req_pool_indices, seq_lens, _unused, req_to_token):
+        qo = torch.tensor([0, 2, 5], dtype=torch.int32, device=DEV)
+        kp = torch.tensor([0, lens[0], lens[0] + lens[1]], dtype=torch.int32, device=DEV)
+        return pre_idx, kp, qo, None
+
+    spec2 = types.SimpleNamespace(generate_attn_arg_prefill=gen_args, accept_length=acc)
+    fb2 = types.SimpleNamespace(forward_mode=_SpecMode("draft_extend"), batch_size=B,
+                                req_pool_indices=torch.arange(B, device=DEV), seq_lens=torch.tensor(lens, device=DEV),
+                                seq_lens_sum=sum(lens), out_cache_loc=None, token_to_kv_pool=kv, spec_info=spec2)
+    be.init_forward_metadata(fb2)
+    md = be.forward_metadata
+    assert md.max_extend_len == 3 and md.custom_mask is None and md.mask_indptr is None
+    T = 5
+    q = torch.randn(T, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    k = torch.randn(T, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    v = torch.randn(T, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    o = be.forward(q, k, v, layer, fb2, save_kv_cache=False)
+    want = oracle.extend_attention(q.cpu().view(-1, Hq, D), k.cpu().view(-1, Hkv, D), v.cpu().view(-1, Hkv, D),
+                                   kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu(), md.qo_indptr.cpu(), md.kv_indptr.cpu(),
+                                   md.kv_indices.cpu(), layer.scaling)
+    torch.testing.assert_close(o.float().cpu().view(-1, Hq, D), want, rtol=2e-2, atol=2e-2)

@@ -128,7 +128,7 @@ def test_safekv_private_prefix_is_owner_only():
     shared = torch.randint(0, dec.cfg.vocab, (1024,), generator=g).tolist()
     tail = lambda: torch.randint(0, dec.cfg.vocab, (16,), generator=g).tolist()
     for private, want_other in ((True, 0), (False, 1024)):
-        judge = PrivateJudgeClient(lambda text, p=private: p)
+        judge = PrivateJudgeClient(detector=lambda text, p=private: p)
         h = PrefixCacheHarness(dec, 8192, 2048, judge)
         _, pre, _ = h.serve_first_token(shared + tail(), "victim", "a line\nUser: q")
         assert pre == 0 and judge.drain()

@@ -196,7 +196,7 @@ def test_privacy_hook_end_to_end():
         seen.append(text)
         return "secret" in text
 
-    judge = PrivateJudgeClient(detector, num_workers=2)
+    judge = PrivateJudgeClient(detector=detector, num_workers=2)
     tree = RadixCache(None, Alloc(), 1, judge, get_epoch_fn=lambda: 0)
     pub = list(range(100, 1124))          # exactly one 1024-token chunk
     priv = list(range(5000, 5040))
@@ -309,3 +309,13 @@ def test_traces_on_the_gpu_box():
     replay into the same record as the device kernels."""
     for name in sorted(TRACES.keys()):
         test_trace(name)
+
+
+def test_all_values_flatten_and_pretty_print(capsys):
+    tree = RadixCache(None, Alloc(), 1, Judge(), compat_fork=False, get_epoch_fn=lambda: 0)
+    tree.insert([1, 2, 3, 4], torch.tensor([10, 11, 12, 13]))
+    tree.insert([1, 2, 7, 8, 9], torch.tensor([10, 11, 20, 21, 22]))
+    assert sorted(tree.all_values_flatten().tolist()) == [10, 11, 12, 13, 20, 21, 22]
+    tree.pretty_print()
+    out = capsys.readouterr().out
+    assert "#tokens: 7" in out and "[1, 2]" in out and "r=0" in out
