@@ -93,8 +93,18 @@ SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const vo
  * Same result as sglk_decode_attention on the same inputs (fp tolerance); no counterpart kernel in
  * the reference, whose decode walks every request's full kv_indices
  * (triton_ops/decode_attention.py:107-150).
- * workspace: fp32, sglk_decode_shared_workspace_bytes() bytes. */
+ * One launch: blocks that stream a slice of a shared prefix (lowest block indices, never waiting) leave fp32
+ * partials in the workspace and count them per (request, kv head); the blocks that walk one request's
+ * remainder then wait for that count, merge and write the output.  The wait is bounded (2 s): on expiry the
+ * block writes NaN and raises the workspace's error word (sglk_decode_shared_workspace_status returns 1;
+ * synchronising) instead of hanging the GPU.
+ * workspace: sglk_decode_shared_workspace_bytes() bytes, 16-byte aligned.  Its first B * Hq + 1 int32 words
+ * are counters: they must be ZERO when the workspace is first used (sglk_decode_shared_workspace_init clears
+ * them; a zero-filled allocation does too) and every call leaves them zero.  Calls that overlap in time need
+ * workspaces of their own. */
 SGLK_API int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits);
+SGLK_API int sglk_decode_shared_workspace_init(void* workspace, int B, int Hq, void* stream);
+SGLK_API int sglk_decode_shared_workspace_status(const void* workspace, int B, int Hq);
 SGLK_API int sglk_decode_attention_shared_prefix(
     const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
     const int32_t* kv_indices, const int32_t* group_indptr, const int32_t* prefix_lens, int G,

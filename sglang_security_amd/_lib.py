@@ -41,6 +41,8 @@ _SIGS = {
     "sglk_prepare_for_decode": (i32, [p, i64, p, i32, p, i32, p, p, i32, i32, p]),
     "sglk_argmax": (i32, [p, p, i64, i32, i64, i32, p]),
     "sglk_decode_shared_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "sglk_decode_shared_workspace_init": (i32, [p, i32, i32, p]),
+    "sglk_decode_shared_workspace_status": (i32, [p, i32, i32]),
     "sglk_decode_attention_shared_prefix": (i32, [p, p, p, p, p, p, p, p, i32, p, i32, i32, i32, i32, i32, i32,
                                                   i64, i64, i64, i64, i64, i64, i64, i64, f32, f32, i32, p]),
     "sglk_common_prefix_len": (i32, [p, i64, p, i32, p, i32, i32, p, p]),

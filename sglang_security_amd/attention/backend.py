@@ -87,8 +87,7 @@ class SglkAttnBackend:
         return attn_logits, attn_lse, num_kv_splits
 
     def _shared_workspace(self, bs: int):
-        n = ops.decode_shared_workspace_bytes(bs, self.num_head, self.v_head_dim, self.max_kv_splits)
-        return torch.empty(n // 4, dtype=torch.float32, device=self.device)
+        return ops.decode_shared_workspace(bs, self.num_head, self.v_head_dim, self.max_kv_splits, self.device)
 
     def init_forward_metadata(self, forward_batch):
         """triton_backend.py:271-446 (no sliding window)."""

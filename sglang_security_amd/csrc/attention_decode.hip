@@ -347,19 +347,13 @@ __device__ __forceinline__ int tail_splits(int len, int max_splits) {
   return min(max(cdiv_i(len, 32), 1), max_splits);
 }
 
-// MERGE (remainder mode of the shared-prefix path only): the block's four waves are the request's four remainder
-// splits; instead of storing their partials they leave them in LDS, and the block then merges them with the prefix
-// partials that the group kernel stored (attn_logits / attn_lse, splits [0, split_offset)) and writes the final
-// output row (and its per-head sums when xsum_out is given).
-template <typename T, bool MERGE>
+template <typename T>
 __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
     float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv,
     int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-    int64_t v_stride_h, float sm_scale, float logit_cap, const int32_t* __restrict__ group_indptr,
-    const int32_t* __restrict__ prefix_lens, int num_groups, int split_offset, int total_splits, void* __restrict__ o,
-    int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out, int64_t xs_stride) {
+    int64_t v_stride_h, float sm_scale, float logit_cap) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -370,28 +364,13 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   const int kvh = blockIdx.y / head_tiles, ht = blockIdx.y - kvh * head_tiles;
   const int split = blockIdx.z * kWavesPerBlock + wid;
   const int group = Hq / Hkv;
-  int start = kv_indptr[b];
-  int len = kv_indptr[b + 1] - start;
-  int splits;
-  int plen = 0;
-  if (group_indptr) {
-    // remainder mode: the first prefix_lens[group of b] tokens are handled elsewhere
-    plen = prefix_lens[find_group(group_indptr, num_groups, b)];
-    start += plen;
-    len -= plen;
-    splits = tail_splits(len, max_kv_splits);
-  } else {
-    splits = max(num_kv_splits[b], 1);
-  }
+  const int start = kv_indptr[b];
+  const int len = kv_indptr[b + 1] - start;
+  const int splits = max(num_kv_splits[b], 1);
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
   const int s0 = per_split * split;
-  int s1 = min(s0 + per_split, len);
-  const bool active = split < max_kv_splits && s1 > s0;  // wave-uniform
-  if constexpr (!MERGE) {
-    if (!active) return;  // no block-level synchronisation is used in this form
-  } else {
-    if (!active) s1 = s0;  // runs no tile; joins the merge below
-  }
+  const int s1 = min(s0 + per_split, len);
+  if (split >= max_kv_splits || s1 <= s0) return;  // wave-uniform; no block-level synchronisation is used
 
   const int hl = lane & 15;  // operand column: query head within this head tile
   const int g = lane >> 4;   // 16-lane group
@@ -411,68 +390,9 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
 
   // ---- epilogue: total sum over the four lane groups, normalise, store partial
   const float lsum = wa.total();
-  if constexpr (MERGE) {
-    // this wave's partial: O[16 heads][128] fp32 over its K tile, log-sum-exp[16] at the head of its V tile
-    float* po = reinterpret_cast<float*>(kl);
-    float* pl = reinterpret_cast<float*>(vl);
-    const float inv = active ? 1.0f / lsum : 0.f;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(po + hl * 128 + 16 * n + 4 * g) = oacc[n] * inv;
-    if (g == 0) pl[hl] = active ? (m + log2f(lsum)) * 0.6931471805599453f : -INFINITY;
-    __syncthreads();
-    const int heads_here = min(16, group - ht * 16);
-    const int per_p = cdiv_i(cdiv_i(plen, split_offset), kMinBlockKV) * kMinBlockKV;  // split_offset = prefix splits
-    for (int idx = threadIdx.x; idx < ((heads_here + 1) & ~1) * 128; idx += 256) {  // two heads per trip, uniform
-      const int hh = idx >> 7, d = idx & 127;
-      const bool ok = hh < heads_here;
-      const int hq = kvh * group + ht * 16 + (ok ? hh : 0);
-      float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
-      // prefix partials (global), loads issued together
-      const int64_t base = ((int64_t)b * Hq + hq) * total_splits;
-      float tv[16], tl[16];
-#pragma unroll
-      for (int sp = 0; sp < 16; ++sp) {
-        const bool live = ok && sp < split_offset && per_p * sp < plen;
-        tv[sp] = live ? attn_logits[(base + sp) * 128 + d] : 0.f;
-        tl[sp] = live ? attn_lse[base + sp] : -INFINITY;
-      }
-#pragma unroll
-      for (int sp = 0; sp < 16 + kWavesPerBlock; ++sp) {
-        float v, l;
-        if (sp < 16) {
-          v = tv[sp];
-          l = tl[sp];
-        } else {
-          const char* wbase = lds_all + (sp - 16) * kLdsPerWave;
-          v = reinterpret_cast<const float*>(wbase)[hh * 128 + d];
-          l = reinterpret_cast<const float*>(wbase + kTileBytes)[hh];
-        }
-        if (l > -INFINITY) {
-          const float n_max = fmaxf(l, e_max);
-          const float old = expf(e_max - n_max), w = expf(l - n_max);
-          acc = acc * old + w * v;
-          e_sum = e_sum * old + w;
-          e_max = n_max;
-        }
-      }
-      const float res = acc / e_sum;
-      if (ok) st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d, res);
-      if (xsum_out) {
-        // a head is 128 consecutive idx = two waves: pair them through LDS (the V-tile area past the lse words)
-        float* xr = reinterpret_cast<float*>(lds_all + kTileBytes + 256);
-        const float r = wave_sum(ok ? Conv<T>::to_f32(Conv<T>::from_f32(res)) : 0.f);
-        if (lane == 0) xr[wid] = r;
-        __syncthreads();
-        if (threadIdx.x == 0 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[0] + xr[1];
-        if (threadIdx.x == 128 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[2] + xr[3];
-        __syncthreads();
-      }
-    }
-    return;
-  }
   if (head_ok) {
     const float inv = 1.0f / lsum;
-    const int64_t ob = ((int64_t)b * Hq + head) * total_splits + split_offset + split;
+    const int64_t ob = ((int64_t)b * Hq + head) * max_kv_splits + split;
     float* dst = attn_logits + ob * 128;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -645,62 +565,255 @@ __global__ void __launch_bounds__(256, 3) decode_stage1_mla(
 }
 
 // ---------------------------------------------------------------------------------------------
-// shared-prefix decode: the prefix of a group is streamed once per (kv head, split, 128 columns)
-// and multiplied against every (request, head) column of the group
+// shared-prefix decode in ONE launch.  Two kinds of blocks run side by side:
+//
+//   prefix blocks  (split, 64-column block, kv head): stream one slice of a group's shared prefix once and
+//                  multiply it against 64 (request, head) columns; one partial (normalised O[128] + log-sum-exp,
+//                  fp32) per column and split goes to the workspace with agent-scope stores, then the block adds
+//                  one to the counter of every (request, kv head) pair it contributed to.
+//   tail blocks    (request, kv head, head tile): the four waves walk the request's private remainder in four
+//                  splits and keep their partials in LDS; the block then waits until the pair's counter shows
+//                  that every prefix partial has landed, merges prefix and remainder in slot order and writes
+//                  the output rows.
+//
+// Prefix blocks hold the lowest block indices and never wait for anything; a tail block only waits for prefix
+// blocks, all of which were handed to the hardware before it.  The wait is bounded all the same: a tail block that
+// sees no progress within kSharedWaitTicks fills its output rows with NaN and raises the workspace's error word
+// instead of hanging the GPU.  The last tail block of a pair to finish clears the pair's counter.
 // ---------------------------------------------------------------------------------------------
-static constexpr int kGroupNC = 1;
-static constexpr int kGroupCols = 64 * kGroupNC;  // columns per block
+#ifdef SGLK_ATTN_STAMPS
+// development aid: wall-clock stamps per block and phase (tools/bench_attn.py --stamps)
+__device__ long long g_attn_stamps[1024 * 8];
+#define ATTN_STAMP(k)                                                                                           \
+  do {                                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_stamps[blockIdx.x * 8 + (k)] = (long long)wall_clock64(); \
+  } while (0)
+#else
+#define ATTN_STAMP(k) \
+  do {                \
+  } while (0)
+#endif
+
+static constexpr int kSharedMaxSplits = 16;
+static constexpr int kSc1 = 16;                             // cache policy of the buffer instructions below: agent scope
+static constexpr uint64_t kSharedWaitTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+static constexpr int kTailDone = 1 << 16;                   // a finished tail block adds this to the pair's counter
+static constexpr int kPrefixPF = 4;                         // prefix tiles in flight per block
+
+struct SharedWs {
+  float* part_o;    // [B * Hq][prefix_splits][128]
+  float* part_lse;  // [B * Hq][prefix_splits]
+  int* counters;    // [B * Hkv] (low half: prefix partials landed, high half: tail blocks done)
+  int* error;       // raised by a tail block whose wait ran out
+  int rows;         // B * Hq * prefix_splits (the host keeps rows * 512 below 2^31: byte offsets are 32-bit)
+  __device__ __forceinline__ auto rsrc_o() const {
+    return __builtin_amdgcn_make_buffer_rsrc(part_o, 0, rows * 512, 0x00020000);
+  }
+  __device__ __forceinline__ auto rsrc_lse() const {
+    return __builtin_amdgcn_make_buffer_rsrc(part_lse, 0, rows * 4, 0x00020000);
+  }
+};
+
+// number of 64-column prefix blocks whose columns touch request r (r relative to its group's first request)
+__device__ __forceinline__ int prefix_blocks_of(int r, int heads) {
+  return ((r + 1) * heads - 1) / 64 - (r * heads) / 64 + 1;
+}
+__device__ __forceinline__ int active_prefix_splits(int plen, int prefix_splits) {
+  if (plen <= 0) return 0;
+  const int per_p = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+  return cdiv_i(plen, per_p);
+}
 
 template <typename T>
-__global__ void __launch_bounds__(256) decode_group_prefix_kernel(
+__global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
-    const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, float* __restrict__ part_o,
-    float* __restrict__ part_lse, int prefix_splits, int total_splits, int Hq, int Hkv, int64_t q_stride_b,
+    const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, int num_groups, SharedWs ws,
+    int prefix_splits, int n_prefix_blocks, int col_blocks, int B, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
-    float logit_cap) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int grp = blockIdx.z / prefix_splits, split = blockIdx.z - grp * prefix_splits;
-  const int kvh = blockIdx.y;
-  const int gstart = group_indptr[grp];
-  const int gsize = group_indptr[grp + 1] - gstart;
-  const int heads = Hq / Hkv;
-  const int col0 = blockIdx.x * kGroupCols;
-  const int plen = prefix_lens[grp];
-  const int per_split = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
-  const int t0 = per_split * split, t1 = min(t0 + per_split, plen);
-  if (col0 >= gsize * heads || t1 <= t0) return;  // block-uniform
+    float logit_cap, void* __restrict__ o, int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out,
+    int64_t xs_stride) {
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  __shared__ int wait_failed;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int hl = lane & 15, g = lane >> 4;
+  const int heads = Hq / Hkv;
+  ATTN_STAMP(0);
 
-  BlockAttn<T, kGroupNC> st;
-  st.init();
-  int qpos[kGroupNC];
-  int req[kGroupNC], head[kGroupNC];
-#pragma unroll
-  for (int c = 0; c < kGroupNC; ++c) {
-    const int col = col0 + (wid * kGroupNC + c) * 16 + hl;
+  if ((int)blockIdx.x < n_prefix_blocks) {
+    // ---- prefix block: index = ((grp * prefix_splits + split) * col_blocks + cb) * Hkv + kvh, so that the blocks of
+    // one kv head are congruent modulo Hkv (with 8 kv heads: one XCD and its L2 per kv head)
+    int i = blockIdx.x;
+    const int kvh = i % Hkv;
+    i /= Hkv;
+    const int cb = i % col_blocks;
+    i /= col_blocks;
+    const int split = i % prefix_splits, grp = i / prefix_splits;
+    const int gstart = group_indptr[grp];
+    const int gsize = group_indptr[grp + 1] - gstart;
+    const int col0 = cb * 64;
+    const int plen = prefix_lens[grp];
+    const int per_split = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+    const int t0 = per_split * split, t1 = min(t0 + per_split, plen);
+    if (col0 >= gsize * heads || t1 <= t0) return;  // block-uniform: contributes nothing, counts nowhere
+
+    BlockAttn<T, 1> st;
+    st.init();
+    int qpos[1] = {0};
+    const int col = col0 + wid * 16 + hl;
     const bool ok = col < gsize * heads;
-    req[c] = ok ? gstart + col / heads : -1;
-    head[c] = kvh * heads + col % heads;
-    qpos[c] = 0;
-    st.load_q(c, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req[c] * q_stride_b + (int64_t)head[c] * q_stride_h
+    const int req = ok ? gstart + col / heads : -1;
+    const int head = kvh * heads + col % heads;
+    st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
                     : nullptr);
+    // every request of the group lists the same slots for the prefix: walk the first request's list
+    st.template run<false, true, kPrefixPF>(
+        lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+        reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+        kv_indices + kv_indptr[gstart], t0, t1, qpos, 0, sm_scale, logit_cap);
+    const float tot = st.total(0);
+    ATTN_STAMP(1);
+    if (ok) {
+      const float inv = 1.0f / tot;
+      const int ob = (req * Hq + head) * prefix_splits + split;
+      const auto ro = ws.rsrc_o();
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, st.oacc[0][n] * inv), ro,
+                                               ob * 512 + (16 * n + 4 * g) * 4, 0, kSc1);
+      if (g == 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (st.m[0] + log2f(tot)) * 0.6931471805599453f),
+                                              ws.rsrc_lse(), ob * 4, 0, kSc1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
+    __syncthreads();
+    ATTN_STAMP(2);
+    // one count per request this block's columns touch
+    const int r_lo = col0 / heads, r_hi = (min(col0 + 64, gsize * heads) - 1) / heads;
+    if ((int)threadIdx.x <= r_hi - r_lo)
+      __hip_atomic_fetch_add(ws.counters + (int64_t)(gstart + r_lo + threadIdx.x) * Hkv + kvh, 1, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
-  // every request of the group lists the same slots for the prefix: walk the first request's list
-  st.template run<false, true, 2>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-                                  reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
-                                  v_stride_n, kv_indices + kv_indptr[gstart], t0, t1, qpos, 0, sm_scale, logit_cap);
+
+  // ---- tail block: index = (b * Hkv + kvh) * head_tiles + ht (the kv heads of one request are neighbours in dispatch
+  // order: together they fetch whole pool rows)
+  int i = blockIdx.x - n_prefix_blocks;
+  const int ht = i % head_tiles;
+  i /= head_tiles;
+  const int kvh = i % Hkv, b = i / Hkv;
+  char* kl = lds_all + wid * kLdsPerWave;
+  char* vl = kl + kTileBytes;
+  const int grp = find_group(group_indptr, num_groups, b);
+  const int plen = prefix_lens[grp];
+  const int start = kv_indptr[b] + plen;
+  const int len = kv_indptr[b + 1] - start;
+  const int splits = tail_splits(len, kWavesPerBlock);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int s0 = per_split * wid;
+  const int s1 = max(min(s0 + per_split, len), s0);
+  const bool active = s1 > s0;  // wave-uniform
+  const int head_in_group = ht * 16 + hl;
+  const bool head_ok = head_in_group < heads;
+  const int head = kvh * heads + head_in_group;
+
+  WaveAttn<T> wa;
+  wa.init();
+  wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                    : nullptr);
+  wa.run2(kl, vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+          reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+          kv_indices + start, s0, s1, sm_scale, logit_cap);
+  {
+    // this wave's partial: O[16 heads][128] fp32 over its K tile, log-sum-exp[16] at the head of its V tile
+    const float lsum = wa.total();
+    float* po = reinterpret_cast<float*>(kl);
+    float* pl = reinterpret_cast<float*>(vl);
+    const float inv = active ? 1.0f / lsum : 0.f;
 #pragma unroll
-  for (int c = 0; c < kGroupNC; ++c) {
-    const float tot = st.total(c);
-    if (req[c] < 0) continue;
-    const float inv = 1.0f / tot;
-    const int64_t ob = ((int64_t)req[c] * Hq + head[c]) * total_splits + split;
-    float* dst = part_o + ob * 128;
+    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(po + hl * 128 + 16 * n + 4 * g) = wa.oacc[n] * inv;
+    if (g == 0) pl[hl] = active ? (wa.m + log2f(lsum)) * 0.6931471805599453f : -INFINITY;
+  }
+  ATTN_STAMP(1);
+  // ---- wait for the pair's prefix partials
+  const int aps = active_prefix_splits(plen, prefix_splits);
+  int* const counter = ws.counters + (int64_t)b * Hkv + kvh;
+  if (threadIdx.x == 0) {
+    const int expect = prefix_blocks_of(b - group_indptr[grp], heads) * aps;
+    int failed = 0;
+    if (expect > 0) {
+      const uint64_t t_start = wall_clock64();
+      uint32_t polls = 0;
+      while ((__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (kTailDone - 1)) < expect) {
+        if ((++polls & 255u) == 0 && wall_clock64() - t_start > kSharedWaitTicks) {
+          failed = 1;
+          __hip_atomic_store(ws.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    wait_failed = failed;
+  }
+  __syncthreads();  // also: every wave's partial is in LDS
+  ATTN_STAMP(2);
+  const bool failed = wait_failed != 0;
+  const int heads_here = min(16, heads - ht * 16);
+  const auto ro = ws.rsrc_o();
+  const auto rl = ws.rsrc_lse();
+  float* xr = reinterpret_cast<float*>(lds_all + kTileBytes + 256);  // wave 0's V tile past its 16 lse words
+  for (int base = 0; base < heads_here * 128; base += 256) {  // block-uniform trip count
+    const int idx = base + threadIdx.x;
+    const bool ok = idx < heads_here * 128;
+    const int hh = ok ? idx >> 7 : 0, d = idx & 127;
+    const int hq = kvh * heads + ht * 16 + hh;
+    const int row0 = (b * Hq + hq) * prefix_splits;
+    // prefix partials (global), loads issued together
+    float tv[kSharedMaxSplits], tl[kSharedMaxSplits];
 #pragma unroll
-    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = st.oacc[c][n] * inv;
-    if (g == 0) part_lse[ob] = (st.m[c] + log2f(tot)) * 0.6931471805599453f;
+    for (int sp = 0; sp < kSharedMaxSplits; ++sp) {
+      const bool live = ok && !failed && sp < aps;
+      tv[sp] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, (row0 + sp) * 512 + d * 4, 0, kSc1))
+                    : 0.f;
+      tl[sp] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (row0 + sp) * 4, 0, kSc1))
+                    : -INFINITY;
+    }
+    float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < kSharedMaxSplits + kWavesPerBlock; ++sp) {
+      float v, l;
+      if (sp < kSharedMaxSplits) {
+        v = tv[sp];
+        l = tl[sp];
+      } else {
+        const char* wbase = lds_all + (sp - kSharedMaxSplits) * kLdsPerWave;
+        v = reinterpret_cast<const float*>(wbase)[hh * 128 + d];
+        l = reinterpret_cast<const float*>(wbase + kTileBytes)[hh];
+      }
+      if (l > -INFINITY) {
+        const float n_max = fmaxf(l, e_max);
+        const float old = expf(e_max - n_max), w = expf(l - n_max);
+        acc = acc * old + w * v;
+        e_sum = e_sum * old + w;
+        e_max = n_max;
+      }
+    }
+    const float res = failed ? __builtin_nanf("") : acc / e_sum;
+    if (ok) st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d, res);
+    if (xsum_out) {
+      // a head is 128 consecutive idx = two waves: pair them through LDS
+      const float r = wave_sum(ok ? Conv<T>::to_f32(Conv<T>::from_f32(res)) : 0.f);
+      __syncthreads();  // the partials under xr have been read by everyone
+      if (lane == 0) xr[wid] = r;
+      __syncthreads();
+      if ((threadIdx.x & 127) == 0 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[wid] + xr[wid + 1];
+    }
+  }
+  ATTN_STAMP(3);
+  // the pair's last tail block leaves the counter at zero for the next launch
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(counter, kTailDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((old >> 16) == head_tiles - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -817,12 +930,10 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
     const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
     SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((decode_stage1_mfma128<T, false>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
-                                          k_buffer, v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse,
-                                          num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h,
-                                          k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap,
-                                          (const int32_t*)nullptr, (const int32_t*)nullptr, 0, 0, max_kv_splits,
-                                          (void*)nullptr, (int64_t)0, (int64_t)0, (float*)nullptr, (int64_t)0));
+                       hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer,
+                                          v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                                          max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap));
   } else {
     dim3 grid(B, Hq, max_kv_splits);
     const size_t lds = (size_t)D * sizeof(float);
@@ -867,12 +978,33 @@ int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buf
                                   stream);
 }
 
-static constexpr int kTailMaxSplits = 4;  // remainder splits per request (one block of four waves)
+// Workspace of the shared-prefix path: [counters: B * Hq int32 + one error word, rounded up to 256 bytes]
+// [O partials: B * Hq * max_kv_splits * Dv fp32][log-sum-exp: B * Hq * max_kv_splits fp32].
+static int64_t shared_counter_bytes(int B, int Hq) { return ((((int64_t)B * Hq + 1) * 4 + 255) / 256) * 256; }
 
 int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits) {
   if (B <= 0 || Hq <= 0 || Dv <= 0 || max_kv_splits <= 0) return 0;
-  return (int64_t)B * Hq * (max_kv_splits + kTailMaxSplits) * (Dv + 1) * (int64_t)sizeof(float);
+  return shared_counter_bytes(B, Hq) + (int64_t)B * Hq * max_kv_splits * (Dv + 1) * (int64_t)sizeof(float);
 }
+
+int sglk_decode_shared_workspace_init(void* workspace, int B, int Hq, void* stream) {
+  SGLK_CHECK(workspace && B > 0 && Hq > 0, "decode_shared_workspace_init: bad arguments");
+  SGLK_HIP(hipMemsetAsync(workspace, 0, (size_t)shared_counter_bytes(B, Hq), (hipStream_t)stream));
+  return SGLK_OK;
+}
+
+int sglk_decode_shared_workspace_status(const void* workspace, int B, int Hq) {
+  if (!workspace || B <= 0 || Hq <= 0) return fail(SGLK_EINVAL, "decode_shared_workspace_status: bad arguments");
+  int word = 0;
+  SGLK_HIP(hipMemcpy(&word, reinterpret_cast<const int*>(workspace) + (int64_t)B * Hq, sizeof(int), hipMemcpyDeviceToHost));
+  return word != 0 ? 1 : 0;
+}
+
+#ifdef SGLK_ATTN_STAMPS
+SGLK_API int sglk_debug_attn_stamps(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_attn_stamps), sizeof(long long) * 1024 * 8);
+}
+#endif
 
 int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o,
                                            const int32_t* kv_indptr, const int32_t* kv_indices,
@@ -886,7 +1018,8 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
   SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
              "decode_attention_shared_prefix: null pointer");
   SGLK_CHECK(B >= 0 && G > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
-  SGLK_CHECK(max_kv_splits > 0 && max_kv_splits <= 16, "decode_attention_shared_prefix: max_kv_splits must be in 1..16");
+  SGLK_CHECK(max_kv_splits > 0 && max_kv_splits <= kSharedMaxSplits,
+             "decode_attention_shared_prefix: max_kv_splits must be in 1..16");
   if (B == 0) return SGLK_OK;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
   const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
@@ -897,31 +1030,32 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
                 D, Dv, dtype);
   hipStream_t s = (hipStream_t)stream;
   const int heads = Hq / Hkv;
-  const int total_splits = max_kv_splits + kTailMaxSplits;
-  float* part_o = workspace;
-  float* part_lse = workspace + (int64_t)B * Hq * total_splits * 128;
-  {
-    dim3 grid((B * heads + kGroupCols - 1) / kGroupCols, Hkv, G * max_kv_splits);
-    SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((decode_group_prefix_kernel<T>), grid, dim3(256), kBlockAttnLds, s, q, k_buffer,
-                                          v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, part_o, part_lse,
-                                          max_kv_splits, total_splits, Hq, Hkv, q_stride_b, q_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap));
-    SGLK_LAUNCH_CHECK();
-  }
-  {
-    const int head_tiles = (heads + 15) / 16;
-    dim3 grid(B, Hkv * head_tiles, 1);
-    const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
-    SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((decode_stage1_mfma128<T, true>), grid, dim3(64 * kWavesPerBlock), lds, s, q,
-                                          k_buffer, v_buffer, kv_indptr, kv_indices, part_o, part_lse,
-                                          (const int32_t*)nullptr, kTailMaxSplits, Hq, Hkv, head_tiles, q_stride_b,
-                                          q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap,
-                                          group_indptr, prefix_lens, G, max_kv_splits, total_splits, o, o_stride_b,
-                                          o_stride_h, xsum_out, xs_stride));
-    SGLK_LAUNCH_CHECK();
-  }
+  // prefix splits: enough 64-column blocks to cover the CUs once, as far as max_kv_splits allows
+  static const int env_sp = getenv("SGLK_SHARED_SPLITS") ? atoi(getenv("SGLK_SHARED_SPLITS")) : 0;
+  const int head_tiles = (heads + 15) / 16;
+  const int col_blocks = (B * heads + 63) / 64;  // upper bound per group; blocks past a group's columns leave at once
+  int prefix_splits = std::max(1, std::min(max_kv_splits, 256 / std::max(1, col_blocks * Hkv)));
+  if (env_sp > 0) prefix_splits = std::min(env_sp, max_kv_splits);
+  SharedWs ws;
+  const int64_t rows = (int64_t)B * Hq * prefix_splits;
+  SGLK_CHECK(rows * 512 < ((int64_t)1 << 31), "decode_attention_shared_prefix: B * Hq * max_kv_splits too large");
+  SGLK_CHECK(heads <= kTailDone / 64, "decode_attention_shared_prefix: too many query heads per kv head");
+  ws.rows = (int)rows;
+  ws.counters = reinterpret_cast<int*>(workspace);
+  ws.error = ws.counters + (int64_t)B * Hq;
+  ws.part_o = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
+  ws.part_lse = ws.part_o + rows * 128;
+  const int n_prefix = G * prefix_splits * col_blocks * Hkv;
+  const int n_tail = B * Hkv * head_tiles;
+  const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;  // covers the prefix blocks' two stages as well
+  static_assert(kWavesPerBlock * kLdsPerWave >= kBlockAttnLds, "LDS of the tail role must cover the prefix role");
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((decode_shared_fused_kernel<T>), dim3(n_prefix + n_tail), dim3(256), lds, s, q,
+                                        k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G, ws,
+                                        prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles, q_stride_b, q_stride_h,
+                                        k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o, o_stride_b,
+                                        o_stride_h, xsum_out, xs_stride));
+  SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
 

@@ -245,9 +245,14 @@ struct WaveAttn {
     }
   }
 
-  int4v kreg[8], vreg[8];  // one tile in flight: instruction i covers rows 4i + g
-  __device__ __forceinline__ void fetch(const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
-                                        int64_t v_stride_n, const int32_t* idx, int t0, int s0, int s1) {
+  // Rows of one tile on their way from the pool to LDS: instruction i covers rows 4i + g.
+  struct Rows {
+    int4v k[8], v[8];
+  };
+  Rows rows;  // the tile run() keeps in flight
+
+  static __device__ __forceinline__ void fetch(Rows& r, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                               int64_t v_stride_n, const int32_t* idx, int t0, int s0, int s1) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, chunk = lane & 15;  // chunk: 16-byte piece of the row this lane fetches
 #pragma unroll
@@ -255,86 +260,113 @@ struct WaveAttn {
       int tok = t0 + 4 * i + g;
       tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
       const int64_t slot = idx[tok];
-      kreg[i] = *reinterpret_cast<const int4v*>(kbase + slot * k_stride_n + chunk * 8);
-      vreg[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
+      r.k[i] = *reinterpret_cast<const int4v*>(kbase + slot * k_stride_n + chunk * 8);
+      r.v[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
     }
   }
 
-  // Stream tokens [s0, s1) of the slot list idx (wave-uniform range, may be empty).
+  // fetched rows -> this wave's K / V tile in LDS (swizzled)
+  static __device__ __forceinline__ void park(const Rows& r, char* kl, char* vl) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + g;
+      *reinterpret_cast<int4v*>(kl + k_off(row, chunk)) = r.k[i];
+      *reinterpret_cast<int4v*>(vl + v_off(row, chunk * 16)) = r.v[i];
+    }
+  }
+
+  // One parked tile (tokens t0 .. t0 + 31 of a list that ends at s1) into the running state.  col_ok: this lane's
+  // query column takes part in the tile (a column that does not keeps its state).
+  __device__ __forceinline__ void step(const char* kl, const char* vl, int t0, int s1, bool col_ok, float sm_scale,
+                                       float logit_cap) {
+    const int lane = threadIdx.x & 63;
+    const int hl = lane & 15, g = lane >> 4;
+    const float LOG2E = 1.4426950408889634f;
+    const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+    // ---- S^T = K . Q^T : two 16-token halves, lane (hl, g) gets tokens 16*hh + 4*g + r of column hl
+    float4v sacc[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
+        sacc[hh] = Mfma16<T>::mma(kf, qf[ks], sacc[hh]);
+      }
+    }
+    // ---- scale / cap / mask, online softmax (exp2 domain)
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = sacc[hh][r] * qk_scale;
+        if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
+        const int tok = t0 + 16 * hh + 4 * g + r;
+        s = (col_ok && tok < s1) ? s : -INFINITY;
+        sv[hh * 4 + r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // nothing seen yet: everything stays at zero
+    const float alpha = exp2f(m - m_use);
+    m = m_new;
+    float psum = 0.f;
+    short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p = exp2f(sv[j] - m_use);
+      psum += p;
+      pf[j] = (short)Conv<T>::from_f32(p);
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
+    // ---- O^T += V^T . P^T : eight 16-column blocks of V, read transposed
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int byte_in_row = 32 * n + 8 * (hl & 3);
+      const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
+      const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
+      const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
+    }
+  }
+
+  // Stream tokens [s0, s1) of the slot list idx (wave-uniform range, may be empty); one tile in flight.
   __device__ __forceinline__ void run(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
                                       int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
                                       float sm_scale, float logit_cap) {
-    const int lane = threadIdx.x & 63;
-    const int hl = lane & 15, g = lane >> 4;
-    const int chunk = lane & 15;
-    const float LOG2E = 1.4426950408889634f;
-    const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
-
-    auto park = [&]() {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int r = 4 * i + g;
-        *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[i];
-        *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[i];
-      }
-    };
-
-    if (s1 > s0) fetch(kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
+    if (s1 > s0) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
     for (int t0 = s0; t0 < s1; t0 += kTile) {
-      park();
+      park(rows, kl, vl);
       if (t0 + kTile < s1)  // next tile's rows fly while this one is multiplied
-        fetch(kbase, vbase, k_stride_n, v_stride_n, idx, t0 + kTile, s0, s1);
+        fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, t0 + kTile, s0, s1);
+      step(kl, vl, t0, s1, true, sm_scale, logit_cap);
+    }
+  }
 
-      // ---- S^T = K . Q^T : two 16-token halves, lane (hl, g) gets tokens 16*hh + 4*g + r of column hl
-      float4v sacc[2];
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const short8 kf = *reinterpret_cast<const short8*>(kl + k_off(16 * hh + hl, 4 * ks + g));
-          sacc[hh] = Mfma16<T>::mma(kf, qf[ks], sacc[hh]);
-        }
-      }
-      // ---- scale / cap / mask, online softmax (exp2 domain)
-      float sv[8];
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float s = sacc[hh][r] * qk_scale;
-          if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
-          const int tok = t0 + 16 * hh + 4 * g + r;
-          s = tok < s1 ? s : -INFINITY;
-          sv[hh * 4 + r] = s;
-          tmax = fmaxf(tmax, s);
-        }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m, tmax);  // finite: token t0 of this tile is always valid
-      const float alpha = exp2f(m - m_new);
-      m = m_new;
-      float psum = 0.f;
-      short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float p = exp2f(sv[j] - m_new);
-        psum += p;
-        pf[j] = (short)Conv<T>::from_f32(p);
-      }
-      lsum = lsum * alpha + psum;
-#pragma unroll
-      for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
-      // ---- O^T += V^T . P^T : eight 16-column blocks of V, read transposed
-#pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        const int byte_in_row = 32 * n + 8 * (hl & 3);
-        const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
-        const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
-        const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
-      }
+  // The same with two tiles in flight (64 more registers): short ranges, where the first round trip to memory is
+  // most of the time, start both of their tiles at once.
+  __device__ __forceinline__ void run2(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
+                                       int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
+                                       float sm_scale, float logit_cap) {
+    Rows other;
+    if (s1 > s0) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
+    if (s1 > s0 + kTile) fetch(other, kbase, vbase, k_stride_n, v_stride_n, idx, s0 + kTile, s0, s1);
+    for (int t0 = s0; t0 < s1; t0 += 2 * kTile) {
+      park(rows, kl, vl);
+      if (t0 + 2 * kTile < s1) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, t0 + 2 * kTile, s0, s1);
+      step(kl, vl, t0, s1, true, sm_scale, logit_cap);
+      if (t0 + kTile >= s1) break;
+      park(other, kl, vl);
+      if (t0 + 3 * kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, idx, t0 + 3 * kTile, s0, s1);
+      step(kl, vl, t0 + kTile, s1, true, sm_scale, logit_cap);
     }
   }
 

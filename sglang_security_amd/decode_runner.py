@@ -484,8 +484,7 @@ class LlamaDecoder:
             c = self.cfg
             self.group_indptr = torch.tensor([0, self.B], dtype=torch.int32, device=self.device)
             self.group_prefix = torch.tensor([self.prefix_len], dtype=torch.int32, device=self.device)
-            nbytes = ops.decode_shared_workspace_bytes(self.B, c.q_heads, c.head_dim, self.max_kv_splits)
-            self.shared_ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            self.shared_ws = ops.decode_shared_workspace(self.B, c.q_heads, c.head_dim, self.max_kv_splits, self.device)
         return self.shared
 
     def attention(self, li, q_view, o_view, sm_scale, xsum_out=None):

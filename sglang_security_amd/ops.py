@@ -139,6 +139,15 @@ def decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits) -> int:
     return int(lib().sglk_decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits))
 
 
+def decode_shared_workspace(B, Hq, Dv, max_kv_splits, device) -> torch.Tensor:
+    """A workspace for decode_attention_shared_prefix with its ticket counters (the first B * Hq words) cleared; the
+    kernels leave them cleared, so one tensor serves every later call that does not overlap another one in time."""
+    ws = torch.empty(decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits) // 4, dtype=torch.float32, device=device)
+    check(lib().sglk_decode_shared_workspace_init(_ptr(ws), B, Hq, torch.cuda.current_stream(ws.device).cuda_stream),
+          "decode_shared_workspace_init")
+    return ws
+
+
 def decode_attention_shared_prefix(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens,
                                    workspace, max_kv_splits, sm_scale, logit_cap=0.0):
     _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, workspace)

@@ -161,7 +161,7 @@ def _group_batch(groups, Hq, Hkv, dtype, seed):
 def _run_shared(ops, q, kb, vb, ptr, ind, gi, pls, max_splits, dtype, sm, cap=0.0):
     B, Hq, D = q.shape
     o = torch.full((B, Hq, D), float("nan"), dtype=dtype, device=DEV)
-    ws = torch.empty(ops.decode_shared_workspace_bytes(B, Hq, D, max_splits) // 4, dtype=torch.float32, device=DEV)
+    ws = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
     args = (q.to(DEV), kb.to(DEV), vb.to(DEV))
     meta = (ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV))
     ops.decode_attention_shared_prefix(*args, o, *meta, ws, max_splits, sm, cap)

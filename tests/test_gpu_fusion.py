@@ -131,7 +131,7 @@ def test_attention_block_sums():
     lse = torch.empty(B, Hq, 8, dtype=torch.float32, device=DEV)
     ns = torch.full((B,), 4, dtype=torch.int32, device=DEV)
     ops.decode_attention_fwd_xs(q.to(DEV), kb.to(DEV), vb.to(DEV), o1, ptr.to(DEV), ind.to(DEV), al, lse, ns, 8, sm, 0.0, xs1)
-    ws = torch.empty(ops.decode_shared_workspace_bytes(B, Hq, D, 8) // 4, dtype=torch.float32, device=DEV)
+    ws = ops.decode_shared_workspace(B, Hq, D, 8, DEV)
     ops.decode_attention_shared_prefix_xs(q.to(DEV), kb.to(DEV), vb.to(DEV), o2, ptr.to(DEV), ind.to(DEV), gi.to(DEV),
                                           pls.to(DEV), ws, 8, sm, 0.0, xs2)
     torch.testing.assert_close(xs1, _block_sums(o1.view(B, Hq * D)), rtol=1e-4, atol=2e-2)

@@ -2,8 +2,13 @@
 fused AWQ GEMM, dense skinny GEMM, RMSNorm / fused add, gated activations, RoPE, KV-pool writes, merge_state.
 
 Tolerances are the reference's (sgl-kernel/tests): awq_dequantize rtol 1e-3 atol 1e-5 (we require bit
-equality), norm / activation rtol=atol=1e-3 (fp16), rope 1e-2, merge_state atol 1e-3 rtol 1e-2;
-GEMM bf16 1e-2 (test/srt/cpu/utils.py:6-10)."""
+equality), norm / activation rtol=atol=1e-3 (fp16), rope 1e-2, merge_state atol 1e-3 rtol 1e-2.
+
+GEMMs: per element atol = rtol = 1e-2 for bf16 (test/srt/cpu/utils.py:6-10), 2e-3 for fp16, on outputs of order one
+(activations are scaled so that the products have a standard deviation near 0.5, the magnitude the reference's bar is
+written for).  The fused kernel multiplies by (q - z) * scale without first rounding the dequantised weight to 16 bits,
+as the reference's dequantise-then-matmul does; that rounding (relative 2^-9 per bf16 weight) is what the tolerance
+absorbs."""
 import math
 
 import pytest
@@ -49,8 +54,14 @@ def _awq_case(M, K, N, group, dtype, seed):
     qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, generator=g)
     qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // group, N // 8), dtype=torch.int32, generator=g)
     sc = (torch.rand(K // group, N, generator=g) * 0.01 + 0.001).to(dtype)
-    x = torch.randn(M, K, generator=g).to(dtype)
+    # (q - z) * scale has a standard deviation near 0.04: outputs of standard deviation ~0.5
+    x = (torch.randn(M, K, generator=g) * (12.0 / math.sqrt(K))).to(dtype)
     return x, qw, sc, qz
+
+
+def _gemm_close(got, want, dtype):
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    torch.testing.assert_close(got.float(), want.float(), atol=tol, rtol=tol)
 
 
 @pytest.mark.parametrize("M,K,N,group", [(64, 512, 128, 128), (8, 1024, 256, 128), (1, 256, 64, 128),
@@ -65,9 +76,7 @@ def test_awq_gemm_vs_oracle(M, K, N, group, dtype):
     want = oracle.awq_gemm(x, qw, sc, qz).float()
     packed = ops.awq_repack(qw.to(DEV))
     out = ops.awq_gemm(x.to(DEV), packed, sc.to(DEV), qz.to(DEV)).float().cpu()
-    scale = want.abs().max().item()
-    assert (out - want).abs().max().item() <= 1e-2 * scale + 1e-3
-    torch.testing.assert_close(out, want, rtol=2e-2, atol=1e-2 * scale)
+    _gemm_close(out, want, dtype)
 
 
 def test_awq_gemm_golden(golden):
@@ -77,8 +86,9 @@ def test_awq_gemm_golden(golden):
         packed = ops.awq_repack(g["qweight"].to(DEV))
         out = ops.awq_gemm(g["x"].to(DEV), packed, g["scales"].to(DEV), g["qzeros"].to(DEV)).float().cpu()
         want = g["expect_matmul_f32"]
-        scale = want.abs().max().item()
-        assert (out - want).abs().max().item() <= 1e-2 * scale
+        # the fixture's outputs have a standard deviation near 60: the reference's bar after normalising to unit RMS
+        rms = want.pow(2).mean().sqrt().item()
+        torch.testing.assert_close(out / rms, want / rms, atol=1e-2, rtol=1e-2)
 
 
 def test_awq_gemm_exact_on_integers():
@@ -111,15 +121,14 @@ def test_awq_gemm_llama8b_shapes_linearity(M, K, N):
     scd, qzd = sc.to(DEV), qz.to(DEV)
     y1 = ops.awq_gemm(x.to(DEV), packed, scd, qzd).float()
     y2 = ops.awq_gemm((2 * x).to(DEV), packed, scd, qzd).float()
-    assert (y2 - 2 * y1).abs().max().item() <= 2e-2 * y1.abs().max().item()
+    assert torch.equal(y2, 2 * y1)  # doubling is exact in every product, sum and rounding
     cols = torch.arange(0, N, max(N // 64, 8))[:64]
     blocks = torch.unique(cols // 8)
     # oracle on the int32 columns that hold the sampled outputs
     sub_cols = (blocks[:, None] * 8 + torch.arange(8)[None, :]).flatten()
     want = oracle.awq_gemm(x, qw[:, blocks].contiguous(), sc[:, sub_cols].contiguous(), qz[:, blocks].contiguous())
     got = y1.cpu()[:, sub_cols]
-    scale = want.float().abs().max().item()
-    assert (got - want.float()).abs().max().item() <= 1e-2 * scale
+    _gemm_close(got, want, torch.bfloat16)
 
 
 @pytest.mark.parametrize("M,K,N", [(64, 512, 256), (3, 1024, 100), (64, 4096, 1000)])
@@ -135,8 +144,7 @@ def test_dense_gemm_nt(M, K, N, dtype, strips, monkeypatch):
     w = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
     want = oracle.half_matmul(x, w.t().contiguous()).float()
     out = ops.dense_gemm_nt(x.to(DEV), w.to(DEV)).float().cpu()
-    scale = want.abs().max().item()
-    assert (out - want).abs().max().item() <= 1e-2 * scale
+    _gemm_close(out, want, dtype)
 
 
 @pytest.mark.parametrize("M,K,N,bias", [(64, 4096, 4096, False), (64, 14336, 4096, True), (7, 4096, 6144, False),
@@ -160,7 +168,7 @@ def test_dense_gemm_nt_split_k(M, K, N, bias):
     want = oracle.half_matmul(x[rows], w.t().contiguous()).float()
     if bias:
         want = (want + b.float()).to(torch.bfloat16).float()
-    assert (got[rows] - want).abs().max().item() <= 1e-2 * scale
+    _gemm_close(got[rows], want, torch.bfloat16)
 
 
 # ---------------------------------------------------------------------------------------------- norm / act / rope
@@ -287,8 +295,7 @@ def test_awq_gemm_wide_vs_oracle(force_wide, M, K, N, dtype):
     want = oracle.awq_gemm(x, qw, sc, qz).float()
     packed = ops.awq_repack(qw.to(DEV))
     got = ops.awq_gemm(x.to(DEV), packed, sc.to(DEV), qz.to(DEV)).float().cpu()
-    scale = want.abs().max().item()
-    assert (got - want).abs().max().item() <= 1e-2 * max(scale, 1.0)
+    _gemm_close(got, want, dtype)
     # twice in a row on the same workspace: the ticket words must have been left at zero
     work = torch.zeros(max(ops.awq_gemm_workspace_bytes(M, N, K), 256), dtype=torch.uint8, device=DEV)
     a = ops.awq_gemm(x.to(DEV), packed, sc.to(DEV), qz.to(DEV), None, None, work)
@@ -314,7 +321,7 @@ def test_awq_gemm_wide_zero_scales(force_wide):
     got = ops.awq_gemm(x.to(DEV), ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV)).float().cpu()
     assert torch.isfinite(got).all()
     assert (got[:, 200] == 0).all()
-    assert (got - want).abs().max().item() <= 1e-2 * max(want.abs().max().item(), 1.0)
+    _gemm_close(got, want, torch.bfloat16)
 
 
 def test_awq_gemm_full_size_shapes():
@@ -326,7 +333,7 @@ def test_awq_gemm_full_size_shapes():
         x, qw, sc, qz = _awq_case(64, K, N, 128, torch.bfloat16, seed=K)
         want = oracle.awq_gemm(x, qw, sc, qz).float()
         got = ops.awq_gemm(x.to(DEV), ops.awq_repack(qw.to(DEV)), sc.to(DEV), qz.to(DEV)).float().cpu()
-        assert (got - want).abs().max().item() <= 1e-2 * max(want.abs().max().item(), 1.0)
+        _gemm_close(got, want, torch.bfloat16)
 
 
 

@@ -13,4 +13,13 @@ for a in "$@"; do
   objs=$(ls $C/build/*.o | grep -v "/awq.hip.o")
   hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libsglk_abl$a.so $objs /tmp/awq_abl$a.o
 done
-ls -la tools/libsglk_abl*.so
+ls -la tools/libsglk_abl*.so 2>/dev/null || true
+
+# ATTN=1 tools/build_abl.sh  also builds tools/libsglk_attnstamps.so: the product library with the decode-attention
+# phase stamps compiled in (tools/bench_attn.py --stamps under SGLK_LIB=tools/libsglk_attnstamps.so)
+if [ -n "$ATTN" ]; then
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Iinclude -I$C -DSGLK_ATTN_STAMPS $EXTRA -c $C/attention_decode.hip -o /tmp/attn_stamps.o
+  objs=$(ls $C/build/*.o | grep -v "/attention_decode.hip.o")
+  hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libsglk_attnstamps.so $objs /tmp/attn_stamps.o
+  ls -la tools/libsglk_attnstamps.so
+fi
