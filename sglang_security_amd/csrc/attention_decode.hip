@@ -598,7 +598,7 @@ static constexpr int kSharedMaxSplits = 16;
 static constexpr int kSc1 = 16;                             // cache policy of the buffer instructions below: agent scope
 static constexpr uint64_t kSharedWaitTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
 static constexpr int kTailDone = 1 << 16;                   // a finished tail block adds this to the pair's counter
-static constexpr int kPrefixPF = 4;                         // prefix tiles in flight per block
+static constexpr int kPrefixPF = 2;                         // prefix tiles in flight per block
 
 struct SharedWs {
   float* part_o;    // [B * Hq][prefix_splits][128]
@@ -625,7 +625,7 @@ __device__ __forceinline__ int active_prefix_splits(int plen, int prefix_splits)
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
+__global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, int num_groups, SharedWs ws,
@@ -633,8 +633,11 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
     float logit_cap, void* __restrict__ o, int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out,
     int64_t xs_stride) {
-  extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  extern __shared__ __attribute__((aligned(16))) char lds_all[];  // 32 KiB: the prefix role's two stages of K + V tiles,
+                                                                  // or the tail role's four V tiles
   __shared__ int wait_failed;
+  __shared__ float tail_lse[kWavesPerBlock][16];
+  __shared__ float xr[kWavesPerBlock];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int hl = lane & 15, g = lane >> 4;
   const int heads = Hq / Hkv;
@@ -649,6 +652,9 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
     const int cb = i % col_blocks;
     i /= col_blocks;
     const int split = i % prefix_splits, grp = i / prefix_splits;
+    // the first request's offset into kv_indices depends on gstart; fetching the head of kv_indptr alongside the
+    // group's metadata saves one of the four dependent trips to memory this block starts with
+    const int spec_indptr = kv_indptr[min(lane, B)];
     const int gstart = group_indptr[grp];
     const int gsize = group_indptr[grp + 1] - gstart;
     const int col0 = cb * 64;
@@ -670,7 +676,8 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
     st.template run<false, true, kPrefixPF>(
         lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
         reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
-        kv_indices + kv_indptr[gstart], t0, t1, qpos, 0, sm_scale, logit_cap);
+        kv_indices + (gstart < 64 ? __shfl(spec_indptr, gstart, 64) : kv_indptr[gstart]), t0, t1, qpos, 0, sm_scale,
+        logit_cap);
     const float tot = st.total(0);
     ATTN_STAMP(1);
     if (ok) {
@@ -702,8 +709,7 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
   const int ht = i % head_tiles;
   i /= head_tiles;
   const int kvh = i % Hkv, b = i / Hkv;
-  char* kl = lds_all + wid * kLdsPerWave;
-  char* vl = kl + kTileBytes;
+  char* vl = lds_all + wid * kTileBytes;  // K goes straight into registers: a wave owns one 8 KiB V tile
   const int grp = find_group(group_indptr, num_groups, b);
   const int plen = prefix_lens[grp];
   const int start = kv_indptr[b] + plen;
@@ -721,18 +727,17 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
   wa.init();
   wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
                     : nullptr);
-  wa.run2(kl, vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-          reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
-          kv_indices + start, s0, s1, sm_scale, logit_cap);
+  wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+            reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+            kv_indices + start, s0, s1, sm_scale, logit_cap);
   {
-    // this wave's partial: O[16 heads][128] fp32 over its K tile, log-sum-exp[16] at the head of its V tile
+    // this wave's partial: O[16 heads][128] fp32 over its V tile, log-sum-exp[16] beside it
     const float lsum = wa.total();
-    float* po = reinterpret_cast<float*>(kl);
-    float* pl = reinterpret_cast<float*>(vl);
+    float* po = reinterpret_cast<float*>(vl);
     const float inv = active ? 1.0f / lsum : 0.f;
 #pragma unroll
     for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(po + hl * 128 + 16 * n + 4 * g) = wa.oacc[n] * inv;
-    if (g == 0) pl[hl] = active ? (wa.m + log2f(lsum)) * 0.6931471805599453f : -INFINITY;
+    if (g == 0) tail_lse[wid][hl] = active ? (wa.m + log2f(lsum)) * 0.6931471805599453f : -INFINITY;
   }
   ATTN_STAMP(1);
   // ---- wait for the pair's prefix partials
@@ -761,7 +766,6 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
   const int heads_here = min(16, heads - ht * 16);
   const auto ro = ws.rsrc_o();
   const auto rl = ws.rsrc_lse();
-  float* xr = reinterpret_cast<float*>(lds_all + kTileBytes + 256);  // wave 0's V tile past its 16 lse words
   for (int base = 0; base < heads_here * 128; base += 256) {  // block-uniform trip count
     const int idx = base + threadIdx.x;
     const bool ok = idx < heads_here * 128;
@@ -786,9 +790,8 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
         v = tv[sp];
         l = tl[sp];
       } else {
-        const char* wbase = lds_all + (sp - kSharedMaxSplits) * kLdsPerWave;
-        v = reinterpret_cast<const float*>(wbase)[hh * 128 + d];
-        l = reinterpret_cast<const float*>(wbase + kTileBytes)[hh];
+        v = reinterpret_cast<const float*>(lds_all + (sp - kSharedMaxSplits) * kTileBytes)[hh * 128 + d];
+        l = tail_lse[sp - kSharedMaxSplits][hh];
       }
       if (l > -INFINITY) {
         const float n_max = fmaxf(l, e_max);
@@ -803,7 +806,7 @@ __global__ void __launch_bounds__(256, 2) decode_shared_fused_kernel(
     if (xsum_out) {
       // a head is 128 consecutive idx = two waves: pair them through LDS
       const float r = wave_sum(ok ? Conv<T>::to_f32(Conv<T>::from_f32(res)) : 0.f);
-      __syncthreads();  // the partials under xr have been read by everyone
+      __syncthreads();  // the previous trip's sums have been read
       if (lane == 0) xr[wid] = r;
       __syncthreads();
       if ((threadIdx.x & 127) == 0 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[wid] + xr[wid + 1];
@@ -1047,8 +1050,8 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
   ws.part_lse = ws.part_o + rows * 128;
   const int n_prefix = G * prefix_splits * col_blocks * Hkv;
   const int n_tail = B * Hkv * head_tiles;
-  const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;  // covers the prefix blocks' two stages as well
-  static_assert(kWavesPerBlock * kLdsPerWave >= kBlockAttnLds, "LDS of the tail role must cover the prefix role");
+  const size_t lds = kBlockAttnLds;  // the prefix role's two stages; the tail role's four V tiles fit in the same bytes
+  static_assert(kWavesPerBlock * kTileBytes <= kBlockAttnLds, "LDS of the prefix role must cover the tail role");
   SGLK_DISPATCH_HALF(dtype, T,
                      hipLaunchKernelGGL((decode_shared_fused_kernel<T>), dim3(n_prefix + n_tail), dim3(256), lds, s, q,
                                         k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G, ws,

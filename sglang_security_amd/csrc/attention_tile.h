@@ -103,15 +103,24 @@ struct BlockAttn {
     const float LOG2E = 1.4426950408889634f;
     const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
 
+    // Pool rows are found through the index list, so a tile costs two trips to memory: its indices, then its rows.
+    // The counters that order returning loads are in issue order, so an index load issued after row loads waits for
+    // them; the indices are therefore fetched one round (PF tiles) ahead of the rows that need them.
     int4v kreg[PF][2], vreg[PF][2];
-    auto fetch = [&](int4v(&kr)[2], int4v(&vr)[2], int t0) {
+    int64_t rowi[PF][2];
+    auto fetch_idx = [&](int64_t(&ri)[2], int t0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         int tok = t0 + frow + 16 * i;
         tok = tok < t_end ? tok : t_begin;  // rows past the end re-read a valid row; their scores are masked
-        const int64_t row = GATHER ? (int64_t)idx[tok] : (int64_t)tok;
-        kr[i] = *reinterpret_cast<const int4v*>(kbase + row * k_stride_n + chunk * 8);
-        vr[i] = *reinterpret_cast<const int4v*>(vbase + row * v_stride_n + chunk * 8);
+        ri[i] = GATHER ? (int64_t)idx[tok] : (int64_t)tok;
+      }
+    };
+    auto fetch = [&](int4v(&kr)[2], int4v(&vr)[2], const int64_t(&ri)[2]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        kr[i] = *reinterpret_cast<const int4v*>(kbase + ri[i] * k_stride_n + chunk * 8);
+        vr[i] = *reinterpret_cast<const int4v*>(vbase + ri[i] * v_stride_n + chunk * 8);
       }
     };
     // One K / V fragment read from LDS feeds all NC column tiles of the wave.
@@ -178,7 +187,13 @@ struct BlockAttn {
     __syncthreads();  // a previous run() may still be reading the stages
 #pragma unroll
     for (int p = 0; p < PF; ++p)
-      if (t_begin + p * kTile < t_end) fetch(kreg[p], vreg[p], t_begin + p * kTile);
+      if (t_begin + p * kTile < t_end) fetch_idx(rowi[p], t_begin + p * kTile);
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (t_begin + p * kTile < t_end) fetch(kreg[p], vreg[p], rowi[p]);
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+      if (t_begin + (PF + p) * kTile < t_end) fetch_idx(rowi[p], t_begin + (PF + p) * kTile);
     int stage = 0;
     for (int tb = t_begin; tb < t_end; tb += kTile * PF) {
 #pragma unroll
@@ -194,8 +209,11 @@ struct BlockAttn {
             *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[p][i];
           }
           __syncthreads();
-          if (t0 + PF * kTile < t_end) fetch(kreg[p], vreg[p], t0 + PF * kTile);  // flies while tiles are multiplied
-          if (!(CAUSAL && t0 > wave_qmax)) compute(t0, kl, vl);                   // wave-uniform skip
+          if (t0 + PF * kTile < t_end) {  // flies while tiles are multiplied
+            fetch(kreg[p], vreg[p], rowi[p]);
+            if (t0 + 2 * PF * kTile < t_end) fetch_idx(rowi[p], t0 + 2 * PF * kTile);
+          }
+          if (!(CAUSAL && t0 > wave_qmax)) compute(t0, kl, vl);  // wave-uniform skip
           stage ^= 1;
         }
       }
@@ -251,15 +269,23 @@ struct WaveAttn {
   };
   Rows rows;  // the tile run() keeps in flight
 
+  // Pool slots of tokens base .. base + 63 of a list [s0, s1): lane l holds the slot of token base + l (tokens past the
+  // end re-read a valid slot; their scores are masked).  One load serves two tiles, and it is issued well before the
+  // row loads that need it: the counters that order returning loads are in issue order.
+  static __device__ __forceinline__ int load_slots(const int32_t* idx, int base, int s0, int s1) {
+    int tok = base + (int)(threadIdx.x & 63);
+    tok = tok < s1 ? tok : s0;
+    return idx[tok];
+  }
+
+  // rows of the tile that starts `off` tokens into the 64 tokens whose slots are held in `slots`
   static __device__ __forceinline__ void fetch(Rows& r, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
-                                               int64_t v_stride_n, const int32_t* idx, int t0, int s0, int s1) {
+                                               int64_t v_stride_n, int slots, int off) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, chunk = lane & 15;  // chunk: 16-byte piece of the row this lane fetches
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      int tok = t0 + 4 * i + g;
-      tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
-      const int64_t slot = idx[tok];
+      const int64_t slot = __shfl(slots, off + 4 * i + g, 64);
       r.k[i] = *reinterpret_cast<const int4v*>(kbase + slot * k_stride_n + chunk * 8);
       r.v[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
     }
@@ -342,12 +368,22 @@ struct WaveAttn {
   __device__ __forceinline__ void run(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
                                       int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
                                       float sm_scale, float logit_cap) {
-    if (s1 > s0) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
-    for (int t0 = s0; t0 < s1; t0 += kTile) {
+    if (s1 <= s0) return;
+    int slots = load_slots(idx, s0, s0, s1);
+    int slots_next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
+    fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
+    for (int t0 = s0; t0 < s1; t0 += 2 * kTile) {
       park(rows, kl, vl);
-      if (t0 + kTile < s1)  // next tile's rows fly while this one is multiplied
-        fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, t0 + kTile, s0, s1);
+      if (t0 + kTile < s1) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots, kTile);  // flies during the step
       step(kl, vl, t0, s1, true, sm_scale, logit_cap);
+      if (t0 + kTile >= s1) break;
+      park(rows, kl, vl);
+      slots = slots_next;
+      if (t0 + 2 * kTile < s1) {
+        fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
+        if (t0 + 4 * kTile < s1) slots_next = load_slots(idx, t0 + 4 * kTile, s0, s1);
+      }
+      step(kl, vl, t0 + kTile, s1, true, sm_scale, logit_cap);
     }
   }
 
@@ -356,17 +392,141 @@ struct WaveAttn {
   __device__ __forceinline__ void run2(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
                                        int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
                                        float sm_scale, float logit_cap) {
+    if (s1 <= s0) return;
     Rows other;
-    if (s1 > s0) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, s0, s0, s1);
-    if (s1 > s0 + kTile) fetch(other, kbase, vbase, k_stride_n, v_stride_n, idx, s0 + kTile, s0, s1);
+    int slots = load_slots(idx, s0, s0, s1);
+    int slots_next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
+    fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
+    if (s0 + kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, slots, kTile);
     for (int t0 = s0; t0 < s1; t0 += 2 * kTile) {
+      const bool more = t0 + 2 * kTile < s1;  // another pair of tiles follows: its slots are in slots_next
       park(rows, kl, vl);
-      if (t0 + 2 * kTile < s1) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, idx, t0 + 2 * kTile, s0, s1);
+      if (more) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots_next, 0);
       step(kl, vl, t0, s1, true, sm_scale, logit_cap);
       if (t0 + kTile >= s1) break;
       park(other, kl, vl);
-      if (t0 + 3 * kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, idx, t0 + 3 * kTile, s0, s1);
+      if (t0 + 3 * kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, slots_next, kTile);
+      if (t0 + 4 * kTile < s1) slots_next = load_slots(idx, t0 + 4 * kTile, s0, s1);
       step(kl, vl, t0 + kTile, s1, true, sm_scale, logit_cap);
+    }
+  }
+
+  // ---- K straight into operand registers -------------------------------------------------------------------
+  // The K operand of S^T = K . Q^T is K-contiguous per lane: lane (hl, g) of half hh and k-step ks needs elements
+  // 32 ks + 8 g .. + 8 of token 16 hh + hl, 16 contiguous bytes of that token's pool row.  So K needs no LDS at all;
+  // only V (contracted over tokens, stored along the head dimension) goes through an LDS tile for its transposed
+  // reads.  A wave then owns 8 KiB of LDS instead of 16.
+  struct RowsKD {
+    short8 k[2][4];  // operand of half hh, k-step ks
+    int4v v[8];      // rows 4i + g on their way to the V tile
+  };
+
+  static __device__ __forceinline__ void fetch_kd(RowsKD& r, const uint16_t* kbase, const uint16_t* vbase,
+                                                  int64_t k_stride_n, int64_t v_stride_n, int slots, int off) {
+    const int lane = threadIdx.x & 63;
+    const int hl = lane & 15, g = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int64_t slot = __shfl(slots, off + 16 * hh + hl, 64);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        r.k[hh][ks] = *reinterpret_cast<const short8*>(kbase + slot * k_stride_n + 32 * ks + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t slot = __shfl(slots, off + 4 * i + g, 64);
+      r.v[i] = *reinterpret_cast<const int4v*>(vbase + slot * v_stride_n + chunk * 8);
+    }
+  }
+
+  static __device__ __forceinline__ void park_v(const RowsKD& r, char* vl) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<int4v*>(vl + v_off(4 * i + g, chunk * 16)) = r.v[i];
+  }
+
+  // step() with the K operands taken from r (must be called before r is refilled)
+  __device__ __forceinline__ float4v score_half(const RowsKD& r, int hh) const {
+    float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) acc = Mfma16<T>::mma(r.k[hh][ks], qf[ks], acc);
+    return acc;
+  }
+
+  // softmax + O update from the two score halves and the parked V tile
+  __device__ __forceinline__ void finish_step(const float4v (&sacc)[2], const char* vl, int t0, int s1, bool col_ok,
+                                              float sm_scale, float logit_cap) {
+    const int lane = threadIdx.x & 63;
+    const int hl = lane & 15, g = lane >> 4;
+    const float LOG2E = 1.4426950408889634f;
+    const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+    float sv[8];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = sacc[hh][r] * qk_scale;
+        if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap) * LOG2E;
+        const int tok = t0 + 16 * hh + 4 * g + r;
+        s = (col_ok && tok < s1) ? s : -INFINITY;
+        sv[hh * 4 + r] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m, tmax);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // nothing seen yet: everything stays at zero
+    const float alpha = exp2f(m - m_use);
+    m = m_new;
+    float psum = 0.f;
+    short8 pf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float p = exp2f(sv[j] - m_use);
+      psum += p;
+      pf[j] = (short)Conv<T>::from_f32(p);
+    }
+    lsum = lsum * alpha + psum;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int byte_in_row = 32 * n + 8 * (hl & 3);
+      const short4v lo = lds_read_tr16(vl + v_off(4 * g + (hl >> 2), byte_in_row));
+      const short4v hi = lds_read_tr16(vl + v_off(16 + 4 * g + (hl >> 2), byte_in_row));
+      const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
+    }
+  }
+
+  // Stream tokens [s0, s1) of the slot list idx with K straight into registers and V through the 8 KiB tile at vl.
+  __device__ __forceinline__ void run_kd(char* vl, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                         int64_t v_stride_n, const int32_t* idx, int s0, int s1, float sm_scale,
+                                         float logit_cap) {
+    if (s1 <= s0) return;
+    RowsKD r;
+    int slots = load_slots(idx, s0, s0, s1);
+    int slots_next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
+    fetch_kd(r, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
+    int off = 0;
+    for (int t0 = s0; t0 < s1; t0 += kTile) {
+      park_v(r, vl);
+      float4v sacc[2];
+      sacc[0] = score_half(r, 0);
+      sacc[1] = score_half(r, 1);
+      // the next tile's rows fly while this one is finished
+      off += kTile;
+      if (off == 2 * kTile) {
+        off = 0;
+        slots = slots_next;
+      }
+      if (t0 + kTile < s1) {
+        fetch_kd(r, kbase, vbase, k_stride_n, v_stride_n, slots, off);
+        if (off == 0 && t0 + 3 * kTile < s1) slots_next = load_slots(idx, t0 + 3 * kTile, s0, s1);
+      }
+      finish_step(sacc, vl, t0, s1, true, sm_scale, logit_cap);
     }
   }
 
