@@ -379,6 +379,14 @@ SGLK_API int sglk_decode_attention_shared_prefix_xs(
 SGLK_API int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N,
                                 int K, int64_t x_stride, int64_t w_stride, int64_t out_stride,
                                 int dtype, void* stream);
+/* The same product on a weight re-laid-out once at load time for sequential streaming (every wave instruction
+ * reads 1 KiB of consecutive memory): packed = [N / 16][K / 128][4][64 lanes][16 bytes], same byte count as w.
+ * For weights that are read whole at every step and never through any other kernel (the lm_head:
+ * python/sglang/srt/layers/vocab_parallel_embedding.py ParallelLMHead -> logits_processor.py _get_logits).
+ * N % 16 == 0, K % 128 == 0.  No counterpart in the reference, which hands the row-major weight to a library GEMM. */
+SGLK_API int sglk_dense_repack(const void* w, void* packed, int N, int K, int64_t w_stride, void* stream);
+SGLK_API int sglk_dense_gemm_packed(const void* x, const void* packed, const void* bias, void* out, int M, int N,
+                                    int K, int64_t x_stride, int64_t out_stride, int dtype, void* stream);
 /* The same product with a scratch buffer (sglk_dense_gemm_workspace_bytes(), contents don't matter): narrow
  * outputs (the decoder-layer projections of the bf16 configuration) are split along K over enough blocks to fill
  * the chip, fp32 partials summed in split order by a second launch.  Falls back to the form above when the

@@ -4,6 +4,12 @@
 // cover 64 contiguous bytes, so one instruction touches one cache line per row; no LDS round trip
 // for the operand that is read once), while the activations, which every wave
 // re-reads, are staged through an XOR-swizzled LDS tile shared by the block.
+//
+// Weight layouts.  Row-major [N, K] (the reference's): an instruction touches 16 rows, K * 2 bytes apart, 64 bytes
+// each.  Packed (sglk_dense_repack, once at load time): [N / 16 strips][K / 128 k-blocks][4 k-steps][64 lanes]
+// [16 bytes], i.e. every instruction of a wave reads 1 KiB of consecutive memory and a wave walks its strip as one
+// sequential stream -- the row-major form leaves a fifth of the HBM bandwidth unused on the lm_head (rows 8 KiB
+// apart fall on few channels at a time).
 #include <algorithm>
 #include <cstdlib>
 
@@ -31,7 +37,7 @@ struct DenseMma<f16_t> {
 static constexpr int kDenseXTile = 64 * 256;
 __device__ __forceinline__ int dx_off(int r, int c) { return r * 256 + ((c ^ (r & 15)) << 4); }
 
-template <typename T, int NS, int PF>
+template <typename T, int NS, int PF, bool PACKED = false>
 __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* __restrict__ x,
                                                                const uint16_t* __restrict__ w,
                                                                const uint16_t* __restrict__ bias,
@@ -65,12 +71,24 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
   };
 
   // lane (i16, g) owns the 16-byte chunks g, 4+g, 8+g, 12+g of its weight row in every 128-k block
+  // packed: strip-major, 2048 elements (4 KiB) per (strip, k-block), 512 per k-step, 8 per lane
   const uint16_t* wsrc[NS];
+  constexpr int kbs = PACKED ? 2048 : 128;  // elements from one k-block to the next
+  constexpr int cs = PACKED ? 512 : 32;     // ... from one k-step to the next
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     const int n = n0 + 16 * s;
-    wsrc[s] = w + (int64_t)(n < N ? n : 0) * w_stride + 128 * (int64_t)kb0 + 8 * g;
+    if (PACKED) {
+      const int strip = min(n >> 4, (N >> 4) - 1);
+      wsrc[s] = w + ((int64_t)strip * kblocks + kb0) * 2048 + 8 * lane;
+    } else {
+      wsrc[s] = w + (int64_t)(n < N ? n : 0) * w_stride + 128 * (int64_t)kb0 + 8 * g;
+    }
   }
+  // packed weights are read once, whole lines at a time: non-temporal; row-major lines are shared by four loads
+  auto wload = [](const uint16_t* p) {
+    return PACKED ? __builtin_nontemporal_load(reinterpret_cast<const int4v*>(p)) : *reinterpret_cast<const int4v*>(p);
+  };
   int4v wq[PF][NS][4];
 #pragma unroll
   for (int p = 0; p < PF; ++p)
@@ -78,7 +96,8 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) wq[p][s][c] = *reinterpret_cast<const int4v*>(wsrc[s] + 128 * p + 32 * c);
+        for (int c = 0; c < 4; ++c)
+          wq[p][s][c] = wload(wsrc[s] + kbs * p + cs * c);
     }
 
   float4v oacc[NS][4];
@@ -115,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
           for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              wq[p][s][c] = *reinterpret_cast<const int4v*>(wsrc[s] + 128 * (int64_t)(j + PF) + 32 * c);
+              wq[p][s][c] = wload(wsrc[s] + kbs * (int64_t)(j + PF) + cs * c);
         }
         if (j + 1 < nkb) x_park(xreg[(p + 1) & 1], buf ^ 1);
         __syncthreads();
@@ -179,6 +198,20 @@ __global__ void __launch_bounds__(256) dense_reduce_kernel(const float* __restri
   *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + n) = o;
 }
 
+// row-major [N, K] -> packed: 16-byte piece (strip, kb, c, lane = 16 g + i16) = w[16 strip + i16][128 kb + 32 c + 8 g ..]
+__global__ void __launch_bounds__(256) dense_repack_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ packed,
+                                                           int N, int K, int64_t w_stride) {
+  const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kblocks = K / 128;
+  if (piece >= (int64_t)(N / 16) * kblocks * 256) return;
+  const int lane = (int)(piece & 63), c = (int)((piece >> 6) & 3);
+  const int64_t sk = piece >> 8;
+  const int kb = (int)(sk % kblocks), strip = (int)(sk / kblocks);
+  const int i16 = lane & 15, g = lane >> 4;
+  *reinterpret_cast<int4v*>(packed + piece * 8) =
+      *reinterpret_cast<const int4v*>(w + (int64_t)(16 * strip + i16) * w_stride + 128 * kb + 32 * c + 8 * g);
+}
+
 // K-splits of the two-launch form: enough blocks to cover the chip about twice, at least 512 of k per block
 static int dense_splits(int M, int N, int K) {
   const char* env = getenv("SGLK_DENSE_SPLITS");
@@ -233,6 +266,43 @@ int sglk_dense_gemm_nt_ws(const void* x, const void* w, const void* bias, void* 
                        (const float*)workspace, (const uint16_t*)bias, (uint16_t*)out, M, mblocks * 64, N, used,
                        out_stride);
   });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_dense_repack(const void* w, void* packed, int N, int K, int64_t w_stride, void* stream) {
+  SGLK_CHECK(w && packed, "dense_repack: null pointer");
+  SGLK_CHECK(N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0, "dense_repack: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(w) && aligned16(packed) && w_stride % 8 == 0, "dense_repack: rows must be 16-byte aligned");
+  const int64_t pieces = (int64_t)(N / 16) * (K / 128) * 256;
+  hipLaunchKernelGGL(dense_repack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)w, (uint16_t*)packed, N, K, w_stride);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_dense_gemm_packed(const void* x, const void* packed, const void* bias, void* out, int M, int N, int K,
+                           int64_t x_stride, int64_t out_stride, int dtype, void* stream) {
+  SGLK_CHECK(x && packed && out, "dense_gemm_packed: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0, "dense_gemm_packed: bad shape");
+  SGLK_CHECK(N % 16 == 0 && K % 128 == 0, "dense_gemm_packed: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(x) && aligned16(packed) && x_stride % 8 == 0, "dense_gemm_packed: rows must be 16-byte aligned");
+  const int mblocks = (M + 63) / 64;
+  if (N >= 16 * 1024) {
+    dim3 grid((N + 127) / 128, 1, mblocks);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 2, 2, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                                          (const uint16_t*)x, (const uint16_t*)packed, (const uint16_t*)bias,
+                                          (uint16_t*)out, (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride,
+                                          (int64_t)0, out_stride));
+  } else {
+    dim3 grid((N + 63) / 64, 1, mblocks);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 1, 4, true>), grid, dim3(256), 0, (hipStream_t)stream,
+                                          (const uint16_t*)x, (const uint16_t*)packed, (const uint16_t*)bias,
+                                          (uint16_t*)out, (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride,
+                                          (int64_t)0, out_stride));
+  }
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

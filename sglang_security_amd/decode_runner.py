@@ -88,9 +88,18 @@ class _DenseLinear:
     def __init__(self, K, N, dtype, device, gen):
         self.K, self.N = K, N
         self.weight = (torch.randn(N, K, device=device, generator=gen) / math.sqrt(K)).to(dtype)
+        self.wpacked = None  # the weight in the sequential-streaming layout, once pack() has run
+
+    def pack(self):
+        """Re-lay the weight out for sequential streaming (the lm_head: read whole at every step) and drop the
+        row-major copy."""
+        if self.wpacked is None and self.N % 16 == 0 and self.K % 128 == 0:
+            self.wpacked = ops.dense_repack(self.weight)
+            self.weight = None
+        return self
 
     def bytes(self):
-        return self.weight.numel() * 2
+        return (self.weight if self.weight is not None else self.wpacked).numel() * 2
 
 
 class LlamaDecoder:
@@ -110,7 +119,7 @@ class LlamaDecoder:
             return _DenseLinear(K, N, dtype, device, gen)
 
         self.embed = (torch.randn(c.vocab, c.hidden, device=device, generator=gen) * 0.5).to(dtype)
-        self.lm_head = _DenseLinear(c.hidden, c.vocab, dtype, device, gen)
+        self.lm_head = _DenseLinear(c.hidden, c.vocab, dtype, device, gen).pack()
         self.final_norm = torch.ones(c.hidden, dtype=dtype, device=device)
         self.layers = []
         for _ in range(c.layers):
@@ -345,8 +354,14 @@ class LlamaDecoder:
             ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])
         else:
             ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps)
-        ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
+        self._lm_head()
         self._sample()
+
+    def _lm_head(self):
+        if self.lm_head.wpacked is not None:
+            ops.dense_gemm_packed(self.hidden, self.lm_head.wpacked, None, self.logits)
+        else:
+            ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
 
     def _xq(self, K):
         return self.x_q.view(-1)[: self.B * K].view(self.B, K)
@@ -393,7 +408,7 @@ class LlamaDecoder:
             if tp is not None:
                 self._tp_sum()
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)
-        ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
+        self._lm_head()
         self._sample()
 
     def step(self):
@@ -425,7 +440,7 @@ class LlamaDecoder:
             ops.act_and_mul(self.act, self.gate_up, 0)
             self._row_parallel("down", L["down"], self.act)
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)
-        ops.dense_gemm_nt(self.hidden, self.lm_head.weight, None, self.logits)
+        self._lm_head()
         self._sample()
 
     def enable_tp(self, group) -> None:

@@ -371,6 +371,29 @@ def awq_gemm(x, packed, scales, qzeros, bias=None, out=None, workspace=None):
     return out
 
 
+def dense_repack(w):
+    """[N, K] row-major 16-bit weight -> the streaming layout dense_gemm_packed reads (same shape and bytes)."""
+    _need_gpu(w)
+    N, K = w.shape
+    packed = torch.empty(N, K, dtype=w.dtype, device=w.device)
+    check(lib().sglk_dense_repack(_ptr(w), _ptr(packed), N, K, w.stride(0), _stream(w)), "dense_repack")
+    return packed
+
+
+def dense_gemm_packed(x, packed, bias=None, out=None):
+    """x:[M,K] @ W^T for a weight laid out by dense_repack ([N, K] in shape, not in meaning)."""
+    _need_gpu(x, packed)
+    M, K = x.shape
+    N = packed.shape[0]
+    if packed.shape[1] != K or not packed.is_contiguous():
+        raise SglkError("dense_gemm_packed: the packed weight must be a contiguous [N, K] tensor from dense_repack")
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    check(lib().sglk_dense_gemm_packed(_ptr(x), _ptr(packed), _ptr(bias), _ptr(out), M, N, K, x.stride(0), out.stride(0),
+                                       dtype_code(x.dtype), _stream(x)), "dense_gemm_packed")
+    return out
+
+
 def dense_gemm_workspace_bytes(M, N, K) -> int:
     return int(lib().sglk_dense_gemm_workspace_bytes(M, N, K))
 

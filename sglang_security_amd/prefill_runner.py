@@ -161,7 +161,11 @@ class LlamaPrefill:
         h = hidden[last_row: last_row + 1].clone()
         r = residual[last_row: last_row + 1].clone()
         ops.fused_add_rmsnorm(h, r, self.dec.final_norm, c.eps)
-        torch.matmul(h, self.dec.lm_head.weight.t(), out=self.logits)
+        lm = self.dec.lm_head
+        if lm.wpacked is not None:
+            ops.dense_gemm_packed(h, lm.wpacked, None, self.logits)
+        else:
+            ops.dense_gemm_nt(h, lm.weight, None, self.logits)
         ops.argmax(self.logits, self.next_id)
         return self.next_id
 

@@ -147,6 +147,35 @@ def test_dense_gemm_nt(M, K, N, dtype, strips, monkeypatch):
     _gemm_close(out, want, dtype)
 
 
+@pytest.mark.parametrize("M,K,N,bias", [(64, 512, 256, False), (3, 1024, 96, True), (64, 4096, 16384, True), (64, 4096, 32064, False)])
+def test_dense_gemm_packed(M, K, N, bias):
+    """The sequential-streaming weight layout: same product, bit for bit, as the row-major kernel of the same shape
+    (same accumulation order), and the oracle's on sampled rows."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(K + N)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.03).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16) if bias else None
+    wd, bd = w.to(DEV), (b.to(DEV) if bias else None)
+    packed = ops.dense_repack(wd)
+    assert packed.shape == wd.shape and not torch.equal(packed, wd)
+    got = ops.dense_gemm_packed(x.to(DEV), packed, bd)
+    import os
+    os.environ["SGLK_DENSE_NS"] = "2" if N >= 16 * 1024 else "1"
+    try:
+        ref = ops.dense_gemm_nt(x.to(DEV), wd, bd)
+    finally:
+        os.environ.pop("SGLK_DENSE_NS", None)
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    rows = torch.arange(0, M, max(M // 4, 1))
+    want = oracle.half_matmul(x[rows], w.t().contiguous()).float()
+    if bias:
+        want = (want + b.float()).to(torch.bfloat16).float()
+    _gemm_close(got.float().cpu()[rows], want, torch.bfloat16)
+
+
 @pytest.mark.parametrize("M,K,N,bias", [(64, 4096, 4096, False), (64, 14336, 4096, True), (7, 4096, 6144, False),
                                         (130, 1024, 512, True), (64, 512, 28672, False)])
 def test_dense_gemm_nt_split_k(M, K, N, bias):

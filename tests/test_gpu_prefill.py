@@ -22,6 +22,10 @@ def _weight(w):
 
     if hasattr(w, "packed"):
         return ops.awq_dequantize_packed(w.packed, w.scales, w.qzeros).float()
+    if getattr(w, "wpacked", None) is not None:
+        # the streaming layout read back through the product with the identity (exact in 16 bits)
+        eye = torch.eye(w.K, dtype=w.wpacked.dtype, device=w.wpacked.device)
+        return ops.dense_gemm_packed(eye, w.wpacked).float()
     return w.weight.t().float()
 
 

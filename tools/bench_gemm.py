@@ -19,6 +19,7 @@ ap.add_argument("--copies", type=int, default=0, help="weight copies to rotate o
 ap.add_argument("--eager", action="store_true", help="plain launches, no graph (counter collection)")
 ap.add_argument("--fused", action="store_true", help="the forms the fused decode step launches: fp32 split-K partials with the "
                 "producer's block sums (qkv, o, down) and the gated-activation epilogue (gate_up)")
+ap.add_argument("--packed", action="store_true", help="with --dense: the sequential-streaming weight layout")
 ap.add_argument("--stamps", action="store_true", help="per-phase clock stamps of the wide AWQ kernel (run with SGLK_AWQ_ABL=16)")
 args = ap.parse_args()
 dev = "cuda"
@@ -35,7 +36,9 @@ for name, K, N in shapes:
     ws = []
     for _ in range(copies):
         if args.dense:
-            ws.append(((torch.randn(N, K, device=dev, generator=gen) * 0.02).to(torch.bfloat16),))
+            wt = (torch.randn(N, K, device=dev, generator=gen) * 0.02).to(torch.bfloat16)
+            ws.append((ops.dense_repack(wt) if args.packed and N % 16 == 0 else wt,))
+            del wt
         else:
             qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=dev, generator=gen)
             qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // 128, N // 8), dtype=torch.int32, device=dev, generator=gen)
@@ -58,6 +61,8 @@ for name, K, N in shapes:
             ops.awq_gemm_silu_mul(x, w[0], w[1], w[2], act, xs, xs_out)
         elif args.fused:
             ops.awq_gemm_partial(x, w[0], w[1], w[2], part, xs)
+        elif args.dense and args.packed:
+            ops.dense_gemm_packed(x, w[0], None, out)
         elif args.dense:
             ops.dense_gemm_nt(x, w[0], None, out, work)
         else:
