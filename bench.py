@@ -36,8 +36,10 @@ def parse():
     ap.add_argument("--prefix", type=int, default=1024)
     ap.add_argument("--suffix", type=int, default=128)
     ap.add_argument("--quant", default="awq", choices=["awq", "bf16", "fp8"])
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8-rank"],
-                    help="llama3-70b-tp8-rank: one rank's shard of Llama-3-70B under TP=8 (no all-reduce on one GPU)")
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8-rank", "qwen2-0.5b"],
+                    help="llama3-70b-tp8-rank: one rank's shard of Llama-3-70B under TP=8 (no all-reduce on one GPU); "
+                         "qwen2-0.5b: the reference's CPU-runnable plumbing case, use with --quant bf16 --batch 1 "
+                         "--prefix 0 --suffix 128 (head size 64: the generic attention kernels)")
     ap.add_argument("--tp", action="store_true",
                     help="the ranks form ONE tensor-parallel group (use with --model llama3-70b-tp8-rank --gpus 8): "
                          "peer-to-peer all-reduce after o / down, value = tokens/s of the one sharded model")
@@ -285,12 +287,14 @@ def main():
         cfg = LlamaConfig.tiny(args.quant)
     elif args.model == "llama3-70b-tp8-rank":
         cfg = LlamaConfig.llama3_70b_tp8_rank(args.quant)
+    elif args.model == "qwen2-0.5b":
+        cfg = LlamaConfig.qwen2_0_5b(args.quant)
     else:
         cfg = LlamaConfig.llama3_8b(args.quant)
     B = args.batch
     total_steps = args.steps + args.warmup + 8
     per_req = args.suffix + total_steps + 2
-    want_hit = not args.no_prefix_hit and world == 1
+    want_hit = not args.no_prefix_hit and world == 1 and args.prefix > 0
     # pool sized for the variant without sharing too (every request holds its own copy of the prefix)
     slots = 1 + (B * (args.prefix + per_req) if want_hit else args.prefix + B * per_req)
     max_ctx = args.prefix + per_req
@@ -320,7 +324,7 @@ def main():
     wdesc = {"awq": "awq (int4 weights, G=128; bf16 activations and KV)",
              "bf16": "bf16 (bf16 weights, activations and KV)",
              "fp8": "fp8 (e4m3 weights with per-channel scales, per-token e4m3 activations; bf16 KV)"}[cfg.quant]
-    mname = ("Llama-3-8B" if args.model == "llama3-8b"
+    mname = ("Llama-3-8B" if args.model == "llama3-8b" else "Qwen2-0.5B" if args.model == "qwen2-0.5b"
              else f"Llama-3-70B TP={world}" if tp else "Llama-3-70B TP=8 rank shard (no all-reduce)")
     out = {
         "metric": f"decode tokens/s (whole job), {mname} {wname}, batch {B}/GPU, {args.prefix}-token shared prefix",

@@ -33,6 +33,7 @@ class LlamaConfig:
     eps: float = 1e-5
     group_size: int = 128
     quant: str = "awq"  # "awq" (int4), "bf16" or "fp8" (w8a8: per-channel weight scales, per-token activation scales)
+    qkv_bias: bool = False  # Qwen2: the fused q/k/v projection carries a bias (models/qwen2.py:133-139)
 
     @staticmethod
     def llama3_8b(quant="awq"):
@@ -44,6 +45,18 @@ class LlamaConfig:
         o/down row-sharded, vocab-parallel lm_head): 8 of 64 query heads, 1 of 8 kv heads, 28672/8 MLP columns."""
         return LlamaConfig(hidden=8192, layers=80, q_heads=8, kv_heads=1, head_dim=128, inter=3584, vocab=128256 // 8,
                            quant=quant)
+
+    @staticmethod
+    def qwen2_0_5b(quant="bf16"):
+        """Qwen2-0.5B (models/qwen2.py; config.json of Qwen/Qwen2-0.5B): 24 layers, hidden 896, 14 query / 2 kv heads of
+        64, MLP 4864, vocabulary 151936, rope base 1e6, rms eps 1e-6, bias on q/k/v only."""
+        return LlamaConfig(hidden=896, layers=24, q_heads=14, kv_heads=2, head_dim=64, inter=4864, vocab=151936,
+                           rope_theta=1000000.0, max_pos=32768, eps=1e-6, quant=quant, qkv_bias=True)
+
+    @staticmethod
+    def tiny_qwen(quant="bf16"):
+        return LlamaConfig(hidden=384, layers=2, q_heads=6, kv_heads=2, head_dim=64, inter=512, vocab=512, max_pos=2048,
+                           eps=1e-6, quant=quant, qkv_bias=True)
 
     @staticmethod
     def tiny(quant="awq"):
@@ -130,6 +143,8 @@ class LlamaDecoder:
                 o=lin(self.q_size, c.hidden),
                 gate_up=lin(c.hidden, 2 * c.inter, keep=True),  # kept until the fused layout has been derived
                 down=lin(c.inter, c.hidden),
+                qkv_bias=((0.1 * torch.randn(self.q_size + 2 * self.kv_size, device=device, generator=gen)).to(dtype)
+                          if c.qkv_bias else None),
             ))
         # rotary cache, layout of RotaryEmbedding._compute_cos_sin_cache (layers/rotary_embedding.py)
         inv = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float32, device=device) / c.head_dim))
@@ -220,16 +235,16 @@ class LlamaDecoder:
         self.prefix_len = prefix_len if share else 0
 
     # ---- one decode step ------------------------------------------------------------------------------
-    def _linear(self, name, w, x, out):
+    def _linear(self, name, w, x, out, bias=None):
         def run():
             if isinstance(w, _AwqLinear):
-                ops.awq_gemm(x, w.packed, w.scales, w.qzeros, None, out, self.workspace)
+                ops.awq_gemm(x, w.packed, w.scales, w.qzeros, bias, out, self.workspace)
             elif isinstance(w, _Fp8Linear):
                 xq = self.x_q.view(-1)[:x.shape[0] * w.K].view(x.shape[0], w.K)
                 ops.per_token_quant_fp8(x, xq, self.x_s)
-                ops.fp8_scaled_mm(xq, w.weight.t(), self.x_s, w.scale, self.dtype, None, out, self.workspace)
+                ops.fp8_scaled_mm(xq, w.weight.t(), self.x_s, w.scale, self.dtype, bias, out, self.workspace)
             else:
-                ops.dense_gemm_nt(x, w.weight, None, out, self.workspace)
+                ops.dense_gemm_nt(x, w.weight, bias, out, self.workspace)
 
         if self.gemm_timer is not None:
             self.gemm_timer(name, run)
@@ -246,7 +261,8 @@ class LlamaDecoder:
     def enable_fusion(self, on: bool = True) -> bool:
         """Decoder-layer fusion (AWQ, 16-bit, head size 128, shapes the partial GEMM covers)."""
         c = self.cfg
-        ok = on and c.quant == "awq" and c.head_dim == 128 and c.hidden % 128 == 0 and c.inter % 128 == 0
+        ok = (on and c.quant == "awq" and c.head_dim == 128 and c.hidden % 128 == 0 and c.inter % 128 == 0
+              and not c.qkv_bias)
         if ok:
             shapes = {"qkv": (c.hidden, self.q_size + 2 * self.kv_size), "o": (self.q_size, c.hidden),
                       "down": (c.inter, c.hidden)}
@@ -414,7 +430,7 @@ class LlamaDecoder:
     def step(self):
         if self.fused:
             return self.step_fused()
-        if self.cfg.quant == "fp8" and getattr(self, "fp8_fold_quant", True):
+        if self.cfg.quant == "fp8" and getattr(self, "fp8_fold_quant", True) and not self.cfg.qkv_bias:
             return self.step_fp8()
         c = self.cfg
         self.prepare_for_decode()
@@ -430,7 +446,7 @@ class LlamaDecoder:
                 ops.rmsnorm(self.hidden, self.hidden, L["ln1"], c.eps)
             else:
                 ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln1"], c.eps)
-            self._linear("qkv", L["qkv"], self.hidden, self.qkv)
+            self._linear("qkv", L["qkv"], self.hidden, self.qkv, L["qkv_bias"])
             ops.rope_and_store_kv(self.qkv, self.cos_sin, self.positions, self.k_pool[li], self.v_pool[li],
                                   self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
             self.attention(li, q_view, o_view, sm_scale)
