@@ -36,10 +36,12 @@ def parse():
     ap.add_argument("--prefix", type=int, default=1024)
     ap.add_argument("--suffix", type=int, default=128)
     ap.add_argument("--quant", default="awq", choices=["awq", "bf16", "fp8"])
-    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8-rank", "qwen2-0.5b"],
+    ap.add_argument("--model", default="llama3-8b", choices=["llama3-8b", "llama3-70b-tp8-rank", "qwen2-0.5b", "deepseek-v3-dense"],
                     help="llama3-70b-tp8-rank: one rank's shard of Llama-3-70B under TP=8 (no all-reduce on one GPU); "
                          "qwen2-0.5b: the reference's CPU-runnable plumbing case, use with --quant bf16 --batch 1 "
-                         "--prefix 0 --suffix 128 (head size 64: the generic attention kernels)")
+                         "--prefix 0 --suffix 128 (head size 64: the generic attention kernels); deepseek-v3-dense: "
+                         "the three dense layers of DeepSeek-V3 (absorbed MLA over a latent KV pool + block-fp8 "
+                         "projections), a layer-stack workload, not a whole model")
     ap.add_argument("--tp", action="store_true",
                     help="the ranks form ONE tensor-parallel group (use with --model llama3-70b-tp8-rank --gpus 8): "
                          "peer-to-peer all-reduce after o / down, value = tokens/s of the one sharded model")
@@ -224,6 +226,78 @@ def pmc_traffic(cfg, B):
     return None
 
 
+def deepseek_dense_workload(args, dev, world):
+    """BASELINE configuration 5's layer type: DeepSeek-V3 dense layers (absorbed MLA + block fp8) on a shared-prefix
+    batch.  One step = the three layers on `batch` new tokens; the line says so (this is not a whole-model rate)."""
+    from sglang_security_amd import ops
+    from sglang_security_amd.benchlib import aggregate, dist_helpers, timed_steps
+    from sglang_security_amd.mla_runner import DeepseekV3Config, DeepseekV3DenseDecoder
+
+    cfg = DeepseekV3Config.tiny() if args.tiny else DeepseekV3Config.deepseek_v3()
+    B = args.batch
+    per_req = args.suffix + args.steps + args.warmup + 10
+    dec = DeepseekV3DenseDecoder(cfg, B, 1 + args.prefix + B * per_req, args.prefix + per_req, device=dev,
+                                 max_kv_splits=args.kv_splits)
+    dec.cu_count = torch.cuda.get_device_properties(dev).multi_processor_count
+    dec.setup_shared_prefix_batch(args.prefix, args.suffix)
+    x_in = dec.hidden.clone()
+    stream = torch.cuda.Stream(dev)
+    barrier, mx = dist_helpers(world, dev)
+    with torch.cuda.stream(stream):
+        for _ in range(2):
+            dec.step(x_in)
+        stream.synchronize()
+        graph = None
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                dec.step(x_in)
+        run = graph.replay if graph is not None else (lambda: dec.step(x_in))
+        elapsed = timed_steps(run, args.steps, max(args.warmup - 2, 0), torch.cuda.synchronize, barrier, mx)
+        # dominant kernel: the block-fp8 GEMM, every projection of every layer launched back to back between events
+        per = {}
+        for name, K in (("qkv_a", cfg.hidden), ("q_b", cfg.q_lora_rank), ("o", cfg.heads * cfg.v_head_dim),
+                        ("gate_up", cfg.hidden), ("down", cfg.inter)):
+            xq, xs = dec._quant(torch.randn(B, K, device=dev).to(torch.bfloat16))
+            ts = []
+            for _ in range(3):
+                torch.cuda._sleep(int(5e-3 * 2.0e9))
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                for L in dec.layers:
+                    w = L[name]
+                    ops.fp8_blockwise_scaled_mm(xq, w.weight.t(), xs, w.scale.t(), torch.bfloat16, dec.workspace)
+                b.record(stream)
+                stream.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3 / cfg.layers)
+            per[name] = sorted(ts)[1]
+    agg = aggregate(B, args.steps, world, elapsed)
+    L0 = dec.layers[0]
+    gemm_bytes = sum(L0[k].bytes() + B * (L0[k].K + 2 * L0[k].N) for k in per)   # weights + fp8 in + bf16 out
+    avg_us = sum(per.values()) / len(per)
+    ach = gemm_bytes / len(per) / (avg_us * 1e-6) / 1e9
+    kv_tok = dec.lat * 2 * cfg.layers
+    uniq = dec.layer_weight_bytes() * cfg.layers + (args.prefix + B * (args.suffix + args.warmup + args.steps // 2)) * kv_tok
+    return {
+        "metric": f"decode tokens/s through DeepSeek-V3's {cfg.layers} dense layers (absorbed MLA + block fp8), batch {B}/GPU, "
+                  f"{args.prefix}-token shared prefix",
+        "value": round(agg["value"], 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(agg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "fp8", "data": "synthetic",
+        "config": {"workload": f"DeepSeek-V3 dense decoder layers x{cfg.layers} (hidden {cfg.hidden}, {cfg.heads} heads, latent "
+                               f"KV 512 + 64, MLP {cfg.inter}; e4m3 weights with 128 x 128 block scales, per-group e4m3 "
+                               f"activations, bf16 latent KV), batch {B}/GPU, prefix {args.prefix} shared + {args.suffix} "
+                               "private tokens, random-init weights; a layer stack, not a whole model",
+                   "attention": "per_request (absorbed MLA, 576 / 512)", "graph": graph is not None,
+                   "parallelism": f"replicas x{world}", "layers": cfg.layers},
+        "step_bytes_unique": int(uniq), "step_hbm_frac_of_8TBps": round(uniq / (elapsed / args.steps) / 8e12, 4),
+        "roofline": {"bound": "hbm", "kernel": f"fp8 block-scaled GEMM (M={B}; 5 launches per layer)", "achieved": round(ach, 1),
+                     "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4), "traffic": None,
+                     "avg_launch_us": round(avg_us, 2), "bytes_per_launch": int(gemm_bytes / len(per)),
+                     "per_projection_us": {k: round(v, 2) for k, v in per.items()}},
+    }
+
+
 def extend_ttft(cfg, B, prefix, suffix, dev):
     """Prefix-hit speedup of the extend (prefill) attention of one layer: all prefix + suffix tokens new, against
     only the suffix new over a cached prefix."""
@@ -283,6 +357,15 @@ def main():
     from sglang_security_amd.benchlib import aggregate
     from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
 
+    if args.model == "deepseek-v3-dense":
+        out = deepseek_dense_workload(args, dev, world)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+        return
     if args.tiny:
         cfg = LlamaConfig.tiny(args.quant)
     elif args.model == "llama3-70b-tp8-rank":

@@ -116,3 +116,101 @@ def test_qwen2_0_5b_shape_one_step():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(dec.next_ids, tok_eager)
+
+
+def _q_group(x):
+    """Per-token, per-128-group e4m3 quantisation, as a float tensor (what the block-fp8 linear multiplies)."""
+    M, K = x.shape
+    g = x.float().view(M, K // 128, 128)
+    s = (g.abs().amax(-1, keepdim=True) / 448.0).clamp(min=1e-10)
+    return ((g / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s).view(M, K)
+
+
+def _q_tensor(x):
+    s = x.float().abs().max() / 448.0
+    return (x.float() / s).clamp(-448, 448).to(torch.float8_e4m3fn).float() * s
+
+
+def test_deepseek_v3_dense_layers_match_torch():
+    """Absorbed-MLA + block-fp8 dense layers (BASELINE configuration 5's layer type) against a torch restatement with
+    the same quantisation points (fp32 products of the dequantised operands), two layers, two steps; the latent
+    rows the steps append to the pool must be the restatement's."""
+    from sglang_security_amd.mla_runner import DeepseekV3Config, DeepseekV3DenseDecoder
+
+    cfg = DeepseekV3Config.tiny()
+    B, prefix, suffix = 4, 40, 6
+    dec = DeepseekV3DenseDecoder(cfg, B, pool_slots=1 + prefix + B * 16, max_ctx=64, device=DEV, seed=0)
+    dec.setup_shared_prefix_batch(prefix, suffix)
+    c = cfg
+    H, lat, nope, rd = c.heads, c.kv_lora_rank, c.qk_nope_head_dim, c.qk_rope_head_dim
+
+    def norm(v, w):
+        v = v.float()
+        return _r(v * torch.rsqrt((v * v).mean(-1, keepdim=True) + c.eps) * w.float())
+
+    def rope_il(t, pos):                                    # [B, heads, 64], interleaved pairs
+        cs = dec.cos_sin[pos]
+        cos, sin = cs[:, None, : rd // 2], cs[:, None, rd // 2:]
+        a, b = t[..., 0::2].float(), t[..., 1::2].float()
+        out = torch.empty_like(t, dtype=torch.float32)
+        out[..., 0::2] = a * cos - b * sin
+        out[..., 1::2] = b * cos + a * sin
+        return _r(out)
+
+    def ref_step(x_in, pools, r2t, seq_lens):
+        pos = seq_lens.clone()
+        x, res = x_in.float(), None
+        for li, L in enumerate(dec.layers):
+            res = x if li == 0 else _r(res + x)
+            h = norm(res, L["ln1"])
+            qkv_a = _r(_q_group(h) @ L["qkv_a"].dequant().t())
+            q_a = norm(qkv_a[:, : c.q_lora_rank], L["q_a_ln"])
+            k_nope = norm(qkv_a[:, c.q_lora_rank: c.q_lora_rank + lat], L["kv_a_ln"])
+            k_pe = qkv_a[:, c.q_lora_rank + lat:]
+            q = _r(_q_group(q_a) @ L["q_b"].dequant().t()).view(B, H, nope + rd)
+            w_kc = L["w_kc"].float() * L["w_scale"]
+            w_vc = L["w_vc"].float() * L["w_scale"]
+            q_nope_out = _r(torch.einsum("bhk,hnk->bhn", _q_tensor(q[..., :nope]), w_kc))
+            q_pe = rope_il(q[..., nope:], pos)
+            k_pe = rope_il(k_pe.view(B, 1, rd), pos).view(B, rd)
+            q_in = torch.cat([q_nope_out, q_pe], -1)
+            k_in = torch.cat([k_nope, k_pe], -1)
+            outs = []
+            for b in range(B):
+                slots = r2t[b, : int(seq_lens[b])].long()
+                rows = torch.cat([pools[li][slots, 0].float(), k_in[b: b + 1]], 0)           # [len + 1, 576]
+                s = (q_in[b] @ rows.t()) * dec.sm_scale
+                outs.append(_r(torch.softmax(s, -1) @ rows[:, :lat]))
+                pools[li][int(r2t[b, int(seq_lens[b])]), 0] = k_in[b].to(torch.bfloat16)
+            attn = torch.stack(outs)                                                         # [B, H, 512]
+            o_heads = _r(torch.einsum("bhk,hnk->bhn", _q_tensor(attn), w_vc)).reshape(B, -1)
+            x = _r(_q_group(o_heads) @ L["o"].dequant().t())
+            res = _r(res + x)
+            h = norm(res, L["ln2"])
+            gu = _r(_q_group(h) @ L["gate_up"].dequant().t())
+            act = _r(_r(torch.nn.functional.silu(gu[:, : c.inter])) * gu[:, c.inter:])
+            x = _r(_q_group(act) @ L["down"].dequant().t())
+        return norm(_r(res + x), dec.final_norm)
+
+    pools = [p.clone() for p in dec.kv_pool]
+    r2t = dec.req_to_token.clone()
+    seq = dec.seq_lens.clone()
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for step in range(2):
+        x_in = torch.randn(B, c.hidden, device=DEV, generator=gen).to(torch.bfloat16)
+        want = ref_step(x_in, pools, r2t, seq)
+        seq += 1
+        dec.step(x_in)
+        torch.cuda.synchronize()
+        # the latent rows appended to the pool: layer 0's depend on one quantised product only (tight), the deeper
+        # ones and the output on chains of fp8 roundings, where a one-ulp difference upstream can flip a 3-bit mantissa
+        new_rows = r2t[torch.arange(B), (seq - 1)].long()
+        for li in range(c.layers):
+            a, b_ = dec.kv_pool[li][new_rows, 0].float(), pools[li][new_rows, 0].float()
+            rel_kv = ((a - b_).norm() / b_.norm()).item()
+            assert rel_kv < (1e-2 if li == 0 else 6e-2), (step, li, rel_kv)
+        rel = ((dec.hidden.float() - want).norm() / want.norm()).item()
+        assert rel < 6e-2, (step, rel)
+        cosine = torch.nn.functional.cosine_similarity(dec.hidden.float().flatten(), want.flatten(), dim=0).item()
+        assert cosine > 0.998, (step, cosine)
+    assert dec.seq_lens.tolist() == seq.tolist()
