@@ -379,6 +379,18 @@ SGLK_API int sglk_decode_attention_shared_prefix_xs(
 SGLK_API int sglk_dense_gemm_nt(const void* x, const void* w, const void* bias, void* out, int M, int N,
                                 int K, int64_t x_stride, int64_t w_stride, int64_t out_stride,
                                 int dtype, void* stream);
+/* Large-M (extend / prefill) products, out[M, N] = x[M, K] @ W (+ bias) on 256 x 128 output tiles with
+ * v_mfma_f32_32x32x16 and two LDS stages.  sglk_awq_gemm_prefill dequantises the packed int4 weight on the way into
+ * LDS -- (q - z) * scale rounded to the activation type, i.e. exactly the matrix the reference's
+ * awq_dequantize-then-matmul multiplies by (python/sglang/srt/layers/quantization/awq.py:197-215) -- so no
+ * dequantised copy is written to memory; sglk_dense_gemm_prefill takes a 16-bit weight [N, K].
+ * K % 128 == 0, N % 128 == 0, group_size % 128 == 0. */
+SGLK_API int sglk_awq_gemm_prefill(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros,
+                                   const void* bias, void* out, int M, int N, int K, int group_size,
+                                   int64_t x_stride, int64_t out_stride, int dtype, void* stream);
+SGLK_API int sglk_dense_gemm_prefill(const void* x, const void* w, const void* bias, void* out, int M, int N, int K,
+                                     int64_t x_stride, int64_t w_stride, int64_t out_stride, int dtype,
+                                     void* stream);
 /* The same product on a weight re-laid-out once at load time for sequential streaming (every wave instruction
  * reads 1 KiB of consecutive memory): packed = [N / 16][K / 128][4][64 lanes][16 bytes], same byte count as w.
  * For weights that are read whole at every step and never through any other kernel (the lm_head:

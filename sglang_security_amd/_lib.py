@@ -77,6 +77,8 @@ _SIGS = {
     "sglk_decode_attention_shared_prefix_xs": (i32, [p] * 8 + [i32, p] + [i32] * 6 + [i64] * 8 + [f32, f32, i32, p, i64, p]),
     "sglk_dense_gemm_nt": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_dense_gemm_workspace_bytes": (i64, [i32, i32, i32]),
+    "sglk_awq_gemm_prefill": (i32, [p, p, p, p, p, p, i32, i32, i32, i32, i64, i64, i32, p]),
+    "sglk_dense_gemm_prefill": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_dense_repack": (i32, [p, p, i32, i32, i64, p]),
     "sglk_dense_gemm_packed": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i32, p]),
     "sglk_dense_gemm_nt_ws": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i64, p, i64, i32, p]),

@@ -371,6 +371,31 @@ def awq_gemm(x, packed, scales, qzeros, bias=None, out=None, workspace=None):
     return out
 
 
+def awq_gemm_prefill(x, packed, scales, qzeros, bias=None, out=None):
+    """Large-M x @ W for a packed AWQ weight, dequantised inside the GEMM (K % 128 == 0, N % 128 == 0)."""
+    _need_gpu(x, packed, scales, qzeros)
+    M, K = x.shape
+    N = scales.shape[1]
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    check(lib().sglk_awq_gemm_prefill(_ptr(x), _ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(bias), _ptr(out), M, N, K,
+                                      K // scales.shape[0], x.stride(0), out.stride(0), dtype_code(x.dtype), _stream(x)),
+          "awq_gemm_prefill")
+    return out
+
+
+def dense_gemm_prefill(x, w, bias=None, out=None):
+    """Large-M x:[M,K] @ w:[N,K]^T on the hand-written tile kernel (K % 128 == 0, N % 128 == 0)."""
+    _need_gpu(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    check(lib().sglk_dense_gemm_prefill(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, x.stride(0), w.stride(0),
+                                        out.stride(0), dtype_code(x.dtype), _stream(x)), "dense_gemm_prefill")
+    return out
+
+
 def dense_repack(w):
     """[N, K] row-major 16-bit weight -> the streaming layout dense_gemm_packed reads (same shape and bytes)."""
     _need_gpu(w)

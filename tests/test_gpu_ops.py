@@ -381,3 +381,41 @@ def test_awq_dequantize_packed_matches_reference_layout(K, N, group, dtype):
     want = ops.awq_dequantize(qw, sc, qz)
     got = ops.awq_dequantize_packed(ops.awq_repack(qw), sc, qz)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
+# ---------------------------------------------------------------------------------------------- large-M (prefill) GEMMs
+@pytest.mark.parametrize("M,K,N", [(256, 256, 128), (300, 512, 256), (1152, 1024, 384), (77, 4096, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_awq_gemm_prefill(M, K, N, dtype):
+    """Dequant-fused large-M GEMM: the weights it multiplies by are bit for bit awq_dequantize's, so the product has to
+    agree with the fp32-accumulated matmul on that matrix to accumulation-order noise (ragged last row tile included)."""
+    import oracle
+
+    ops = _ops()
+    x, qw, sc, qz = _awq_case(M, K, N, 128, dtype, seed=M + K + N)
+    packed = ops.awq_repack(qw.to(DEV))
+    got = ops.awq_gemm_prefill(x.to(DEV), packed, sc.to(DEV), qz.to(DEV)).float().cpu()
+    want = oracle.awq_gemm(x, qw, sc, qz).float()
+    tol = 4e-3 if dtype == torch.bfloat16 else 5e-4        # one rounding of the output, no weight-rounding difference
+    torch.testing.assert_close(got, want, atol=tol, rtol=2 * tol)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(1)).to(dtype)
+    gb = ops.awq_gemm_prefill(x.to(DEV), packed, sc.to(DEV), qz.to(DEV), bias.to(DEV)).float().cpu()
+    torch.testing.assert_close(gb, (want + bias.float()).to(dtype).float(), atol=2 * tol, rtol=2 * tol)
+
+
+@pytest.mark.parametrize("M,K,N", [(256, 128, 128), (513, 1024, 256), (1152, 4096, 512)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_dense_gemm_prefill(M, K, N, dtype):
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * (8.0 / math.sqrt(K))).to(dtype)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(dtype)
+    got = ops.dense_gemm_prefill(x.to(DEV), w.to(DEV)).float().cpu()
+    rows = torch.arange(0, M, max(M // 16, 1))
+    want = oracle.half_matmul(x[rows], w.t().contiguous()).float()
+    _gemm_close(got[rows], want, dtype)
+    # against torch's fp32 product everywhere (checks every tile's placement)
+    full = (x.float().to(DEV) @ w.float().to(DEV).t()).cpu()
+    assert (got - full).abs().max().item() <= 1e-2 * max(full.abs().max().item(), 1.0)

@@ -76,13 +76,13 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm()).item()
 
 
-@pytest.mark.parametrize("T", [40, 300])          # below / above the reference's dequantise-then-GEMM switch
-@pytest.mark.parametrize("quant", ["awq", "bf16"])
-def test_extend_matches_torch(T, quant):
+@pytest.mark.parametrize("T,gemm", [(40, "library"), (300, "library"), (300, "fused")])   # below / above the switch to
+@pytest.mark.parametrize("quant", ["awq", "bf16"])                                         # large-batch GEMMs, both kinds
+def test_extend_matches_torch(T, gemm, quant):
     from sglang_security_amd.prefill_runner import PrefixCacheHarness
 
     dec = _tiny(quant)
-    h = PrefixCacheHarness(dec, 4096, 2048, None)
+    h = PrefixCacheHarness(dec, 4096, 2048, None, prefill_gemm=gemm)
     ids = torch.randint(0, dec.cfg.vocab, (T,), generator=torch.Generator().manual_seed(T)).tolist()
     tok, pre, req = h.serve_first_token(ids, "u", finish=False)
     assert pre == 0
