@@ -372,6 +372,22 @@ SGLK_API int sglk_decode_attention_shared_prefix_xs(
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
     int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, float* xsum_out,
     int64_t xs_stride, void* stream);
+/* sglk_rope_and_store_kv_partial folded into sglk_decode_attention_shared_prefix_xs (the reference runs
+ * rotary_embedding, set_kv_buffer and decode_attention_fwd as three ops: models/llama.py:160-190,
+ * layers/radix_attention.py:60-86): the query rows and every request's new K / V row are assembled from the
+ * qkv projection's split-K partial sums inside the attention kernel -- summed in split order, biased, rounded,
+ * rotated, rounded: the bits the separate kernel stores -- the new rows are written to pool slot loc[b], which
+ * must be the last entry of request b's index list, and no rotated q is written anywhere.
+ * Rotation of full 128-element heads in the (d, d + 64) pairing only (rot_dim == 128, interleave == 0), at most
+ * 16 query heads per kv head; SGLK_EUNSUP otherwise. */
+SGLK_API int sglk_decode_attention_shared_prefix_rope(
+    const float* qkv_partials, int splits, int64_t part_stride, const void* qkv_bias,
+    const float* cos_sin_cache, const int64_t* positions, int rot_dim, int interleave, const void* loc,
+    int loc_is64, void* k_buffer, void* v_buffer, void* o, const int32_t* kv_indptr, const int32_t* kv_indices,
+    const int32_t* group_indptr, const int32_t* prefix_lens, int G, float* workspace, int max_kv_splits, int B,
+    int Hq, int Hkv, int D, int Dv, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+    int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype,
+    float* xsum_out, int64_t xs_stride, void* stream);
 
 /* Skinny dense GEMM out[M,N] = x[M,K] @ W[N,K]^T (+bias), bf16/fp16, for the unquantised lm_head and
  * the bf16 configuration (UnquantizedLinearMethod.apply, python/sglang/srt/layers/linear.py:170-186;

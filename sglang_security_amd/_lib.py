@@ -74,6 +74,8 @@ _SIGS = {
     "sglk_act_and_mul_xs": (i32, [p, p, i64, i32, i32, i32, p, i64, p]),
     "sglk_rope_and_store_kv_partial": (i32, [p, p, i32, i64, p, p, p, p, p, p, i32, i64, i32, i32, i32, i32, i64, i64, i32, i32, p]),
     "sglk_decode_attention_xs": (i32, [p] * 9 + [i32] * 6 + [i64] * 8 + [f32, f32, i32, p, i64, p]),
+    "sglk_decode_attention_shared_prefix_rope": (i32, [p, i32, i64, p, p, p, i32, i32, p, i32] + [p] * 7 + [i32, p] +
+                                                 [i32] * 6 + [i64] * 6 + [f32, f32, i32, p, i64, p]),
     "sglk_decode_attention_shared_prefix_xs": (i32, [p] * 8 + [i32, p] + [i32] * 6 + [i64] * 8 + [f32, f32, i32, p, i64, p]),
     "sglk_dense_gemm_nt": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_dense_gemm_workspace_bytes": (i64, [i32, i32, i32]),

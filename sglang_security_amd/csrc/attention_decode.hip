@@ -624,9 +624,12 @@ __device__ __forceinline__ int active_prefix_splits(int plen, int prefix_splits)
   return cdiv_i(plen, per_p);
 }
 
-template <typename T>
+// ROPE: q is not read; the query rows, and every request's new K / V row, come from the qkv projection's split-K
+// partial sums (qp).  A (request, kv head) pair's tail block (one head tile only) writes the pair's new pool rows
+// before it walks the request's list, whose last entry is that row's slot.
+template <typename T, bool ROPE>
 __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
-    const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
+    const void* __restrict__ q, QkvPartials qp, void* k_buffer, void* v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, int num_groups, SharedWs ws,
     int prefix_splits, int n_prefix_blocks, int col_blocks, int B, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
@@ -670,14 +673,23 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const bool ok = col < gsize * heads;
     const int req = ok ? gstart + col / heads : -1;
     const int head = kvh * heads + col % heads;
-    st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
-                    : nullptr);
+    const int32_t* const plist = kv_indices + (gstart < 64 ? __shfl(spec_indptr, gstart, 64) : kv_indptr[gstart]);
     // every request of the group lists the same slots for the prefix: walk the first request's list
-    st.template run<false, true, kPrefixPF>(
-        lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-        reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
-        kv_indices + (gstart < 64 ? __shfl(spec_indptr, gstart, 64) : kv_indptr[gstart]), t0, t1, qpos, 0, sm_scale,
-        logit_cap);
+    if constexpr (ROPE) {
+      // the position travels with the first tiles' slots, the partial sums and the cos / sin row with their rows
+      const int64_t pos = ok ? qp.positions[req] : 0;
+      st.template run<false, true, kPrefixPF>(
+          lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+          reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
+          qpos, 0, sm_scale, logit_cap, [&]() { load_q_rotated<T>(st.qf[0], qp, req, pos, head * 128, ok); });
+    } else {
+      st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
+                      : nullptr);
+      st.template run<false, true, kPrefixPF>(
+          lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+          reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
+          qpos, 0, sm_scale, logit_cap);
+    }
     const float tot = st.total(0);
     ATTN_STAMP(1);
     if (ok) {
@@ -710,6 +722,11 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   i /= head_tiles;
   const int kvh = i % Hkv, b = i / Hkv;
   char* vl = lds_all + wid * kTileBytes;  // K goes straight into registers: a wave owns one 8 KiB V tile
+  int64_t pos = 0, new_slot = 0;
+  if constexpr (ROPE) {
+    pos = qp.positions[b];
+    new_slot = ld_idx(qp.loc, qp.loc_is64, b);
+  }
   const int grp = find_group(group_indptr, num_groups, b);
   const int plen = prefix_lens[grp];
   const int start = kv_indptr[b] + plen;
@@ -725,11 +742,28 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
 
   WaveAttn<T> wa;
   wa.init();
-  wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
-                    : nullptr);
-  wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-            reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
-            kv_indices + start, s0, s1, sm_scale, logit_cap);
+  if constexpr (ROPE) {
+    // One wave writes the pair's new rows while the slot lists are fetched; every wave then waits for its own loads and
+    // stores and for the block, so the wave whose range ends with the new row's slot reads it back from L2 (the
+    // vector cache writes through, and nothing on this CU has read the row before).
+    if (wid == kWavesPerBlock - 1)
+      store_new_kv<T>(qp, b, pos, (Hq + kvh) * 128, (Hq + Hkv + kvh) * 128,
+                      reinterpret_cast<uint16_t*>(k_buffer) + new_slot * k_stride_n + (int64_t)kvh * k_stride_h,
+                      reinterpret_cast<uint16_t*>(v_buffer) + new_slot * v_stride_n + (int64_t)kvh * v_stride_h);
+    load_q_rotated<T>(wa.qf, qp, b, pos, head * 128, head_ok);
+    const auto ks = wa.begin_kd(kv_indices + start, s0, s1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+              kv_indices + start, s0, s1, sm_scale, logit_cap, ks);
+  } else {
+    wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                      : nullptr);
+    wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+              kv_indices + start, s0, s1, sm_scale, logit_cap);
+  }
   {
     // this wave's partial: O[16 heads][128] fp32 over its V tile, log-sum-exp[16] beside it
     const float lsum = wa.total();
@@ -1009,25 +1043,25 @@ SGLK_API int sglk_debug_attn_stamps(void* dst) {
 }
 #endif
 
-int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o,
-                                           const int32_t* kv_indptr, const int32_t* kv_indices,
-                                           const int32_t* group_indptr, const int32_t* prefix_lens, int G,
-                                           float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
-                                           int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
-                                           int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
-                                           float sm_scale, float logit_cap, int dtype, float* xsum_out, int64_t xs_stride,
-                                           void* stream) {
+static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_buffer, void* v_buffer, void* o,
+                                const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* group_indptr,
+                                const int32_t* prefix_lens, int G, float* workspace, int max_kv_splits, int B, int Hq,
+                                int Hkv, int D, int Dv, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n,
+                                int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b,
+                                int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, float* xsum_out,
+                                int64_t xs_stride, void* stream) {
   SGLK_CHECK(!xsum_out || xs_stride >= B, "decode_attention_shared_prefix: xs_stride smaller than B");
-  SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
+  SGLK_CHECK((q || qp) && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
              "decode_attention_shared_prefix: null pointer");
   SGLK_CHECK(B >= 0 && G > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
   SGLK_CHECK(max_kv_splits > 0 && max_kv_splits <= kSharedMaxSplits,
              "decode_attention_shared_prefix: max_kv_splits must be in 1..16");
   if (B == 0) return SGLK_OK;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
-  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
-                    aligned16(k_buffer) && aligned16(v_buffer) && aligned16(workspace) && mult8(q_stride_b) &&
-                    mult8(q_stride_h) && mult8(k_stride_n) && mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h);
+  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && (qp || aligned16(q)) &&
+                    aligned16(k_buffer) && aligned16(v_buffer) && aligned16(workspace) &&
+                    (qp || (mult8(q_stride_b) && mult8(q_stride_h))) && mult8(k_stride_n) && mult8(k_stride_h) &&
+                    mult8(v_stride_n) && mult8(v_stride_h);
   if (!fast)
     return fail(SGLK_EUNSUP, "decode_attention_shared_prefix: only 16-bit types with head size 128 (got D=%d Dv=%d dtype=%d)",
                 D, Dv, dtype);
@@ -1052,14 +1086,71 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
   const int n_tail = B * Hkv * head_tiles;
   const size_t lds = kBlockAttnLds;  // the prefix role's two stages; the tail role's four V tiles fit in the same bytes
   static_assert(kWavesPerBlock * kTileBytes <= kBlockAttnLds, "LDS of the prefix role must cover the tail role");
-  SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((decode_shared_fused_kernel<T>), dim3(n_prefix + n_tail), dim3(256), lds, s, q,
-                                        k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G, ws,
-                                        prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles, q_stride_b, q_stride_h,
-                                        k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o, o_stride_b,
-                                        o_stride_h, xsum_out, xs_stride));
+#define SGLK_SHARED_LAUNCH(ROPE, QP)                                                                                   \
+  SGLK_DISPATCH_HALF(dtype, T,                                                                                         \
+                     hipLaunchKernelGGL((decode_shared_fused_kernel<T, ROPE>), dim3(n_prefix + n_tail), dim3(256), lds, s, \
+                                        q, QP, k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G,  \
+                                        ws, prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles, q_stride_b,    \
+                                        q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, \
+                                        o, o_stride_b, o_stride_h, xsum_out, xs_stride))
+  if (qp) {
+    // a pair's single tail block writes the pair's new rows: more than one head tile would need them across blocks
+    if (head_tiles != 1)
+      return fail(SGLK_EUNSUP, "decode_attention_shared_prefix_rope: at most 16 query heads per kv head (got %d)", heads);
+    SGLK_SHARED_LAUNCH(true, *qp);
+  } else {
+    SGLK_SHARED_LAUNCH(false, QkvPartials{});
+  }
+#undef SGLK_SHARED_LAUNCH
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                           const int32_t* kv_indptr, const int32_t* kv_indices,
+                                           const int32_t* group_indptr, const int32_t* prefix_lens, int G,
+                                           float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
+                                           int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                           int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                           float sm_scale, float logit_cap, int dtype, float* xsum_out, int64_t xs_stride,
+                                           void* stream) {
+  SGLK_CHECK(q, "decode_attention_shared_prefix: null pointer");
+  return launch_shared_prefix(q, nullptr, const_cast<void*>(k_buffer), const_cast<void*>(v_buffer), o, kv_indptr,
+                              kv_indices, group_indptr, prefix_lens, G, workspace, max_kv_splits, B, Hq, Hkv, D, Dv,
+                              q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h,
+                              sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
+}
+
+int sglk_decode_attention_shared_prefix_rope(const float* qkv_partials, int splits, int64_t part_stride,
+                                             const void* qkv_bias, const float* cos_sin_cache, const int64_t* positions,
+                                             int rot_dim, int interleave, const void* loc, int loc_is64, void* k_buffer,
+                                             void* v_buffer, void* o, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                             const int32_t* group_indptr, const int32_t* prefix_lens, int G,
+                                             float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
+                                             int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                             int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+                                             int dtype, float* xsum_out, int64_t xs_stride, void* stream) {
+  SGLK_CHECK(qkv_partials && cos_sin_cache && positions && loc, "decode_attention_shared_prefix_rope: null pointer");
+  if (rot_dim != 128 || interleave != 0 || D != 128)
+    return fail(SGLK_EUNSUP, "decode_attention_shared_prefix_rope: full rotation of 128-element heads in the (d, d + 64) "
+                "pairing only (got rot_dim=%d interleave=%d D=%d)", rot_dim, interleave, D);
+  const int64_t row_len = (int64_t)(Hq + 2 * Hkv) * 128;
+  SGLK_CHECK(splits >= 1 && part_stride >= (int64_t)B * row_len && part_stride % 4 == 0 && aligned16(qkv_partials) &&
+                 aligned16(cos_sin_cache) && (!qkv_bias || aligned16(qkv_bias)),
+             "decode_attention_shared_prefix_rope: bad partial layout");
+  QkvPartials qp;
+  qp.partials = qkv_partials;
+  qp.splits = splits;
+  qp.part_stride = part_stride;
+  qp.row_len = (int)row_len;
+  qp.bias = reinterpret_cast<const uint16_t*>(qkv_bias);
+  qp.cos_sin = cos_sin_cache;
+  qp.positions = positions;
+  qp.loc = loc;
+  qp.loc_is64 = loc_is64;
+  return launch_shared_prefix(nullptr, &qp, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, G,
+                              workspace, max_kv_splits, B, Hq, Hkv, D, Dv, 0, 0, k_stride_n, k_stride_h, v_stride_n,
+                              v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
 }
 
 int sglk_decode_attention_shared_prefix(const void* q, const void* k_buffer, const void* v_buffer, void* o,

@@ -50,6 +50,132 @@ __device__ __forceinline__ int v_off(int r, int byte_in_row) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The qkv projection of a fused decode layer as its GEMM leaves it: split-K partial sums in fp32, not yet added up,
+// biased, rounded or rotated.  The value the attention kernels work on is
+//   round_T(rope(round_T(sum_s partial[s][token][col] + bias[col])))   (rotation of full 128-element heads, pairs
+// (d, d + 64), cos_sin row = cos[64] | sin[64] at the token's position): the bits the separate
+// "sum, round, rotate, store" kernel produces.
+// ---------------------------------------------------------------------------------------------------
+struct QkvPartials {
+  const float* partials;     // [splits][tokens][row_len]
+  int splits;
+  int64_t part_stride;       // floats between splits
+  int row_len;               // (q heads + 2 kv heads) * 128
+  const uint16_t* bias;      // row_len values of the 16-bit type, or nullptr
+  const float* cos_sin;      // [positions][128]
+  const int64_t* positions;  // [tokens]
+  const void* loc;           // pool slot of every token's new K / V row
+  int loc_is64;
+};
+
+// sum over splits (in split order, four splits' loads in flight together) of the 8 floats at p + s * stride
+__device__ __forceinline__ void sum_splits8(const float* p, int splits, int64_t stride, float (&acc)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int s0 = 0; s0 < splits; s0 += 4) {
+    float4v a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* pr = p + (int64_t)min(s0 + u, splits - 1) * stride;
+      a[u] = *reinterpret_cast<const float4v*>(pr);
+      b[u] = *reinterpret_cast<const float4v*>(pr + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < splits) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] += a[u][j];
+          acc[4 + j] += b[u][j];
+        }
+      }
+  }
+}
+
+// The rotated Q^T operand of one column (a 128-element head starting at element col_off of row `token`) in the
+// register layout of load_q: lane (hl, g) keeps elements 32 ks + 8 g .. + 8, and the rotation partner of element d,
+// d + 64, is element (ks + 2, same g) of the same lane.
+template <typename T>
+__device__ __forceinline__ void load_q_rotated(short8 (&qf)[4], const QkvPartials& qp, int token, int64_t pos, int col_off,
+                                               bool ok) {
+  const int g = (threadIdx.x & 63) >> 4;
+  if (!ok) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    return;
+  }
+  const float* cs = qp.cos_sin + pos * 128;
+  const float* base = qp.partials + (int64_t)token * qp.row_len + col_off + 8 * g;
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    float a[8], b[8];
+    sum_splits8(base + 32 * pr, qp.splits, qp.part_stride, a);
+    sum_splits8(base + 32 * pr + 64, qp.splits, qp.part_stride, b);
+    const float4v c0 = *reinterpret_cast<const float4v*>(cs + 32 * pr + 8 * g);
+    const float4v c1 = *reinterpret_cast<const float4v*>(cs + 32 * pr + 8 * g + 4);
+    const float4v s0 = *reinterpret_cast<const float4v*>(cs + 64 + 32 * pr + 8 * g);
+    const float4v s1 = *reinterpret_cast<const float4v*>(cs + 64 + 32 * pr + 8 * g + 4);
+    short8 ba = short8{0, 0, 0, 0, 0, 0, 0, 0}, bb = ba;
+    if (qp.bias) {
+      ba = *reinterpret_cast<const short8*>(qp.bias + col_off + 32 * pr + 8 * g);
+      bb = *reinterpret_cast<const short8*>(qp.bias + col_off + 32 * pr + 8 * g + 64);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float bja = qp.bias ? Conv<T>::to_f32((uint16_t)ba[e]) : 0.f;
+      const float bjb = qp.bias ? Conv<T>::to_f32((uint16_t)bb[e]) : 0.f;
+      const float xa = Conv<T>::to_f32(Conv<T>::from_f32(a[e] + bja));
+      const float xb = Conv<T>::to_f32(Conv<T>::from_f32(b[e] + bjb));
+      float ra, rb;
+      rope_pair(xa, xb, e < 4 ? c0[e & 3] : c1[e & 3], e < 4 ? s0[e & 3] : s1[e & 3], ra, rb);
+      qf[pr][e] = (short)Conv<T>::from_f32(ra);
+      qf[pr + 2][e] = (short)Conv<T>::from_f32(rb);
+    }
+  }
+}
+
+// One wave finishes a token's new K row (rotated) and V row (as it is) of one kv head and writes them to the pool:
+// lane l owns elements l and l + 64.  The stores are left in flight: a reader waits for this wave's "s_waitcnt
+// vmcnt(0)" (and a barrier, if it is another wave) before it loads the rows.
+template <typename T>
+__device__ __forceinline__ void store_new_kv(const QkvPartials& qp, int token, int64_t pos, int k_col, int v_col,
+                                             uint16_t* krow, uint16_t* vrow) {
+  const int l = threadIdx.x & 63;
+  const float* cs = qp.cos_sin + pos * 128;
+  const float* pk = qp.partials + (int64_t)token * qp.row_len + k_col + l;
+  const float* pv = qp.partials + (int64_t)token * qp.row_len + v_col + l;
+  float ka = 0.f, kb = 0.f, va = 0.f, vb = 0.f;
+  for (int s0 = 0; s0 < qp.splits; s0 += 4) {
+    float t[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t o = (int64_t)min(s0 + u, qp.splits - 1) * qp.part_stride;
+      t[u][0] = pk[o];
+      t[u][1] = pk[o + 64];
+      t[u][2] = pv[o];
+      t[u][3] = pv[o + 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (s0 + u < qp.splits) {
+        ka += t[u][0];
+        kb += t[u][1];
+        va += t[u][2];
+        vb += t[u][3];
+      }
+  }
+  auto bias_at = [&](int col) { return qp.bias ? Conv<T>::to_f32(qp.bias[col]) : 0.f; };
+  const float xa = Conv<T>::to_f32(Conv<T>::from_f32(ka + bias_at(k_col + l)));
+  const float xb = Conv<T>::to_f32(Conv<T>::from_f32(kb + bias_at(k_col + l + 64)));
+  float ra, rb;
+  rope_pair(xa, xb, cs[l], cs[64 + l], ra, rb);
+  krow[l] = Conv<T>::from_f32(ra);
+  krow[l + 64] = Conv<T>::from_f32(rb);
+  vrow[l] = Conv<T>::from_f32(va + bias_at(v_col + l));
+  vrow[l + 64] = Conv<T>::from_f32(vb + bias_at(v_col + l + 64));
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Block-cooperative streaming attention: the 4 waves of a 256-thread block share each K/V tile
 // (double-buffered in LDS, one barrier per tile) and every wave multiplies it against its own NC
 // column tiles of 16 query rows.  State is carried across run() calls, so a caller can stream a
@@ -92,10 +218,15 @@ struct BlockAttn {
   // else in row t of kbase/vbase.  CAUSAL: column tile c of this lane sees token t only if t <= qpos[c];
   // wave_qmax is the largest qpos of the wave (tiles wholly above it are skipped by the wave).
   // PF: tiles in flight ahead of the one being multiplied (registers: 4 x 16-byte per tile and thread).
-  template <bool CAUSAL, bool GATHER, int PF = 1>
+  struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+  };
+  // after_fetch runs once the first tiles' loads are on their way (e.g. to assemble the Q operand in their shadow)
+  template <bool CAUSAL, bool GATHER, int PF = 1, typename Hook = NoHook>
   __device__ __forceinline__ void run(char* lds, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
                                       int64_t v_stride_n, const int32_t* idx, int t_begin, int t_end,
-                                      const int (&qpos)[NC], int wave_qmax, float sm_scale, float logit_cap) {
+                                      const int (&qpos)[NC], int wave_qmax, float sm_scale, float logit_cap,
+                                      Hook after_fetch = Hook()) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hl = lane & 15, g = lane >> 4;
@@ -194,6 +325,7 @@ struct BlockAttn {
 #pragma unroll
     for (int p = 0; p < PF; ++p)
       if (t_begin + (PF + p) * kTile < t_end) fetch_idx(rowi[p], t_begin + (PF + p) * kTile);
+    after_fetch();
     int stage = 0;
     for (int tb = t_begin; tb < t_end; tb += kTile * PF) {
 #pragma unroll
@@ -502,13 +634,29 @@ struct WaveAttn {
   }
 
   // Stream tokens [s0, s1) of the slot list idx with K straight into registers and V through the 8 KiB tile at vl.
+  struct KdSlots {
+    int first, next;
+  };
+  // the slot loads of run_kd's first tiles, for a caller with work to place between them and the row loads
+  static __device__ __forceinline__ KdSlots begin_kd(const int32_t* idx, int s0, int s1) {
+    KdSlots k{0, 0};
+    if (s1 <= s0) return k;
+    k.first = load_slots(idx, s0, s0, s1);
+    k.next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
+    return k;
+  }
   __device__ __forceinline__ void run_kd(char* vl, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
                                          int64_t v_stride_n, const int32_t* idx, int s0, int s1, float sm_scale,
                                          float logit_cap) {
+    run_kd(vl, kbase, vbase, k_stride_n, v_stride_n, idx, s0, s1, sm_scale, logit_cap, begin_kd(idx, s0, s1));
+  }
+  __device__ __forceinline__ void run_kd(char* vl, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
+                                         int64_t v_stride_n, const int32_t* idx, int s0, int s1, float sm_scale,
+                                         float logit_cap, KdSlots ks) {
     if (s1 <= s0) return;
     RowsKD r;
-    int slots = load_slots(idx, s0, s0, s1);
-    int slots_next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
+    int slots = ks.first;
+    int slots_next = ks.next;
     fetch_kd(r, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
     int off = 0;
     for (int t0 = s0; t0 < s1; t0 += kTile) {

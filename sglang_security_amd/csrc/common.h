@@ -113,6 +113,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// One rotary pair in fp32 with a fixed operation order (two roundings per output), so that every kernel that rotates
+// the same values produces the same bits whatever the compiler would contract elsewhere.
+__device__ __forceinline__ void rope_pair(float xa, float xb, float c, float s, float& ra, float& rb) {
+  ra = __fmaf_rn(xa, c, -__fmul_rn(xb, s));
+  rb = __fmaf_rn(xb, c, __fmul_rn(xa, s));
+}
+
 __device__ __forceinline__ int64_t ld_idx(const void* p, int is64, int64_t i) {
   return is64 ? reinterpret_cast<const int64_t*>(p)[i] : (int64_t) reinterpret_cast<const int32_t*>(p)[i];
 }

@@ -266,34 +266,45 @@ __global__ void __launch_bounds__(1024) rope_store_partial_kernel(
     void* __restrict__ qkv, const float* __restrict__ partials, int splits, int64_t part_stride,
     const void* __restrict__ bias, const float* __restrict__ cos_sin, const int64_t* __restrict__ positions,
     void* __restrict__ k_buffer, void* __restrict__ v_buffer, const void* loc, int loc_is64, int q_heads, int kv_heads,
-    int head_size, int rot, int64_t kbuf_stride_n, int64_t vbuf_stride_n, int interleave) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t rowS[];  // (q_heads + 2 kv_heads) * head_size
+    int head_size, int rot, int64_t kbuf_stride_n, int64_t vbuf_stride_n, int interleave, int heads_per_block) {
+  // block (t, part) owns heads [h0, h1) of token t's row (q heads, then k heads, then v heads): heads are independent,
+  // so a row is spread over several blocks when there are fewer tokens than CUs
+  extern __shared__ __attribute__((aligned(16))) uint16_t rowS[];  // heads_per_block * head_size
   const int64_t t = blockIdx.x;
-  const int row_len = (q_heads + 2 * kv_heads) * head_size;
+  const int total_heads = q_heads + 2 * kv_heads;
+  const int h0 = blockIdx.y * heads_per_block, h1 = min(h0 + heads_per_block, total_heads);
+  if (h0 >= h1) return;
+  const int row_len = total_heads * head_size;
+  const int c0 = h0 * head_size, ncol = (h1 - h0) * head_size;
+  // requested before the sums so that they travel together
+  const int64_t pos = positions[t];
+  const int64_t slot = ld_idx(loc, loc_is64, t);
   const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
-  for (int v = threadIdx.x; v < (row_len >> 3); v += blockDim.x) {
+  for (int v = threadIdx.x; v < (ncol >> 3); v += blockDim.x) {
     float acc[8];
-    sum_partials(partials, splits, part_stride, t * row_len + 8 * v, acc);
+    sum_partials(partials, splits, part_stride, t * row_len + c0 + 8 * v, acc);
     short8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (short)Conv<T>::from_f32(acc[j] + (br ? Conv<T>::to_f32(br[8 * v + j]) : 0.f));
+    for (int j = 0; j < 8; ++j)
+      o[j] = (short)Conv<T>::from_f32(acc[j] + (br ? Conv<T>::to_f32(br[c0 + 8 * v + j]) : 0.f));
     reinterpret_cast<short8*>(rowS)[v] = o;
   }
   __syncthreads();
   uint16_t* qdst = reinterpret_cast<uint16_t*>(qkv) + t * row_len;
-  const float* cs = cos_sin + positions[t] * rot;
+  const float* cs = cos_sin + pos * rot;
   const int half = rot / 2;
-  const int64_t slot = ld_idx(loc, loc_is64, t);
   uint16_t* kdst = reinterpret_cast<uint16_t*>(k_buffer) + slot * kbuf_stride_n;
   uint16_t* vdst = reinterpret_cast<uint16_t*>(v_buffer) + slot * vbuf_stride_n;
-  const int nrot = (q_heads + kv_heads) * half;
-  for (int i = threadIdx.x; i < nrot; i += blockDim.x) {
-    const int h = i / half, p = i - h * half;
+  const int rot_heads = max(0, min(h1, q_heads + kv_heads) - h0);  // q and k heads of this block
+  for (int i = threadIdx.x; i < rot_heads * half; i += blockDim.x) {
+    const int hl = i / half, p = i - hl * half, h = h0 + hl;
     const int a = interleave ? 2 * p : p, b = interleave ? 2 * p + 1 : p + half;
-    const uint16_t* v = rowS + h * head_size;
+    const uint16_t* v = rowS + hl * head_size;
     const float c = cs[p], s = cs[half + p];
     const float xa = Conv<T>::to_f32(v[a]), xb = Conv<T>::to_f32(v[b]);
-    const uint16_t ra = Conv<T>::from_f32(xa * c - xb * s), rb = Conv<T>::from_f32(xb * c + xa * s);
+    float fa, fb;
+    rope_pair(xa, xb, c, s, fa, fb);
+    const uint16_t ra = Conv<T>::from_f32(fa), rb = Conv<T>::from_f32(fb);
     uint16_t* d = h < q_heads ? qdst + h * head_size : kdst + (h - q_heads) * head_size;
     d[a] = ra;
     d[b] = rb;
@@ -302,21 +313,23 @@ __global__ void __launch_bounds__(1024) rope_store_partial_kernel(
       qdst[h * head_size + b] = rb;
     }
   }
-  // pass-through dims (rot < head_size) of q and k, and all of v
+  // pass-through dims (rot < head_size) of q and k
   if (rot < head_size) {
     const int pass = head_size - rot;
-    for (int i = threadIdx.x; i < (q_heads + kv_heads) * pass; i += blockDim.x) {
-      const int h = i / pass, p = rot + (i - h * pass);
-      const uint16_t val = rowS[h * head_size + p];
+    for (int i = threadIdx.x; i < rot_heads * pass; i += blockDim.x) {
+      const int hl = i / pass, p = rot + (i - hl * pass), h = h0 + hl;
+      const uint16_t val = rowS[hl * head_size + p];
       qdst[h * head_size + p] = val;
       if (h >= q_heads) kdst[(h - q_heads) * head_size + p] = val;
     }
   }
-  const int voff = (q_heads + kv_heads) * head_size;
-  for (int i = threadIdx.x; i < kv_heads * head_size; i += blockDim.x) {
-    const uint16_t val = rowS[voff + i];
-    vdst[i] = val;
-    qdst[voff + i] = val;
+  // v heads of this block
+  const int v0 = max(h0, q_heads + kv_heads);
+  for (int i = threadIdx.x; i < max(0, h1 - v0) * head_size; i += blockDim.x) {
+    const int col = v0 * head_size + i;
+    const uint16_t val = rowS[col - c0];
+    vdst[col - (q_heads + kv_heads) * head_size] = val;
+    qdst[col] = val;
   }
 }
 
@@ -381,8 +394,10 @@ __device__ __forceinline__ void rope_rows(typename Raw<T>::type* base, int heads
     typename Raw<T>::type* v = base + (int64_t)h * head_size;
     const float c = cs[p], s = cs[half + p];
     const float xa = Conv<T>::to_f32(v[a]), xb = Conv<T>::to_f32(v[b]);
-    v[a] = Conv<T>::from_f32(xa * c - xb * s);
-    v[b] = Conv<T>::from_f32(xb * c + xa * s);
+    float fa, fb;
+    rope_pair(xa, xb, c, s, fa, fb);
+    v[a] = Conv<T>::from_f32(fa);
+    v[b] = Conv<T>::from_f32(fb);
   }
 }
 
@@ -422,7 +437,9 @@ __global__ void __launch_bounds__(256) rope_store_kernel(void* qkv, const float*
     R* v = base + (int64_t)h * head_size;
     const float c = cs[p], s = cs[half + p];
     const float xa = Conv<T>::to_f32(v[a]), xb = Conv<T>::to_f32(v[b]);
-    const R ra = Conv<T>::from_f32(xa * c - xb * s), rb = Conv<T>::from_f32(xb * c + xa * s);
+    float fa, fb;
+    rope_pair(xa, xb, c, s, fa, fb);
+    const R ra = Conv<T>::from_f32(fa), rb = Conv<T>::from_f32(fb);
     v[a] = ra;
     v[b] = rb;
     if (h >= q_heads) {
@@ -810,14 +827,19 @@ int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits,
   if (tokens == 0) return SGLK_OK;
   SGLK_CHECK(cos_sin_cache && positions && k_buffer && v_buffer && loc, "rope_and_store_kv_partial: null pointer");
   SGLK_CHECK(rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size, "rope_and_store_kv_partial: bad rotary dim");
-  SGLK_CHECK(row_len * 2 <= 64 * 1024, "rope_and_store_kv_partial: qkv row of %lld elements does not fit in LDS",
-             (long long)row_len);
+  SGLK_CHECK(head_size % 8 == 0, "rope_and_store_kv_partial: head size must be a multiple of 8");
+  // enough blocks to cover the CUs: a token's heads are spread over `parts` blocks
+  const int total_heads = q_heads + 2 * kv_heads;
+  const int parts = (int)std::max<int64_t>(1, std::min<int64_t>(total_heads, 256 / tokens));
+  const int hpb = (total_heads + parts - 1) / parts;
+  const int64_t cols = (int64_t)hpb * head_size;
+  SGLK_CHECK(cols * 2 <= 64 * 1024, "rope_and_store_kv_partial: %lld elements per block do not fit in LDS", (long long)cols);
   SGLK_DISPATCH_HALF(dtype, T,
-                     hipLaunchKernelGGL((rope_store_partial_kernel<T>), dim3((unsigned)tokens),
-                                        dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(256, (row_len / 8 + 63) / 64 * 64))),
-                                        (size_t)row_len * 2, (hipStream_t)stream, qkv, partials, splits, part_stride, bias,
+                     hipLaunchKernelGGL((rope_store_partial_kernel<T>), dim3((unsigned)tokens, (unsigned)((total_heads + hpb - 1) / hpb)),
+                                        dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, (cols / 8 + 63) / 64 * 64))),
+                                        (size_t)cols * 2, (hipStream_t)stream, qkv, partials, splits, part_stride, bias,
                                         cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, q_heads, kv_heads,
-                                        head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave));
+                                        head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave, hpb));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

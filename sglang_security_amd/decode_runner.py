@@ -189,6 +189,7 @@ class LlamaDecoder:
             self.x_s = torch.empty(B, dtype=torch.float32, device=device)
         # layer fusion: block sums of every GEMM input come from its producer, split-K partials go to the consumer
         self.fused = False
+        self.fold_rope = False
         self.xs_hidden = torch.zeros(c.hidden // 128, B, dtype=torch.float32, device=device)
         self.xs_attn = torch.zeros(self.q_size // 128, B, dtype=torch.float32, device=device)
         self.xs_act = torch.zeros(c.inter // 128, B, dtype=torch.float32, device=device)
@@ -272,6 +273,11 @@ class LlamaDecoder:
                 need = max(self.part_splits[k] * self.B * n for k, (kk, n) in shapes.items())
                 self.partial = torch.empty(need, dtype=torch.float32, device=self.device)
         self.fused = bool(ok)
+        # rotary embedding and the new K / V rows folded into the shared-prefix attention kernel
+        # (decode_attention_shared_prefix_rope; needs at most 16 query heads per kv head and full rotation of 128)
+        # (off: four splits of fp32 partial sums per query row cost the attention kernel more than the separate
+        # rotation launch they replace; worth it only where the projection runs unsplit)
+        self.fold_rope = False
         # gate_up with the activation in its epilogue: columns interleaved in blocks of 64 (gate, up, gate, up, ...)
         self.fused_act = self.fused and c.inter % 128 == 0 and c.hidden % 512 == 0
         if self.fused_act:
@@ -336,9 +342,18 @@ class LlamaDecoder:
                 ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln1"], c.eps, xsum_out=self.xs_hidden)
             w = L["qkv"]
             self._timed("qkv", lambda: ops.awq_gemm_partial(self.hidden, w.packed, w.scales, w.qzeros, P, self.xs_hidden))
-            ops.rope_and_store_kv_partial(self.qkv, P, S["qkv"], self.cos_sin, self.positions, self.k_pool[li],
-                                          self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
-            self.attention(li, q_view, o_view, sm_scale, xsum_out=self.xs_attn)
+            if self.fold_rope and getattr(self, "shared", False):
+                # the attention kernel assembles q and the new K / V rows from the projection's partial sums itself
+                ops.decode_attention_shared_prefix_rope(P, S["qkv"], self.qkv.numel(), L["qkv_bias"], self.cos_sin,
+                                                        self.positions, self.out_cache_loc, self.k_pool[li],
+                                                        self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
+                                                        self.group_indptr, self.group_prefix, self.shared_ws,
+                                                        self.max_kv_splits, sm_scale, 0.0, self.xs_attn)
+            else:
+                ops.rope_and_store_kv_partial(self.qkv, P, S["qkv"], self.cos_sin, self.positions, self.k_pool[li],
+                                              self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim,
+                                              bias=L["qkv_bias"])
+                self.attention(li, q_view, o_view, sm_scale, xsum_out=self.xs_attn)
             w = L["o"]
             if tp is None:
                 self._timed("o", lambda: ops.awq_gemm_partial(self.attn_out, w.packed, w.scales, w.qzeros, P, self.xs_attn))

@@ -148,6 +148,12 @@ def decode_shared_workspace(B, Hq, Dv, max_kv_splits, device) -> torch.Tensor:
     return ws
 
 
+def decode_shared_workspace_status(ws, B, Hq) -> int:
+    """1 if a launch on this workspace gave up waiting for its prefix partials (its outputs are NaN), else 0.
+    Synchronises with the device."""
+    return int(lib().sglk_decode_shared_workspace_status(_ptr(ws), B, Hq))
+
+
 def decode_attention_shared_prefix(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens,
                                    workspace, max_kv_splits, sm_scale, logit_cap=0.0):
     _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, workspace)
@@ -767,6 +773,25 @@ def decode_attention_shared_prefix_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_in
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
         float(sm_scale), float(logit_cap), dtype_code(q.dtype), _ptr(xsum_out),
         0 if xsum_out is None else xsum_out.stride(0), _stream(q)), "decode_attention_shared_prefix_xs")
+
+
+def decode_attention_shared_prefix_rope(partials, splits, part_stride, bias, cos_sin_cache, positions, loc, k_buffer,
+                                        v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, workspace,
+                                        max_kv_splits, sm_scale, logit_cap, xsum_out, interleave=False):
+    """rope_and_store_kv_partial + decode_attention_shared_prefix_xs in one launch: q and the new K / V rows come from
+    the qkv projection's split-K partial sums [splits][B][(Hq + 2 Hkv) * 128]; o is [B, Hq, 128]."""
+    _need_gpu(partials, cos_sin_cache, positions, loc, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr,
+              prefix_lens, workspace)
+    B, Hq, D = o.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    G = group_indptr.shape[0] - 1
+    check(lib().sglk_decode_attention_shared_prefix_rope(
+        _ptr(partials), int(splits), int(part_stride), _ptr(bias), _ptr(cos_sin_cache), _ptr(positions),
+        cos_sin_cache.shape[1], 1 if interleave else 0, _ptr(loc), _is64(loc), _ptr(k_buffer), _ptr(v_buffer), _ptr(o),
+        _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr), _ptr(prefix_lens), G, _ptr(workspace), max_kv_splits, B, Hq,
+        Hkv, D, Dv, k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0),
+        o.stride(1), float(sm_scale), float(logit_cap), dtype_code(o.dtype), _ptr(xsum_out),
+        0 if xsum_out is None else xsum_out.stride(0), _stream(o)), "decode_attention_shared_prefix_rope")
 
 
 def prefill_attention_paged(q, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, max_q_len, sm_scale,

@@ -139,6 +139,68 @@ def test_attention_block_sums():
     assert (o1.float() - o2.float()).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("groups,max_splits", [([(6, 70, 1, 40)], 8), ([(3, 200, 1, 9), (2, 0, 1, 33), (4, 64, 64, 65)], 4),
+                                               ([(64, 1024, 129, 129)], 8)])
+def test_attention_with_rope_folded_in(groups, max_splits):
+    """Shared-prefix decode attention fed with the qkv projection's split-K partial sums (rotation and the new pool
+    rows inside the kernel) against the separate rope_and_store_kv_partial + attention launches on the same
+    inputs: the same pool rows bit for bit, the same outputs and block sums bit for bit."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_attention_extend import _group_batch
+
+    ops = _ops()
+    Hq, Hkv, D, splits = 32, 8, 128, 3
+    _, kb, vb, ptr, ind, gi, pls = _group_batch(groups, Hq, Hkv, torch.bfloat16, seed=5)
+    B = ptr.shape[0] - 1
+    g = torch.Generator().manual_seed(11)
+    row = (Hq + 2 * Hkv) * D
+    parts = (torch.randn(splits, B, row, generator=g) * 0.6).to(DEV)
+    cs_ang = torch.rand(512, D // 2, generator=g) * 6.28
+    cs = torch.cat([cs_ang.cos(), cs_ang.sin()], dim=1).to(DEV)
+    pos = torch.randint(0, 512, (B,), generator=g).to(DEV)
+    # every request's new row goes to the slot its list ends with
+    loc = ind[(ptr[1:] - 1).long()].to(torch.int64).to(DEV)
+    sm = 1.0 / math.sqrt(D)
+    kb1, vb1 = kb.to(DEV).clone(), vb.to(DEV).clone()
+    kb2, vb2 = kb.to(DEV).clone(), vb.to(DEV).clone()
+    meta = [t.to(DEV) for t in (ptr, ind, gi, pls)]
+    qkv = torch.empty(B, row, dtype=torch.bfloat16, device=DEV)
+    o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=DEV)
+    o2 = torch.full_like(o1, float("nan"))
+    xs1, xs2 = torch.zeros(Hq, B, device=DEV), torch.zeros(Hq, B, device=DEV)
+    ws = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
+    ops.rope_and_store_kv_partial(qkv, parts, splits, cs, pos, kb1, vb1, loc, Hq, Hkv, D)
+    ops.decode_attention_shared_prefix_xs(qkv[:, : Hq * D].view(B, Hq, D), kb1, vb1, o1, *meta, ws, max_splits, sm, 0.0, xs1)
+    for _ in range(2):   # twice: the second launch finds the rows already in place and the counters back at zero
+        ops.decode_attention_shared_prefix_rope(parts, splits, B * row, None, cs, pos, loc, kb2, vb2, o2, *meta, ws,
+                                                max_splits, sm, 0.0, xs2)
+        torch.cuda.synchronize()
+        assert torch.equal(kb1.view(torch.int16), kb2.view(torch.int16))
+        assert torch.equal(vb1.view(torch.int16), vb2.view(torch.int16))
+        assert torch.equal(o1.view(torch.int16), o2.view(torch.int16))
+        assert torch.equal(xs1, xs2)
+    assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
+
+
+def test_attention_with_rope_folded_in_rejects():
+    ops = _ops()
+    from sglang_security_amd.ops import SglkError
+    B, Hq, Hkv, D = 2, 8, 2, 128
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)
+    i32 = lambda *v: torch.tensor(v, dtype=torch.int32, device=DEV)
+    ws = ops.decode_shared_workspace(B, Hq, D, 4, DEV)
+    kb = z(8, Hkv, D, dt=torch.bfloat16)
+    o = z(B, Hq, D, dt=torch.bfloat16)
+    args = lambda cs: (z(1, B, (Hq + 2 * Hkv) * D), 1, B * (Hq + 2 * Hkv) * D, None, cs, z(B, dt=torch.int64),
+                       z(B, dt=torch.int64), kb, kb.clone(), o, i32(0, 2, 4), i32(1, 2, 1, 3), i32(0, 2), i32(1), ws, 4, 1.0,
+                       0.0, None)
+    with pytest.raises(SglkError):      # partial rotation
+        ops.decode_attention_shared_prefix_rope(*args(z(16, 64)))
+    with pytest.raises(SglkError):      # pairs (2p, 2p + 1)
+        ops.decode_attention_shared_prefix_rope(*args(z(16, 128)), interleave=True)
+
+
 def test_fused_decode_step_matches_unfused():
     """Two decoders with identical weights and batch: one runs the layer fusion, one the plain op sequence.  Both are
     fed the plain decoder's tokens after every step (a greedy pick between two logits one rounding apart may

@@ -20,6 +20,8 @@ ap.add_argument("--iters", type=int, default=64)
 ap.add_argument("--eager", action="store_true")
 ap.add_argument("--head-major", action="store_true",
                 help="experiment: pools laid out [Hkv][tokens][D] (a kv head's rows contiguous) instead of [tokens][Hkv][D]")
+ap.add_argument("--rope", action="store_true",
+                help="the launch that assembles q and the new K / V rows from split-K partial sums of the qkv projection")
 ap.add_argument("--stamps", action="store_true",
                 help="phase stamps of one launch (library built by ATTN=1 tools/build_abl.sh, named by SGLK_LIB)")
 args = ap.parse_args()
@@ -49,8 +51,20 @@ xs = torch.zeros(Hq, B, dtype=torch.float32, device=dev)
 sm = 1.0 / math.sqrt(D)
 
 
+row_len = (Hq + 2 * Hkv) * D
+qsplits = 4
+parts = [torch.randn(qsplits, B, row_len, device=dev, generator=gen) for _ in range(args.pools if args.rope else 0)]
+cos_sin = torch.randn(8192, D, device=dev, generator=gen)
+positions = torch.full((B,), P + Tl - 1, dtype=torch.int64, device=dev)
+loc = ind[(ptr[1:] - 1).long()].to(torch.int64)
+
+
 def run(i):
     kb, vb = pools[i % args.pools]
+    if args.rope:
+        ops.decode_attention_shared_prefix_rope(parts[i % args.pools], qsplits, B * row_len, None, cos_sin, positions, loc,
+                                                kb, vb, o, ptr, ind, gi, pls, ws, args.splits, sm, 0.0, xs)
+        return
     ops.decode_attention_shared_prefix_xs(q, kb, vb, o, ptr, ind, gi, pls, ws, args.splits, sm, 0.0, xs)
 
 

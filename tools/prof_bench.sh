@@ -1,12 +1,11 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of a short bench run on the GPU box; prints the top kernels.  usage: tools/prof_bench.sh tag [bench args]
+# Per-kernel statistics of the default bench under rocprofv3 (run on the GPU box): tools/prof_bench.sh <tag> [bench args]
 tag=$1; shift
-/usr/local/graft/bin/gpurun --timeout 900 -- "cd /tmp && export TMPDIR=/tmp && R=\$GRAFT_REPO_ROOT && timeout -k 10 400 rocprofv3 --kernel-trace --stats -d \$R/gpurun_out/$tag -o bench -- python3 \$R/bench.py --no-cpu-baseline --no-prefix-hit --steps 20 --warmup 4 $* > \$R/gpurun_out/$tag.log 2>&1; echo exit=\$?" 2>&1 | grep -E "exit=|GPU-minutes"
-python tools/rocpd_stats.py gpurun_out/$tag/bench_results.db > gpurun_out/$tag.csv
-python - "$tag" <<'PY'
-import csv, sys
-rows=list(csv.reader(open(f'gpurun_out/{sys.argv[1]}.csv')))[1:]
-for r in rows[:14]:
-    if 'spin_kernel' in r[0]: continue
-    print(r[0][:58].ljust(58), r[1].rjust(6), f"{float(r[3])/1e3:8.2f} us", f"{float(r[2])/26/1e3:8.1f} us/step")
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -o ${tag} -- python3 bench.py --no-cpu-baseline --no-prefix-hit --steps 20 --warmup 4 "$@" > gpurun_out/${tag}_under_rocprof.json 2> gpurun_out/${tag}.err
+python3 - <<PY
+import csv
+rows=list(csv.DictReader(open('gpurun_out/${tag}_prof/${tag}_kernel_stats.csv')))
+for r in rows[:12]:
+    print(f"{r['Name'][:80]:80s} {r['Calls']:>6s} {float(r['AverageNs'])/1e3:8.2f}us {r['Percentage']:>6s}%")
 PY
