@@ -649,6 +649,9 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   if ((int)blockIdx.x < n_prefix_blocks) {
     // ---- prefix block: index = ((grp * prefix_splits + split) * col_blocks + cb) * Hkv + kvh, so that the blocks of
     // one kv head are congruent modulo Hkv (with 8 kv heads: one XCD and its L2 per kv head)
+#ifdef SGLK_ATTN_PRIO
+    __builtin_amdgcn_s_setprio(3);  // every tail block waits for these: issue them ahead of the co-resident tail waves
+#endif
     int i = blockIdx.x;
     const int kvh = i % Hkv;
     i /= Hkv;

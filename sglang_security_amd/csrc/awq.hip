@@ -581,6 +581,15 @@ struct Wide {
 #ifndef SGLK_ABL
 #define SGLK_ABL 0
 #endif
+#if SGLK_ABL & 1024
+// per-wave cycle timeline of one steady-state stage (shader clock, s_memtime): [block][wave][16], word 15 = wall clock
+__device__ unsigned int g_timeline[256 * 8 * 16];
+#define SGLK_TL(k) tl[k] = (unsigned int)__builtin_readcyclecounter()
+#else
+#define SGLK_TL(k) \
+  do {             \
+  } while (0)
+#endif
 #if SGLK_ABL & 64
 __device__ long long g_stamps[256 * 24];
 #define SGLK_STAMP(k)                                                                             \
@@ -647,25 +656,50 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   }
   // four 1-KiB pieces as raw instructions in the scalar-base form (uniform 64-bit base in SGPRs, 32-bit lane offset,
   // instruction offset): through the builtin every piece costs two 64-bit vector adds for its address
-  auto glds_quad = [&](const char* src, char* dst, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3) {
+  // Look-ahead requests past the split's end are issued with every lane switched off (live = 0): the instruction
+  // still counts in vmcnt, so the counted waits hold for every stage, but nothing is fetched.  A short split (the o
+  // projection runs one stage per block) would otherwise fetch up to three stages for each one it multiplies, through
+  // an address unit that is the prologue's limit, and wait for them before its reduction.
+  auto live_mask = [&](int stage) -> uint64_t {
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(((SGLK_ABL & 16384) || stage < nst) ? -1 : 0);
+    uint64_t m = ((uint64_t)c << 32) | c;
+    asm volatile("" : "+s"(m));  // in a register pair, never a 64-bit literal
+    return m;
+  };
+  auto glds_quad = [&](const char* src, char* dst, uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, uint64_t live) {
     const uint32_t lds_addr = (uint32_t)(uintptr_t)(lds_void_ptr)dst;
+    uint64_t saved;
     asm volatile(
-        "s_mov_b32 m0, %0\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %5\n\t"
-        "global_load_lds_dwordx4 %2, %5 offset:1024\n\t"
-        "global_load_lds_dwordx4 %3, %5 offset:2048\n\t"
-        "global_load_lds_dwordx4 %4, %5 offset:3072"
-        :
-        : "s"(lds_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(src)
-        : "memory", "m0");
+        "s_mov_b32 m0, %1\n\t"
+        "s_and_saveexec_b64 %0, %7\n\t"
+        "global_load_lds_dwordx4 %2, %6\n\t"
+        "global_load_lds_dwordx4 %3, %6 offset:1024\n\t"
+        "global_load_lds_dwordx4 %4, %6 offset:2048\n\t"
+        "global_load_lds_dwordx4 %5, %6 offset:3072\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved)
+        : "s"(lds_addr), "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(src), "s"(live)
+        : "memory", "m0", "scc");
+  };
+  // one dword per lane to lds_dst + 4 * lane, per-lane 64-bit source address
+  auto glds4_live = [&](const void* src, char* dst, uint64_t live) {
+    const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uintptr_t)(lds_void_ptr)dst);
+    uint64_t saved;
+    asm volatile(
+        "s_mov_b32 m0, %1\n\t"
+        "s_and_saveexec_b64 %0, %3\n\t"
+        "global_load_lds_dword %2, off\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved)
+        : "s"(lds_addr), "v"(src), "s"(live)
+        : "memory", "m0", "scc");
   };
   auto issue_x = [&](int stage, int buf) {
     const char* src = reinterpret_cast<const char*>(x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK) - 3072;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024;
     // eight 1-KiB pieces, two LDS bases (the instruction offset reaches 4095)
-    glds_quad(src, dst, xoff[0], xoff[1], xoff[2], xoff[3]);
-    glds_quad(src, dst + 4096, xoff[4], xoff[5], xoff[6], xoff[7]);
+    glds_quad(src, dst, xoff[0], xoff[1], xoff[2], xoff[3], live_mask(0));
+    glds_quad(src, dst + 4096, xoff[4], xoff[5], xoff[6], xoff[7], live_mask(0));
     if constexpr (XS_EXT) {
       // this wave's group of the stage: 64 row sums, one per lane, into the wave's own slot
       const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
@@ -679,11 +713,13 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   auto issue_x_half = [&](int stage, int buf, int half) {
     const char* src = reinterpret_cast<const char*>(x + (int64_t)(st0 + min(stage, nst - 1)) * Wide::kStageK) - 3072;
     char* dst = smem + buf * Wide::kXStage + wid * 8 * 1024 + half * 4096;
-    glds_quad(src, dst, xoff[4 * half + 0], xoff[4 * half + 1], xoff[4 * half + 2], xoff[4 * half + 3]);
+    const uint64_t live = live_mask(stage);
+    glds_quad(src, dst, xoff[4 * half + 0], xoff[4 * half + 1], xoff[4 * half + 2], xoff[4 * half + 3], live);
     if constexpr (XS_EXT) {
       if (half == 1) {
         const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
-        glds4(xsum_in + (int64_t)gq * xs_stride + min(m0 + lane, M - 1), smem + Wide::kXsumOff + (buf * 8 + wid) * 256);
+        glds4_live(xsum_in + (int64_t)gq * xs_stride + min(m0 + lane, M - 1), smem + Wide::kXsumOff + (buf * 8 + wid) * 256,
+                   live);
       }
     }
     asm volatile("" ::: "memory");
@@ -696,7 +732,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     const int gq = (st0 + min(stage, nst - 1)) * 4 + kw;
     const void* src = sz_is_zero ? (const void*)(qzeros + (int64_t)gq * qcols + (n0 >> 3) + (lane - 32))
                                  : (const void*)(scales + (int64_t)gq * N + n0 + sz_col);
-    glds4(src, smem + Wide::kSzOff + (slot * 8 + wid) * 256);
+    glds4_live(src, smem + Wide::kSzOff + (slot * 8 + wid) * 256, live_mask(stage));
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -708,14 +744,18 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   const uint32_t wvoff = (uint32_t)((((int64_t)kw * nstrips + (n0 >> 4) + (r32 >> 4)) * 64 + i16 + 16 * h) * 16);
   auto load_w = [&](int stage, int4v(&w)[4]) {
     const char* src = reinterpret_cast<const char*>(packed) + (int64_t)(st0 + min(stage, nst - 1)) * 4 * nstrips * 1024;
+    uint64_t saved;
+    const uint64_t live = live_mask(stage);
     asm volatile(
-        "global_load_dwordx4 %0, %4, %5\n\t"
-        "global_load_dwordx4 %1, %4, %5 offset:512\n\t"
-        "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
-        "global_load_dwordx4 %3, %4, %5 offset:2560"
-        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3])
-        : "v"(wvoff), "s"(src)
-        : "memory");
+        "s_and_saveexec_b64 %4, %7\n\t"
+        "global_load_dwordx4 %0, %5, %6\n\t"
+        "global_load_dwordx4 %1, %5, %6 offset:512\n\t"
+        "global_load_dwordx4 %2, %5, %6 offset:2048\n\t"
+        "global_load_dwordx4 %3, %5, %6 offset:2560\n\t"
+        "s_mov_b64 exec, %4"
+        : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&s"(saved)
+        : "v"(wvoff), "s"(src), "s"(live)
+        : "memory", "scc");
     __builtin_amdgcn_sched_barrier(0);
   };
   // x(next) has landed once only sz and w issued after it (five operations) are outstanding; the weights named
@@ -763,6 +803,89 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     if (half == 0) xsumS[(buf * 4 + tile) * 64 + row] = part;
   };
 
+  // Per stage and wave, before its k-steps: read the group's scales and zeros, move R to the new unit, add the
+  // zero-point term.  Everything it reads was fetched by this wave's own DMA (scale / zero piece, block sums), so it
+  // needs no barrier, only the wave's own counted wait: waves 4-7 run it at the END of the previous stage (after that
+  // wait, before the barrier) and waves 0-3 at the start of the stage.  SIMD partners (waves w and w + 4) are then out
+  // of phase: one multiplies while the other rescales, instead of both idling the matrix pipe after each barrier.
+  uint32_t msk[2] = {nib_mask, nib_mask}, orc[2] = {or_const, or_const};  // dequantisation constants per column tile
+  auto prep = [&](int ws, int buf) {
+    int4v bz[2];   // B operand of the zero-point k-step
+    float nzo[2];  // -(OFF + z), vector-unit form
+    const char* szp = smem + Wide::kSzOff + (ws * 8 + wid) * 256;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int c = 32 * ct + r32;
+      const float s_in = Conv<T>::to_f32(*reinterpret_cast<const uint16_t*>(szp + 2 * c));
+      const uint32_t zw = *reinterpret_cast<const uint32_t*>(szp + 128 + 4 * (c >> 3));
+      // A zero (or denormal) scale cannot become the unit of R: that column keeps its unit and this group
+      // contributes nothing to it (its B operand and zero-point term are zeroed).
+      const bool ok = fabsf(s_in) >= 1.17549435e-38f;
+      const float sg = ok ? s_in : s_cur[ct];
+      const float ratio = s_cur[ct] * __builtin_amdgcn_rcpf(sg);
+      s_cur[ct] = sg;
+      const uint32_t z = (zw >> zsh) & 0xF;
+      msk[ct] = ok ? nib_mask : 0u;
+      orc[ct] = ok ? or_const : 0u;
+      if constexpr (ZPM) {
+        // -(OFF + z) as the 16-bit pattern of the operand type: sign bit on the dequantisation constant
+        const uint32_t nzb = ((AwqMagic<T>::kOr & 0xFFFFu) | 0x8000u) | z;
+        const bool okh = ok && h == 0;  // k-slots 0..2 belong to the lower half-wave
+        bz[ct] = int4v{okh ? (int)(nzb * 0x10001u) : 0, okh ? (int)nzb : 0, 0, 0};
+      } else {
+        nzo[ct] = ok ? -(AwqMagic<T>::kOff + (float)z) : 0.f;
+      }
+#pragma unroll
+      for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          if constexpr ((SGLK_ABL & 8192) != 0) {
+            // one plain multiply per register: the compiler otherwise pairs them into packed fp32 multiplies
+            float v = R[ct][rt][e];
+            asm("v_mul_f32 %0, %1, %0" : "+v"(v) : "v"(ratio));
+            R[ct][rt][e] = v;
+          } else if constexpr (!(SGLK_ABL & 16)) {
+            R[ct][rt][e] *= ratio;
+          }
+        }
+      if constexpr (SGLK_ABL & 16) asm volatile("" ::"v"(ratio));
+    }
+    const float* xp = xsumS + (XS_EXT ? (buf * 8 + wid) : (buf * 4 + kw)) * 64;
+    if constexpr (ZPM) {
+      // zero-point k-step: X[row] = a + b + c exactly, three values of the operand type
+#pragma unroll
+      for (int rt = 0; rt < MT; ++rt) {
+        const float X = xp[32 * rt + r32];
+        const uint32_t a = __float_as_uint(X) & 0xFFFF0000u;
+        const float r1 = X - __uint_as_float(a);
+        const uint32_t b = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(b);
+        const int4v ax = int4v{(int)((a >> 16) | b), (int)(__float_as_uint(r2) >> 16), 0, 0};
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) R[ct][rt] = AwqMagic<T>::mma32(ax, bz[ct], R[ct][rt]);
+      }
+    } else {
+      // zero-point term with this group's block sums on the vector unit: register e of a tile is row
+      // (e & 3) + 8 (e >> 2) + 4 h
+#pragma unroll
+      for (int rt = 0; rt < MT; ++rt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 32 * rt + 8 * j + 4 * h);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) R[ct][rt][4 * j + e] = fmaf(xs4[e], nzo[ct], R[ct][rt][4 * j + e]);
+        }
+    }
+    asm volatile("" ::: "memory");
+  };
+#if SGLK_ABL & 4096
+  const bool late = false;
+#else
+  const bool late = XS_EXT && wid >= 4;
+#endif
+
   int4v wreg[3][4];
   // prologue: sz(0), w(0), x(0), sz(1), w(1); then X(0)
   issue_sz(0, 0);
@@ -786,6 +909,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     asm volatile("" ::: "memory");
   }
 
+  if (late) prep(0, 0);
   SGLK_STAMP(1);
   // register set = unroll index mod 3, x buffer = unroll index mod 2: unrolled six times, every index is static
   const int npad = (nst + 5) / 6 * 6;
@@ -797,59 +921,15 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
       (void)kUnused;
       const int buf = u & 1;
       const int ws = u % 3;
+      [[maybe_unused]] unsigned int tl[16];
+#if SGLK_ABL & 1024
+      tl[14] = (unsigned int)wall_clock64();
+#endif
+      SGLK_TL(0);
       {
         const char* xt = smem + buf * Wide::kXStage;
-        // this stage's per-column scale and zero (landed two stages ago); rescale R to the new unit
-        uint32_t msk[2], orc[2];  // per-column-tile dequantisation constants (zeroed for a column whose scale is zero)
-        int4v bz[2];              // B operand of the zero-point k-step
-        float nzo[2];             // -(OFF + z), vector-unit form
-        {
-          const char* szp = smem + Wide::kSzOff + (ws * 8 + wid) * 256;
-#pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            const int c = 32 * ct + r32;
-            const float s_in = Conv<T>::to_f32(*reinterpret_cast<const uint16_t*>(szp + 2 * c));
-            const uint32_t zw = *reinterpret_cast<const uint32_t*>(szp + 128 + 4 * (c >> 3));
-            // A zero (or denormal) scale cannot become the unit of R: that column keeps its unit and this group
-            // contributes nothing to it (its B operand and zero-point term are zeroed).
-            const bool ok = fabsf(s_in) >= 1.17549435e-38f;
-            const float sg = ok ? s_in : s_cur[ct];
-            const float ratio = s_cur[ct] * __builtin_amdgcn_rcpf(sg);
-            s_cur[ct] = sg;
-            const uint32_t z = (zw >> zsh) & 0xF;
-            msk[ct] = ok ? nib_mask : 0u;
-            orc[ct] = ok ? or_const : 0u;
-            if constexpr (ZPM) {
-              // -(OFF + z) as the 16-bit pattern of the operand type: sign bit on the dequantisation constant
-              const uint32_t nzb = ((AwqMagic<T>::kOr & 0xFFFFu) | 0x8000u) | z;
-              const bool okh = ok && h == 0;  // k-slots 0..2 belong to the lower half-wave
-              bz[ct] = int4v{okh ? (int)(nzb * 0x10001u) : 0, okh ? (int)nzb : 0, 0, 0};
-            } else {
-              nzo[ct] = ok ? -(AwqMagic<T>::kOff + (float)z) : 0.f;
-            }
-#pragma unroll
-            for (int rt = 0; rt < MT; ++rt)
-#pragma unroll
-              for (int e = 0; e < 16; ++e)
-                if constexpr (!(SGLK_ABL & 16)) R[ct][rt][e] *= ratio;
-            if constexpr (SGLK_ABL & 16) asm volatile("" ::"v"(ratio));
-          }
-        }
-        const float* xp = xsumS + (XS_EXT ? (buf * 8 + wid) : (buf * 4 + kw)) * 64;
-        if constexpr (ZPM) {
-          // zero-point k-step: X[row] = a + b + c exactly, three values of the operand type
-#pragma unroll
-          for (int rt = 0; rt < MT; ++rt) {
-            const float X = xp[32 * rt + r32];
-            const uint32_t a = __float_as_uint(X) & 0xFFFF0000u;
-            const float r1 = X - __uint_as_float(a);
-            const uint32_t b = __float_as_uint(r1) & 0xFFFF0000u;
-            const float r2 = r1 - __uint_as_float(b);
-            const int4v ax = int4v{(int)((a >> 16) | b), (int)(__float_as_uint(r2) >> 16), 0, 0};
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) R[ct][rt] = AwqMagic<T>::mma32(ax, bz[ct], R[ct][rt]);
-          }
-        }
+        if (!late) prep(ws, buf);
+        SGLK_TL(1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
           int4v af[MT];
@@ -899,20 +979,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
             issue_sz(i + 2, (u + 2) % 3);
             load_w(i + 2, wreg[(u + 2) % 3]);
           }
-        }
-        if constexpr (!ZPM) {
-          // zero-point term with this group's block sums on the vector unit: register e of a tile is row
-          // (e & 3) + 8 (e >> 2) + 4 h
-#pragma unroll
-          for (int rt = 0; rt < MT; ++rt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float4v xs4 = *reinterpret_cast<const float4v*>(xp + 32 * rt + 8 * j + 4 * h);
-#pragma unroll
-              for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) R[ct][rt][4 * j + e] = fmaf(xs4[e], nzo[ct], R[ct][rt][4 * j + e]);
-            }
+          SGLK_TL(2 + s);
         }
       }
       SGLK_STAMP(2 + i);
@@ -923,11 +990,22 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
           SGLK_STAMP(16);
         }
       }
+      SGLK_TL(10);
       stage_wait(wreg[(u + 1) % 3]);  // x(i+1) and w(i+1) landed; sz(i+2), w(i+2) fly on
+      if (late) prep((u + 1) % 3, buf ^ 1);
+      SGLK_TL(11);
       if (i == 2) SGLK_STAMP(17);
       if constexpr (!(SGLK_ABL & 32)) __builtin_amdgcn_s_barrier();
+      SGLK_TL(12);
       if (i == 2) SGLK_STAMP(18);
       asm volatile("" ::: "memory");
+#if SGLK_ABL & 1024
+      if (i == 3 && lane == 0 && blin < 256) {
+        tl[15] = (unsigned int)wall_clock64();
+        for (int k = 0; k < 16; ++k) g_timeline[(blin * 8 + wid) * 16 + k] = tl[k];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+#endif
       if constexpr (!XS_EXT) {
         xsum_pass(buf ^ 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1404,6 +1482,11 @@ static int static_scratch(void** ptr) {
   return SGLK_OK;
 }
 
+#if SGLK_ABL & 1024
+__attribute__((visibility("default"))) int sglk_debug_read_timeline(void* dst) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_timeline), sizeof(unsigned int) * 256 * 8 * 16);
+}
+#endif
 #if SGLK_ABL & 64
 __attribute__((visibility("default"))) int sglk_debug_read_stamps(void* dst) {
   return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(long long) * 256 * 24);
