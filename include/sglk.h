@@ -101,7 +101,11 @@ SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const vo
  * workspace: sglk_decode_shared_workspace_bytes() bytes, 16-byte aligned.  Its first B * Hq + 1 int32 words
  * are counters: they must be ZERO when the workspace is first used (sglk_decode_shared_workspace_init clears
  * them; a zero-filled allocation does too) and every call leaves them zero.  Calls that overlap in time need
- * workspaces of their own. */
+ * workspaces of their own.
+ * The one-launch kernel covers 16-bit types with head size 128.  Every other shape sglk_decode_attention accepts
+ * (absorbed MLA 576 / 512 with the values a view of the key rows, head size 64, fp32) is routed to the per-request
+ * kernels over the same lists with max_kv_splits splits per request, their partials in the workspace: the same result,
+ * a group's shared rows fetched once per request (from L2 after the first). */
 SGLK_API int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits);
 SGLK_API int sglk_decode_shared_workspace_init(void* workspace, int B, int Hq, void* stream);
 SGLK_API int sglk_decode_shared_workspace_status(const void* workspace, int B, int Hq);

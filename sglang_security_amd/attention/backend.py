@@ -227,7 +227,7 @@ class SglkAttnBackend:
         vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
-        if md.prefix_groups is not None and layer.qk_head_dim == 128 and layer.v_head_dim == 128 and q.dtype != torch.float32:
+        if md.prefix_groups is not None:  # every shape: the library routes those without a tile kernel per request
             gi, pl = md.prefix_groups
             ops.decode_attention_shared_prefix(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, gi, pl, md.shared_workspace,
                                                self.max_kv_splits, layer.scaling, layer.logit_cap)

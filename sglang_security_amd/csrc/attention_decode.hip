@@ -159,6 +159,10 @@ __global__ void __launch_bounds__(256) common_prefix_kernel(const int32_t* __res
 }
 
 __global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
+__global__ void __launch_bounds__(256) fill_i32_kernel(int32_t* p, int32_t v, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
 
 // kv_indptr, num_kv_splits and kv_indices in one launch: block b finds its own offset (the sum of the lengths
 // before it) and gathers its row; block 0 also writes the offsets and the split counts.
@@ -1024,7 +1028,10 @@ static int64_t shared_counter_bytes(int B, int Hq) { return ((((int64_t)B * Hq +
 
 int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits) {
   if (B <= 0 || Hq <= 0 || Dv <= 0 || max_kv_splits <= 0) return 0;
-  return shared_counter_bytes(B, Hq) + (int64_t)B * Hq * max_kv_splits * (Dv + 1) * (int64_t)sizeof(float);
+  // counters, then partial outputs + log-sum-exps, then one split count per request (used by the shapes that take
+  // the per-request kernels)
+  return shared_counter_bytes(B, Hq) + (int64_t)B * Hq * max_kv_splits * (Dv + 1) * (int64_t)sizeof(float) +
+         (((int64_t)B * 4 + 255) / 256) * 256;
 }
 
 int sglk_decode_shared_workspace_init(void* workspace, int B, int Hq, void* stream) {
@@ -1065,10 +1072,24 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
                     aligned16(k_buffer) && aligned16(v_buffer) && aligned16(workspace) &&
                     (qp || (mult8(q_stride_b) && mult8(q_stride_h))) && mult8(k_stride_n) && mult8(k_stride_h) &&
                     mult8(v_stride_n) && mult8(v_stride_h);
-  if (!fast)
-    return fail(SGLK_EUNSUP, "decode_attention_shared_prefix: only 16-bit types with head size 128 (got D=%d Dv=%d dtype=%d)",
-                D, Dv, dtype);
   hipStream_t s = (hipStream_t)stream;
+  if (!fast) {
+    // Other shapes (absorbed MLA 576 / 512, head size 64, fp32): the same result from the per-request kernels over the
+    // same lists, with the groups ignored: a group's shared rows are then fetched once per request, from L2 after the
+    // first.  The workspace holds their partials ([B, Hq, S, Dv] + [B, Hq, S]) and one split count per request.
+    if (qp)
+      return fail(SGLK_EUNSUP, "decode_attention_shared_prefix_rope: only 16-bit types with head size 128 (got D=%d Dv=%d)",
+                  D, Dv);
+    SGLK_CHECK(aligned16(workspace), "decode_attention_shared_prefix: workspace must be 16-byte aligned");
+    float* logits = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
+    float* lse = logits + (int64_t)B * Hq * max_kv_splits * Dv;
+    int32_t* ns = reinterpret_cast<int32_t*>(lse + (int64_t)B * Hq * max_kv_splits);
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, ns, max_kv_splits, B);
+    SGLK_LAUNCH_CHECK();
+    return sglk_decode_attention_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, logits, lse, ns, max_kv_splits, B, Hq,
+                                    Hkv, D, Dv, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h,
+                                    o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
+  }
   const int heads = Hq / Hkv;
   // prefix splits: enough 64-column blocks to cover the CUs once, as far as max_kv_splits allows
   static const int env_sp = getenv("SGLK_SHARED_SPLITS") ? atoi(getenv("SGLK_SHARED_SPLITS")) : 0;

@@ -525,7 +525,7 @@ class LlamaDecoder:
     def enable_shared_prefix(self, on: bool = True) -> bool:
         """Route decode attention through the shared-prefix kernel: the batch is one group whose first
         prefix_len slots are the radix-tree hit every request shares (what RadixCache.match_prefix returned)."""
-        self.shared = bool(on) and getattr(self, "prefix_len", 0) > 0 and self.cfg.head_dim == 128
+        self.shared = bool(on) and getattr(self, "prefix_len", 0) > 0
         if self.shared:
             c = self.cfg
             self.group_indptr = torch.tensor([0, self.B], dtype=torch.int32, device=self.device)

@@ -240,17 +240,59 @@ def test_shared_prefix_full_size_matches_per_request_kernel():
     assert int(out.item()) == 1024
 
 
-def test_shared_prefix_unsupported_shape():
-    ops = _ops()
-    from sglang_security_amd import SglkError
+@pytest.mark.parametrize("dtype,Hq,Hkv,D,Dv", [(torch.bfloat16, 16, 1, 576, 512), (torch.bfloat16, 14, 2, 64, 64),
+                                              (torch.float32, 8, 2, 128, 128), (torch.float16, 4, 4, 96, 96)])
+def test_shared_prefix_other_shapes(dtype, Hq, Hkv, D, Dv):
+    """Shapes without a tile kernel (absorbed MLA 576 / 512 with the values a view of the key rows, head size 64, fp32)
+    go through the shared-prefix entry point too: the library runs the per-request kernels over the same lists, so the
+    result is the per-request result (against the oracle, and bit for bit against decode_attention_fwd with the same
+    split counts).  Two groups with different prefixes, ragged tails, two calls on one workspace."""
+    import oracle
 
-    q = torch.zeros(1, 4, 64, dtype=torch.bfloat16, device=DEV)
-    kb = torch.zeros(8, 4, 64, dtype=torch.bfloat16, device=DEV)
-    o = torch.zeros_like(q)
-    ws = torch.zeros(1 << 16, device=DEV)
-    i32 = lambda *v: torch.tensor(v, dtype=torch.int32, device=DEV)
-    with pytest.raises(SglkError):
-        ops.decode_attention_shared_prefix(q, kb, kb, o, i32(0, 3), i32(1, 2, 3), i32(0, 1), i32(2), ws, 4, 1.0)
+    ops = _ops()
+    gen = torch.Generator().manual_seed(Hq * 100 + D)
+    groups = [(3, 70), (2, 33)]  # (requests, shared prefix length)
+    tails = [5, 40, 1, 17, 64]
+    n = 1 + sum(p for _, p in groups) + sum(tails)
+    kb = torch.randn(n, Hkv, D, generator=gen).to(dtype)
+    mla = D == 576
+    vb = kb[..., :Dv] if mla else torch.randn(n, Hkv, Dv, generator=gen).to(dtype)
+    B = sum(r for r, _ in groups)
+    q = (torch.randn(B, Hq, D, generator=gen) * 0.5).to(dtype)
+    rows, nxt, gi, pl, b = [], 1, [0], [], 0
+    for r, p in groups:
+        shared = list(range(nxt, nxt + p))
+        nxt += p
+        for _ in range(r):
+            rows.append(shared + list(range(nxt, nxt + tails[b])))
+            nxt += tails[b]
+            b += 1
+        gi.append(b)
+        pl.append(p)
+    lens = [len(r) for r in rows]
+    ind = torch.tensor([s for r in rows for s in r], dtype=torch.int32)
+    ptr = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    S = 4
+    sm = 1.0 / math.sqrt(192 if mla else D)
+    ns = torch.full((B,), S, dtype=torch.int32)
+    want = oracle.decode_attention(q, kb, vb.contiguous(), ptr, ind, ns, sm)
+    kd = kb.to(DEV)
+    vd = kd[..., :Dv] if mla else vb.to(DEV)
+    ws = ops.decode_shared_workspace(B, Hq, Dv, S, DEV)
+    for _ in range(2):
+        o = torch.full((B, Hq, Dv), float("nan"), dtype=dtype, device=DEV)
+        ops.decode_attention_shared_prefix(q.to(DEV), kd, vd, o, ptr.to(DEV), ind.to(DEV),
+                                           torch.tensor(gi, dtype=torch.int32, device=DEV),
+                                           torch.tensor(pl, dtype=torch.int32, device=DEV), ws, S, sm)
+        torch.cuda.synchronize()
+        tol = 2e-2 if dtype == torch.bfloat16 else 4e-3 if dtype == torch.float16 else 2e-4
+        assert (o.float().cpu() - want.float()).abs().max().item() < tol
+    o2 = torch.empty_like(o)
+    al = torch.empty(B, Hq, S, Dv, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, S, dtype=torch.float32, device=DEV)
+    ops.decode_attention_fwd(q.to(DEV), kd, vd, o2, ptr.to(DEV), ind.to(DEV), al, lse, ns.to(DEV), S, sm, 0.0)
+    assert torch.equal(o, o2)
+    assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
 
 
 # ------------------------------------------------------------------------------------------ aiter call surface
