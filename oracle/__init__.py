@@ -473,8 +473,9 @@ def tree_speculative_sampling_target_only(candidates, retrive_index, retrive_nex
 
 
 # ---------------------------------------------------------------------------------------------- GPTQ int4
-def gptq_dequantize(qweight, qzeros, scales, group_size, zero_offset=1):
-    """w[k, n] = (q[k, n] - (z[k // G, n] + zero_offset)) * scales[k // G, n] in fp32, rounded to the scale dtype.
+def gptq_dequantize(qweight, qzeros, scales, group_size, zero_offset=1, g_idx=None):
+    """w[k, n] = (q[k, n] - (z[g(k), n] + zero_offset)) * scales[g(k), n] in fp32, rounded to the scale dtype, with
+    g(k) = k // G, or g_idx[k] for an activation-ordered (desc_act) checkpoint.
     Restates the published GPTQ checkpoint format (qweight int32 [K/8, N], nibble e of a word = row 8 * word + e;
     qzeros int32 [K/G, N/8], nibble j = column 8 * word + j; v1 stores zero points minus one).  PARITY UNPINNED: the
     reference delegates this arithmetic to vllm 0.8.4 (layers/quantization/gptq.py:18-31), which is not in the
@@ -484,7 +485,7 @@ def gptq_dequantize(qweight, qzeros, scales, group_size, zero_offset=1):
     sh = torch.arange(8, dtype=torch.int64) * 4
     q = ((qw.unsqueeze(1) >> sh.view(1, 8, 1)) & 0xF).reshape(-1, qw.shape[1])            # [K, N]
     z = ((qz.unsqueeze(2) >> sh.view(1, 1, 8)) & 0xF).reshape(qz.shape[0], -1) + zero_offset  # [K/G, N]
-    g = torch.arange(q.shape[0]) // group_size
+    g = torch.arange(q.shape[0]) // group_size if g_idx is None else g_idx.cpu().long()
     w = (q - z[g]).float() * scales.cpu().float()[g]
     return w.to(scales.dtype)
 

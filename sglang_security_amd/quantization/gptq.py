@@ -6,7 +6,10 @@ shapes and dtypes: qweight int32 [K/8, N], qzeros int32 [K/G, N/8], scales [K/G,
 arithmetic of the published format: w[k, n] = scales[g, n] * (q[k, n] - (zeros[g, n] + 1)) with g = k // G for v1
 checkpoints, zeros stored as they are for v2.  `process_weights_after_loading` re-lays the tensors out once into the
 form the AWQ kernels stream, so decode batches take the fused int4 kernel and prefill dequantises + multiplies, as
-for AWQ.  Activation reordering (desc_act with a g_idx that is not k // G) is not supported.
+for AWQ.  Activation reordering (desc_act: g_idx[k] names the group of input row k, in any order) is handled by one
+row permutation at load time: the rows are sorted by group (a stable sort, as the exllama shuffle of vllm's
+gptq_shuffle does), which makes every group 128 contiguous rows again, and `apply` gathers the activation columns in
+the same order before the product.
 """
 from __future__ import annotations
 
@@ -82,15 +85,27 @@ class GPTQLinearMethod:
         k, n = layer.qweight.shape[0] * cfg.pack_factor, layer.qweight.shape[1]
         group = getattr(layer, "sglk_group", cfg.group_size if cfg.group_size != -1 else k)
         g_idx = getattr(layer, "g_idx", None)
+        layer.sglk_perm = None
+        qweight = layer.qweight.data.contiguous()
         if g_idx is not None and g_idx.numel():
             plain = torch.arange(k, dtype=g_idx.dtype, device=g_idx.device) // group
             if not torch.equal(g_idx.data, plain):
-                raise NotImplementedError("GPTQ activation reordering (desc_act with a permuted g_idx) is not supported")
+                gi = g_idx.data.to(torch.int64)
+                if gi.numel() != k or int(gi.min()) < 0 or int(gi.max()) >= k // group or \
+                        not torch.all(torch.bincount(gi, minlength=k // group) == group):
+                    raise ValueError("GPTQ g_idx must assign exactly group_size input rows to every group")
+                perm = torch.argsort(gi, stable=True)
+                # unpack the eight rows of every word, reorder whole rows, pack again
+                sh = (torch.arange(8, device=qweight.device, dtype=torch.int64) * 4).view(1, 8, 1)
+                q = ((qweight.to(torch.int64).unsqueeze(1) >> sh) & 0xF).reshape(k, n).index_select(0, perm)
+                w = (q.reshape(k // 8, 8, n) << sh).sum(dim=1)
+                qweight = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+                layer.sglk_perm = perm
         if k % 128 != 0 or n % 64 != 0 or group % 128 != 0:
             raise NotImplementedError(f"GPTQ layer [{k}, {n}] with group size {group}: the int4 kernels need "
                                       "K % 128 == 0, N % 64 == 0 and a group size that is a multiple of 128")
         offset = 0 if cfg.checkpoint_format == "gptq_v2" else 1
-        packed, zeros = ops.gptq_repack(layer.qweight.data.contiguous(), layer.qzeros.data.contiguous(), group, offset)
+        packed, zeros = ops.gptq_repack(qweight, layer.qzeros.data.contiguous(), group, offset)
         layer.sglk_packed, layer.sglk_zeros = packed, zeros
         layer.scales = torch.nn.Parameter(layer.scales.data.contiguous(), requires_grad=False)
         layer.sglk_shape = (k, n)
@@ -111,6 +126,8 @@ class GPTQLinearMethod:
         k, n = layer.sglk_shape
         out_shape = x.shape[:-1] + (n,)
         x2 = x.reshape(-1, x.shape[-1])
+        if getattr(layer, "sglk_perm", None) is not None:
+            x2 = x2.index_select(1, layer.sglk_perm)  # activation columns in the order the rows were sorted into
         m = x2.shape[0]
         if 0 < m <= self.fused_max_tokens:
             out = ops.awq_gemm(x2.contiguous(), layer.sglk_packed, layer.scales, layer.sglk_zeros, bias, None,

@@ -67,7 +67,39 @@ def test_gptq_linear_method(M):
     torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2 * want.abs().max().item())
 
 
-def test_gptq_rejects_activation_reordering():
+@pytest.mark.parametrize("M", [3, 64, 300])
+def test_gptq_activation_reordering(M):
+    """desc_act: g_idx assigns the input rows to groups in a shuffled order.  The method sorts the rows by group once
+    and gathers the activation columns to match; the product equals x @ W of the format's restatement with that g_idx
+    (tolerances of the AWQ GEMM tests), and equals, bit for bit, the product of the same layer stored in group order
+    on the gathered activations."""
+    import oracle
+    from sglang_security_amd.quantization import GPTQConfig, GPTQLinearMethod
+
+    K, N, group = 512, 128, 128
+    qw, qz, sc = _gptq(K, N, group, torch.bfloat16, seed=7 + M)
+    g_idx = (torch.randperm(K, generator=torch.Generator().manual_seed(3)) // group).to(torch.int32)
+    method = GPTQLinearMethod(GPTQConfig(4, group, True))
+    layer = torch.nn.Module()
+    method.create_weights(layer, K, [N], K, N, torch.bfloat16, device=DEV)
+    layer.qweight.data.copy_(qw)
+    layer.qzeros.data.copy_(qz)
+    layer.scales.data.copy_(sc)
+    layer.g_idx.data.copy_(g_idx)
+    method.process_weights_after_loading(layer)
+    x = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16)
+    got = method.apply(layer, x.to(DEV)).float().cpu()
+    want = x.float() @ oracle.gptq_dequantize(qw, qz, sc, group, 1, g_idx).float()
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=2e-2 * want.abs().max().item())
+    # the dequantised, re-ordered weight is the restatement's rows in sorted order, bit for bit
+    from sglang_security_amd import ops
+    perm = torch.argsort(g_idx.long(), stable=True)
+    w_sorted = ops.awq_dequantize_packed(layer.sglk_packed, layer.scales, layer.sglk_zeros).cpu()
+    ref_rows = oracle.gptq_dequantize(qw, qz, sc, group, 1, g_idx)[perm]
+    assert torch.equal(w_sorted.view(torch.int16), ref_rows.view(torch.int16))
+
+
+def test_gptq_rejects_malformed_g_idx():
     from sglang_security_amd.quantization import GPTQConfig, GPTQLinearMethod
 
     K, N, group = 256, 64, 128
@@ -78,6 +110,8 @@ def test_gptq_rejects_activation_reordering():
     layer.qweight.data.copy_(qw)
     layer.qzeros.data.copy_(qz)
     layer.scales.data.copy_(sc)
-    layer.g_idx.data.copy_(torch.randperm(K).to(torch.int32) // group)
-    with pytest.raises(NotImplementedError, match="reordering"):
+    bad = torch.zeros(K, dtype=torch.int32)
+    bad[:100] = 1                                                          # 156 rows in group 0, 100 in group 1
+    layer.g_idx.data.copy_(bad)
+    with pytest.raises(ValueError, match="g_idx"):
         method.process_weights_after_loading(layer)
