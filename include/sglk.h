@@ -74,7 +74,10 @@ SGLK_API int sglk_decode_metadata(const int32_t* req_to_token, int64_t row_strid
  * fp32 and attn_lse [B,Hq,max_kv_splits] fp32, merged by LSE.
  * Replaces decode_attention_fwd, python/sglang/srt/layers/attention/triton_ops/decode_attention.py:682-733
  * (== decode_attention_cpu, sgl-kernel/csrc/cpu/decode.cpp:1064-1207, without its KV write).
- * Strides are in elements; the last dimension of every tensor is contiguous. */
+ * Strides are in elements; the last dimension of every tensor is contiguous.
+ * Matrix-core kernels serve 16-bit types with head size 128, head size 64 with an even number of contiguous kv heads
+ * (k_stride_h == v_stride_h == 64: pairs of kv heads are walked as one 128-element row) and the absorbed-MLA shape
+ * 576 / 512 with v_buffer a view of k_buffer; every other shape or stride takes a generic kernel. */
 SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o,
                                    const int32_t* kv_indptr, const int32_t* kv_indices,
                                    float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,

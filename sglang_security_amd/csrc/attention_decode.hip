@@ -351,13 +351,18 @@ __device__ __forceinline__ int tail_splits(int len, int max_splits) {
   return min(max(cdiv_i(len, 32), 1), max_splits);
 }
 
+// pair64 > 0: head size 64.  Two neighbouring kv heads of 64 elements are one 128-element pool row piece (the launcher
+// checks that they are contiguous) and are walked as ONE kv head of 128: Hkv counts such pairs, a pair's query heads are
+// the pair64 heads of its first kv head followed by the pair64 heads of its second.  A query row is placed in the half
+// of the 128-wide operand that faces its own kv head, the other half is zero, so S is exactly q . k of its own head;
+// O = P . [v_first, v_second] holds the head's output in the same half, which alone is stored (rows of 64).
 template <typename T>
 __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
     float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv,
     int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-    int64_t v_stride_h, float sm_scale, float logit_cap) {
+    int64_t v_stride_h, float sm_scale, float logit_cap, int pair64) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -384,8 +389,13 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
 
   WaveAttn<T> wa;
   wa.init();
-  wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
-                    : nullptr);
+  const int half = pair64 > 0 ? min(head_in_group / pair64, 1) : 0;
+  if (pair64 > 0)
+    wa.load_q_half(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                           : nullptr, half);
+  else
+    wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                      : nullptr);
   wa.run(kl, vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
          reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
          kv_indices + start, s0, s1, sm_scale, logit_cap);
@@ -397,11 +407,18 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   if (head_ok) {
     const float inv = 1.0f / lsum;
     const int64_t ob = ((int64_t)b * Hq + head) * max_kv_splits + split;
-    float* dst = attn_logits + ob * 128;
+    if (pair64 > 0) {
+      float* dst = attn_logits + ob * 64;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      // lane (hl, g) holds O[head][16n + 4g + r], r = 0..3
-      *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[n] * inv;
+      for (int n = 0; n < 8; ++n)
+        if ((n >> 2) == half) *reinterpret_cast<float4v*>(dst + 16 * (n & 3) + 4 * g) = oacc[n] * inv;
+    } else {
+      float* dst = attn_logits + ob * 128;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        // lane (hl, g) holds O[head][16n + 4g + r], r = 0..3
+        *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[n] * inv;
+      }
     }
     if (g == 0) attn_lse[ob] = (m + log2f(lsum)) * 0.6931471805599453f;
   }
@@ -957,6 +974,11 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
                     aligned16(k_buffer) && aligned16(v_buffer) && aligned16(attn_logits) && (q_stride_b % 8 == 0) &&
                     (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) && (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) &&
                     (v_stride_h % 8 == 0);
+  // head size 64 with an even number of kv heads whose rows are contiguous: pairs of kv heads on the 128-wide kernel
+  const bool pair64 = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 64 && Dv == 64 && Hkv % 2 == 0 &&
+                      k_stride_h == 64 && v_stride_h == 64 && aligned16(q) && aligned16(k_buffer) && aligned16(v_buffer) &&
+                      aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
+                      (v_stride_n % 8 == 0);
   // absorbed MLA: V is a view of the first 512 elements of the 576-element K rows (memory_pool.py:492-521)
   const bool mla = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == kMlaD && Dv == kMlaDv && v_buffer == k_buffer &&
                    v_stride_n == k_stride_n && v_stride_h == k_stride_h && aligned16(q) && aligned16(k_buffer) &&
@@ -977,7 +999,17 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
                        hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer,
                                           v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
                                           max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap));
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, 0));
+  } else if (pair64) {
+    // head size 64 on the 128-wide tile kernel: Hkv / 2 pairs of kv heads, 2 * group query heads per pair
+    const int head_tiles = (2 * group + 15) / 16;
+    dim3 grid(B, (Hkv / 2) * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
+    const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave;
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer,
+                                          v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                                          max_kv_splits, Hq, Hkv / 2, head_tiles, q_stride_b, q_stride_h, k_stride_n,
+                                          (int64_t)128, v_stride_n, (int64_t)128, sm_scale, logit_cap, group));
   } else {
     dim3 grid(B, Hq, max_kv_splits);
     const size_t lds = (size_t)D * sizeof(float);

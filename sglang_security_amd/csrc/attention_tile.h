@@ -395,6 +395,18 @@ struct WaveAttn {
     }
   }
 
+  // a 64-element query row in half `half` of the 128-wide operand, zeros in the other half
+  __device__ __forceinline__ void load_q_half(const uint16_t* qrow, int half) {
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (qrow && (ks >> 1) == half)
+        qf[ks] = *reinterpret_cast<const short8*>(qrow + 32 * (ks & 1) + 8 * g);
+      else
+        qf[ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
   // Rows of one tile on their way from the pool to LDS: instruction i covers rows 4i + g.
   struct Rows {
     int4v k[8], v[8];

@@ -215,6 +215,44 @@ def test_decode_attention_vs_oracle(dtype, B, Hq, Hkv, prefix, max_splits):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Hq,Hkv,prefix,max_splits", [(5, 14, 2, 96, 8), (3, 8, 4, 10, 4), (2, 64, 2, 300, 16),
+                                                        (4, 16, 16, 0, 8), (3, 40, 8, 33, 8)])
+def test_decode_attention_head64_pairs_vs_oracle(dtype, B, Hq, Hkv, prefix, max_splits):
+    """Head size 64 with an even number of contiguous kv heads: pairs of kv heads are walked as one 128-element row on
+    the matrix-core kernel (query rows zero-padded into their head's half).  Against the C oracle, and against the
+    generic kernel, which a pool whose heads are not contiguous selects (Qwen2-0.5B's 14 / 2 heads, MHA, a GQA group of
+    32 = four head tiles per pair, ragged lengths)."""
+    import oracle
+
+    ops = _ops()
+    q, kb, vb, r2t, seq = _synthetic_batch(B, Hq, Hkv, 64, prefix, 1, 200, dtype, seed=B + Hq)
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(seq, 0)
+    ind = oracle.create_kv_indices(r2t, torch.arange(B), seq, ptr)
+    ns_d = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.get_num_kv_splits(ns_d, seq.to(DEV), Hq, Hkv, max_splits, 256)
+    ns = ns_d.cpu()
+    sm = 1.0 / math.sqrt(64)
+    want = oracle.decode_attention(q, kb, vb, ptr, ind, ns, sm)
+    g = dict(q=q, k_buffer=kb, v_buffer=vb, kv_indptr=ptr, kv_indices=ind, num_kv_splits=ns, sm_scale=sm,
+             logit_cap=0.0)
+    o = _run_decode(ops, g, dtype, max_splits)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o).all()
+    assert (o - want).abs().max().item() < tol
+    # the same through the generic kernel: pools padded to a head stride of 72 elements are not pairable
+    pad = lambda t: torch.nn.functional.pad(t.to(dtype), (0, 8)).to(DEV)[..., :64]
+    kd, vd = pad(kb), pad(vb)
+    assert kd.stride(1) == 72
+    o2 = torch.zeros(B, Hq, 64, dtype=dtype, device=DEV)
+    al = torch.empty(B, Hq, max_splits, 64, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, max_splits, dtype=torch.float32, device=DEV)
+    ops.decode_attention_fwd(q.to(dtype).to(DEV), kd, vd, o2, ptr.to(DEV), ind.to(DEV), al, lse, ns.to(DEV), max_splits,
+                             sm, 0.0)
+    assert (o - o2.float().cpu()).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Hq,max_len,max_splits,cap", [(3, 16, 70, 4, 0.0), (4, 128, 500, 8, 0.0), (2, 24, 1300, 16, 30.0),
                                                         (5, 16, 31, 2, 0.0)])
 def test_decode_attention_mla(dtype, B, Hq, max_len, max_splits, cap):

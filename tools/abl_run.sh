@@ -1,6 +1,2 @@
-echo > gpurun_out/abl7.log
-for a in base 16384 base 16384 base 16384; do
-  echo "== $a" >> gpurun_out/abl7.log
-  lib=tools/libsglk_abl$a.so; [ $a = base ] && lib=sglang_security_amd/libsglk.so
-  SGLK_LIB=$lib timeout -k 10 120 python tools/bench_gemm.py --fused --iters 40 >> gpurun_out/abl7.log 2>&1 || exit 1
-done
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02_ttft_prof -o ttft -- python3 tools/bench_ttft.py > gpurun_out/r02_ttft.json 2> gpurun_out/r02_ttft.err
