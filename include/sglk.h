@@ -189,6 +189,27 @@ SGLK_API int sglk_extend_attention_masked(const void* q_extend, const void* k_ex
                                           int64_t v_stride_n, int64_t v_stride_h, int max_extend_len,
                                           float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* sglk_extend_attention for a sliding-window layer (extend_attention.py:179-184,323 as called by
+ * triton_backend.py:759-790).  The caller lists, as the reference's backend does (update_sliding_window_buffer,
+ * triton_backend.py:75-103), only the last min(prefix_len, window + 1) prefix tokens of every request in kv_indices;
+ * in the stage over that list row i of the request's extend sees listed token n iff i <= n + sliding_window_size
+ * (both counted from zero: the reference's formula, kept as it stands); the stage over the new tokens is causal (or
+ * custom_mask, if given: same meaning as in sglk_extend_attention_masked, its prefix columns being the listed ones)
+ * without a window term, as in the reference.  sliding_window_size <= 0: no window.  Served by the wave-per-row
+ * kernel. */
+SGLK_API int sglk_extend_attention_window(const void* q_extend, const void* k_extend, const void* v_extend,
+                                          void* o_extend, const void* k_buffer, const void* v_buffer,
+                                          const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                          const int32_t* kv_indices, const uint8_t* custom_mask,
+                                          const int64_t* mask_indptr, int skip_prefix_custom_mask,
+                                          int sliding_window_size, int B, int Hq, int Hkv, int D, int Dv,
+                                          int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                          int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h,
+                                          int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n,
+                                          int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                          int max_extend_len, float sm_scale, float logit_cap, int causal,
+                                          int dtype, void* stream);
+
 /* Paged prefill: like sglk_extend_attention, but the new tokens are already in the pool and kv_indices lists
  * every token of each sequence (prefix + new); with causal != 0 query row i of a sequence with q_len rows and
  * kv_len tokens sees tokens 0 .. kv_len - q_len + i.  This is the form the reference's ROCm default backend

@@ -490,6 +490,24 @@ def gptq_dequantize(qweight, qzeros, scales, group_size, zero_offset=1, g_idx=No
     return w.to(scales.dtype)
 
 
+def extend_attention_window(q_ext, k_ext, v_ext, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, window,
+                            sm_scale, logit_cap=0.0):
+    """extend_attention_fwd with SLIDING_WINDOW_SIZE = window (triton_ops/extend_attention.py:179-184): in the stage over
+    the listed prefix, row i of a request's extend sees listed token n iff i <= n + window; the new tokens are causal.
+    Expressed as a mask for extend_attention_masked below."""
+    qo, kp = qo_indptr.tolist(), kv_indptr.tolist()
+    masks, mptr = [], [0]
+    for b in range(len(qo) - 1):
+        ext, pre = qo[b + 1] - qo[b], kp[b + 1] - kp[b]
+        i = torch.arange(ext).view(-1, 1)
+        allow = torch.cat([i <= torch.arange(pre).view(1, -1) + window, i >= torch.arange(ext).view(1, -1)], dim=1)
+        masks.append(allow.flatten())
+        mptr.append(mptr[-1] + allow.numel())
+    mask = torch.cat(masks).to(torch.uint8)
+    return extend_attention_masked(q_ext, k_ext, v_ext, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, mask,
+                                   torch.tensor(mptr, dtype=torch.int64), False, sm_scale, logit_cap)
+
+
 # ---------------------------------------------------------------------------------------------- masked extend
 def extend_attention_masked(q_ext, k_ext, v_ext, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, custom_mask,
                             mask_indptr, skip_prefix_custom_mask, sm_scale, logit_cap=0.0):

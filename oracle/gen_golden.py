@@ -250,6 +250,38 @@ def gen_extend_masked(tri):
             expect_triton_f32=o_t))
 
 
+def gen_extend_window(tri):
+    """extend_attention_fwd with sliding_window_size > 0, called as triton_backend.py:759-790 calls it: kv_indices lists
+    only the last min(prefix_len, window + 1) prefix tokens of each request (update_sliding_window_buffer, :75-103)."""
+    torch.manual_seed(11)
+    cases = [("w8", 3, 8, 2, 128, 128, [40, 3, 0], [33, 20, 12], 8), ("w4_h64", 2, 4, 4, 64, 64, [17, 9], [9, 30], 4)]
+    for tag, B, Hq, Hkv, D, Dv, pre, ext, W in cases:
+        n = sum(pre) + sum(ext) + 5
+        kb, vb = _mk_pool(n, Hkv, D, Dv, torch.bfloat16)
+        T = sum(ext)
+        q = torch.randn(T, Hq, D).to(torch.bfloat16)
+        ke, ve = torch.randn(T, Hkv, D).to(torch.bfloat16), torch.randn(T, Hkv, Dv).to(torch.bfloat16)
+        perm = torch.randperm(n - 1) + 1
+        wpre = [min(p, W + 1) for p in pre]
+        qo = torch.zeros(B + 1, dtype=torch.int32)
+        qo[1:] = torch.cumsum(torch.tensor(ext), 0)
+        kp = torch.zeros(B + 1, dtype=torch.int32)
+        kp[1:] = torch.cumsum(torch.tensor(wpre), 0)
+        rows, off = [], 0
+        for b in range(B):
+            full = perm[off: off + pre[b]]
+            off += pre[b]
+            rows.append(full[pre[b] - wpre[b]:])
+        ki = torch.cat(rows).to(torch.int32) if sum(wpre) else torch.zeros(0, dtype=torch.int32)
+        sm = 1.0 / math.sqrt(D)
+        o_t = torch.zeros(T, Hq, Dv)
+        tri.extend_attention_fwd(q.float(), ke.float(), ve.float(), o_t, kb.float(), vb.float(), qo, kp, ki,
+                                 None, True, None, max(ext), sm, 0.0, sliding_window_size=W)
+        save(f"extend_window_{tag}", dict(
+            q_extend=q, k_extend=ke, v_extend=ve, k_buffer=kb, v_buffer=vb, qo_indptr=qo, kv_indptr=kp, kv_indices=ki,
+            window=W, sm_scale=sm, expect_triton_f32=o_t))
+
+
 def gen_merge_state(tri):
     torch.manual_seed(42)
     m = load_test_module("sgl-kernel/tests/test_merge_state_v2.py", "ref_test_merge_state_v2") \
@@ -682,6 +714,8 @@ def main():
         gen_extend(tri, ops)
     if want("extend_masked"):
         gen_extend_masked(tri)
+    if want("extend_window"):
+        gen_extend_window(tri)
     if want("merge"):
         gen_merge_state(tri)
     if want("awq"):

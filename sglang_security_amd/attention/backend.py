@@ -46,6 +46,10 @@ class ForwardMetadata:
     mask_indptr: Optional[torch.Tensor] = None
     prefix_groups: Optional[tuple] = None
     shared_workspace: Optional[torch.Tensor] = None
+    # sliding-window layers (triton_backend.py:146-148)
+    window_kv_indptr: Optional[torch.Tensor] = None
+    window_kv_indices: Optional[torch.Tensor] = None
+    window_num_kv_splits: Optional[torch.Tensor] = None
 
 
 class SglkAttnBackend:
@@ -69,6 +73,11 @@ class SglkAttnBackend:
         self.device_core_count = int(lib().sglk_device_cu_count())
         self.max_context_len = self.req_to_token.shape[1]
         self.forward_metadata: Optional[ForwardMetadata] = None
+        # triton_backend.py:175-199: models with sliding-window layers list, beside the full sequences, the last
+        # window + 1 tokens of every request
+        sw = getattr(model_runner, "sliding_window_size", None)
+        self.sliding_window_size = int(sw) if sw is not None and sw > 0 else None
+        self.window_kv_indptr = torch.zeros_like(self.kv_indptr) if self.sliding_window_size else None
 
     # ---- metadata ------------------------------------------------------------------------------------------
     def get_num_kv_splits(self, num_kv_splits: torch.Tensor, seq_lens: torch.Tensor):
@@ -86,11 +95,23 @@ class SglkAttnBackend:
         num_kv_splits = torch.empty((bs,), dtype=torch.int32, device=self.device)
         return attn_logits, attn_lse, num_kv_splits
 
+    def _window_lists(self, lens: torch.Tensor, req_pool_indices: torch.Tensor, bs: int, indices_out=None):
+        """update_sliding_window_buffer (triton_backend.py:75-131): the last min(len, window + 1) slots of every
+        request.  Returns (window_kv_indptr[: bs + 1], window_kv_indices, window_kv_lens)."""
+        lens = lens[:bs]
+        wlens = torch.clamp(lens, max=self.sliding_window_size + 1)
+        ops.kv_indptr_cumsum(wlens, self.window_kv_indptr)
+        indptr = self.window_kv_indptr[: bs + 1]
+        if indices_out is None:
+            indices_out = torch.empty(max(bs * (self.sliding_window_size + 1), 1), dtype=torch.int32, device=self.device)
+        ops.create_kv_indices(self.req_to_token, req_pool_indices[:bs], wlens, indptr, lens - wlens, indices_out)
+        return indptr, indices_out, wlens
+
     def _shared_workspace(self, bs: int):
         return ops.decode_shared_workspace(bs, self.num_head, self.v_head_dim, self.max_kv_splits, self.device)
 
     def init_forward_metadata(self, forward_batch):
-        """triton_backend.py:271-446 (no sliding window)."""
+        """triton_backend.py:271-446."""
         bs = forward_batch.batch_size
         kv_indptr = self.kv_indptr
         spec_info = getattr(forward_batch, "spec_info", None)
@@ -112,6 +133,12 @@ class SglkAttnBackend:
             self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
                                                     None, prefix_groups=groups,
                                                     shared_workspace=self._shared_workspace(bs) if groups else None)
+            if self.sliding_window_size and spec_info is None:  # :297-316
+                wp, wi, wl = self._window_lists(forward_batch.seq_lens, forward_batch.req_pool_indices, bs)
+                wsplits = torch.empty((bs,), dtype=torch.int32, device=self.device)
+                self.get_num_kv_splits(wsplits, wl)
+                md = self.forward_metadata
+                md.window_kv_indptr, md.window_kv_indices, md.window_num_kv_splits = wp, wi, wsplits
             return
         if is_mode("is_target_verify"):
             # :338-374: every request scores num_draft_tokens tree nodes against its whole cached sequence; the tree's
@@ -159,6 +186,9 @@ class SglkAttnBackend:
         qo_indptr = qo_indptr[: bs + 1]
         max_extend_len = int(forward_batch.extend_seq_lens.max().item())
         self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+        if self.sliding_window_size:  # :412-421: the window over the cached prefix
+            wp, wi, _ = self._window_lists(forward_batch.extend_prefix_lens, forward_batch.req_pool_indices, bs)
+            self.forward_metadata.window_kv_indptr, self.forward_metadata.window_kv_indices = wp, wi
 
     # ---- graph capture: metadata lives at fixed addresses, refreshed by one launch per replay -----------------
     def init_cuda_graph_state(self, max_bs: int, kv_indices_buf: Optional[torch.Tensor] = None):
@@ -168,6 +198,11 @@ class SglkAttnBackend:
         self.cuda_graph_kv_indices = kv_indices_buf if kv_indices_buf is not None else torch.zeros(
             (max_bs * self.max_context_len,), dtype=torch.int32, device=self.device)
         self.cuda_graph_shared_workspace = self._shared_workspace(max_bs)
+        if self.sliding_window_size:  # :480-490 (window + 1 slots per request: what update_sliding_window_buffer lists)
+            self.cuda_graph_window_kv_indices = torch.zeros((max_bs * (self.sliding_window_size + 1),), dtype=torch.int32,
+                                                            device=self.device)
+            self.cuda_graph_window_num_kv_splits = torch.full((max_bs,), self.max_kv_splits, dtype=torch.int32,
+                                                              device=self.device)
 
     def init_forward_metadata_capture_cuda_graph(self, bs: int, num_tokens: int, req_pool_indices: torch.Tensor,
                                                  seq_lens: torch.Tensor, encoder_lens=None, forward_mode=None,
@@ -182,6 +217,12 @@ class SglkAttnBackend:
                                                 self.cuda_graph_num_kv_splits, self.kv_indptr, self.cuda_graph_kv_indices,
                                                 None, prefix_groups=prefix_groups,
                                                 shared_workspace=self.cuda_graph_shared_workspace)
+        if self.sliding_window_size:  # :523-541
+            wp, wi, wl = self._window_lists(seq_lens, req_pool_indices, bs, self.cuda_graph_window_kv_indices)
+            self.get_num_kv_splits(self.cuda_graph_window_num_kv_splits[:bs], wl)
+            md = self.forward_metadata
+            md.window_kv_indptr, md.window_kv_indices = self.window_kv_indptr, wi
+            md.window_num_kv_splits = self.cuda_graph_window_num_kv_splits
 
     def init_forward_metadata_replay_cuda_graph(self, bs: int, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
                                                 seq_lens_sum: int, encoder_lens=None, forward_mode=None, spec_info=None,
@@ -190,6 +231,9 @@ class SglkAttnBackend:
         ops.decode_metadata(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
                             self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head,
                             self.max_kv_splits, self.device_core_count)
+        if self.sliding_window_size:  # :656-675
+            _, _, wl = self._window_lists(seq_lens, req_pool_indices, bs, self.cuda_graph_window_kv_indices)
+            self.get_num_kv_splits(self.cuda_graph_window_num_kv_splits[:bs], wl)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -207,13 +251,24 @@ class SglkAttnBackend:
             else torch.empty_like(q)
         if save_kv_cache:
             forward_batch.token_to_kv_pool.set_kv_buffer(layer, forward_batch.out_cache_loc, k, v)
+        kv_indptr, kv_indices, window = md.kv_indptr, md.kv_indices, -1
+        if self._windowed(layer):  # :759-768
+            if md.window_kv_indptr is None:
+                raise SglkError("sliding-window layer, but model_runner.sliding_window_size was not set")
+            kv_indptr, kv_indices, window = md.window_kv_indptr, md.window_kv_indices, layer.sliding_window_size
         ops.extend_attention_fwd(
             q.view(-1, layer.tp_q_head_num, layer.qk_head_dim), k.contiguous().view(-1, layer.tp_k_head_num, layer.qk_head_dim),
             v.contiguous().view(-1, layer.tp_k_head_num, layer.v_head_dim), o.view(-1, layer.tp_q_head_num, layer.v_head_dim),
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
-            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id), md.qo_indptr, md.kv_indptr, md.kv_indices,
-            md.custom_mask, True, md.mask_indptr, md.max_extend_len, layer.scaling, layer.logit_cap)
+            forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id), md.qo_indptr, kv_indptr, kv_indices,
+            md.custom_mask, True, md.mask_indptr, md.max_extend_len, layer.scaling, layer.logit_cap,
+            sliding_window_size=window)
         return o
+
+    @staticmethod
+    def _windowed(layer) -> bool:
+        sw = getattr(layer, "sliding_window_size", None)
+        return sw is not None and sw > -1
 
     def forward_decode(self, q, k, v, layer, forward_batch, save_kv_cache: bool = True):
         """triton_backend.py:790-835."""
@@ -227,7 +282,12 @@ class SglkAttnBackend:
         vb = forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id)
         q3 = q.view(-1, layer.tp_q_head_num, layer.qk_head_dim)
         o3 = o.view(-1, layer.tp_q_head_num, layer.v_head_dim)
-        if md.prefix_groups is not None:  # every shape: the library routes those without a tile kernel per request
+        if self._windowed(layer):  # :814-816: the window's slots instead of the whole sequence
+            if md.window_kv_indptr is None:
+                raise SglkError("sliding-window layer, but model_runner.sliding_window_size was not set")
+            ops.decode_attention_fwd(q3, kb, vb, o3, md.window_kv_indptr, md.window_kv_indices, md.attn_logits, md.attn_lse,
+                                     md.window_num_kv_splits, self.max_kv_splits, layer.scaling, layer.logit_cap)
+        elif md.prefix_groups is not None:  # every shape: the library routes those without a tile kernel per request
             gi, pl = md.prefix_groups
             ops.decode_attention_shared_prefix(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, gi, pl, md.shared_workspace,
                                                self.max_kv_splits, layer.scaling, layer.logit_cap)

@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
     int64_t ke_stride_t, int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
     int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
     float logit_cap, int causal, const uint8_t* __restrict__ custom_mask, const int64_t* __restrict__ mask_indptr,
-    int skip_prefix_mask) {
+    int skip_prefix_mask, int window) {
   extern __shared__ float qs[];  // D floats
   const int b = blockIdx.z, h = blockIdx.y, qi = blockIdx.x;
   const int q0 = qo_indptr[b];
@@ -158,7 +158,10 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
       }
     }
     float s = -INFINITY;
-    const bool shown = valid && (!mrow || (in_prefix && skip_prefix_mask) || mrow[tok] != 0);
+    // sliding window, as the reference masks it (extend_attention.py:179-184): only in the stage over the listed
+    // prefix, row qi of the extend sees listed prefix token n iff qi <= n + window
+    const bool in_window = !(window > 0 && in_prefix && !paged) || qi <= tok + window;
+    const bool shown = valid && in_window && (!mrow || (in_prefix && skip_prefix_mask) || mrow[tok] != 0);
     if (shown) {
       s = 0.f;
       for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(kp, kb + d);
@@ -206,7 +209,7 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                                  int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
                                  int max_extend_len, float sm_scale, float logit_cap, int causal, int dtype, void* stream,
                                  bool paged, const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
-                                 int skip_prefix_mask = 1) {
+                                 int skip_prefix_mask = 1, int window = 0) {
   SGLK_CHECK(!custom_mask || (mask_indptr && !paged), "extend_attention: a custom mask needs mask_indptr and new K/V");
   SGLK_CHECK(q_extend && o_extend && qo_indptr && kv_indptr && (paged || (k_extend && v_extend)),
              "extend_attention: null pointer");
@@ -221,7 +224,7 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
   if (paged) k_extend = v_extend = nullptr;  // the kernels take a null k_extend as "every token is in the pool"
   hipStream_t s = (hipStream_t)stream;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
-  const bool fast = !custom_mask && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
+  const bool fast = !custom_mask && window <= 0 && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
                     (paged || (aligned16(k_extend) && aligned16(v_extend))) && aligned16(k_buffer) && aligned16(v_buffer) &&
                     ((uintptr_t)o_extend % 8 == 0) && mult8(q_stride_t) && mult8(q_stride_h) && mult8(ke_stride_t) &&
                     mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && mult8(k_stride_n) &&
@@ -255,7 +258,7 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                      k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, D, Dv, q_stride_t, q_stride_h,     \
                      ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,           \
                      k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, custom_mask, mask_indptr,        \
-                     skip_prefix_mask)
+                     skip_prefix_mask, window)
     SGLK_DISPATCH_FLOAT(dtype, T, {
       if (per_lane <= 1) {
         SGLK_GEN(1);
@@ -305,6 +308,24 @@ extern "C" int sglk_extend_attention_masked(const void* q_extend, const void* k_
                                o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
                                sm_scale, logit_cap, 1, dtype, stream, false, custom_mask, mask_indptr,
                                skip_prefix_custom_mask ? 1 : 0);
+}
+
+extern "C" int sglk_extend_attention_window(const void* q_extend, const void* k_extend, const void* v_extend,
+                                            void* o_extend, const void* k_buffer, const void* v_buffer,
+                                            const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                            const uint8_t* custom_mask, const int64_t* mask_indptr,
+                                            int skip_prefix_custom_mask, int sliding_window_size, int B, int Hq, int Hkv,
+                                            int D, int Dv, int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                            int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h,
+                                            int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                            int64_t v_stride_n, int64_t v_stride_h, int max_extend_len, float sm_scale,
+                                            float logit_cap, int causal, int dtype, void* stream) {
+  SGLK_CHECK(!custom_mask || mask_indptr, "extend_attention_window: a custom mask needs mask_indptr");
+  return extend_attention_impl(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                               B, Hq, Hkv, D, Dv, q_stride_t, q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h,
+                               o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
+                               sm_scale, logit_cap, custom_mask ? 1 : causal, dtype, stream, false, custom_mask, mask_indptr,
+                               skip_prefix_custom_mask ? 1 : 0, sliding_window_size > 0 ? sliding_window_size : 0);
 }
 
 extern "C" int sglk_prefill_attention_paged(const void* q, void* o, const void* k_buffer, const void* v_buffer,

@@ -174,20 +174,32 @@ def decode_attention_shared_prefix(q, k_buffer, v_buffer, o, kv_indptr, kv_indic
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
                          kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale=None,
                          logit_cap=0.0, skip_prefix_custom_mask=True, sliding_window_size=-1):
-    """Same signature as triton_ops/extend_attention.py:306-438; sliding window unsupported."""
-    if sliding_window_size is not None and sliding_window_size > 0:
-        raise SglkError("extend_attention: sliding window is not supported")
+    """Same signature as triton_ops/extend_attention.py:306-438.  With sliding_window_size > 0 the caller lists only the
+    window's prefix tokens in kv_indices (triton_backend.py:75-103) and the reference's window mask applies to them."""
     _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
     T, Hq, D = q_extend.shape
     Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
     if sm_scale is None:
         sm_scale = 1.0 / (D ** 0.5)
     B = qo_indptr.shape[0] - 1
+    m8 = None
     if custom_mask is not None:
         _need_gpu(custom_mask, mask_indptr)
         m8 = custom_mask.view(torch.uint8) if custom_mask.dtype == torch.bool else custom_mask
         if m8.dtype != torch.uint8 or not m8.is_contiguous() or mask_indptr.dtype != torch.int64 or mask_indptr.numel() != B + 1:
             raise SglkError("extend_attention: custom_mask must be contiguous uint8 / bool, mask_indptr int64 [B + 1]")
+    if sliding_window_size is not None and sliding_window_size > 0:
+        check(lib().sglk_extend_attention_window(
+            _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
+            _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _ptr(m8) if m8 is not None else None,
+            _ptr(mask_indptr) if m8 is not None else None, 1 if skip_prefix_custom_mask else 0, int(sliding_window_size),
+            B, Hq, Hkv, D, Dv, q_extend.stride(0), q_extend.stride(1), k_extend.stride(0), k_extend.stride(1),
+            v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
+            k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
+            int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0,
+            dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention_window")
+        return
+    if custom_mask is not None:
         check(lib().sglk_extend_attention_masked(
             _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
             _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), _ptr(m8), _ptr(mask_indptr),

@@ -358,6 +358,45 @@ def test_extend_masked_golden(golden, case):
     torch.testing.assert_close(o.float().cpu(), g["expect_triton_f32"], rtol=2e-2, atol=2e-2)   # bf16 output
 
 
+@pytest.mark.parametrize("case", ["w8", "w4_h64"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_extend_window_golden(golden, case, dtype):
+    """extend_attention_fwd(sliding_window_size=W) against the reference Triton kernel's output (the rows it gets
+    finite: see test_oracle_extend_window_golden) and against the oracle on every row."""
+    import oracle
+
+    ops = _ops()
+    g = golden("extend_window_" + case)
+    W = int(g["window"])
+    d = lambda t: t.to(dtype).to(DEV)
+    q = d(g["q_extend"])
+    o = torch.full((q.shape[0], q.shape[1], g["v_extend"].shape[-1]), float("nan"), dtype=dtype, device=DEV)
+    ext = (g["qo_indptr"][1:] - g["qo_indptr"][:-1]).max().item()
+    ops.extend_attention_fwd(q, d(g["k_extend"]), d(g["v_extend"]), o, d(g["k_buffer"]), d(g["v_buffer"]),
+                             g["qo_indptr"].to(DEV), g["kv_indptr"].to(DEV), g["kv_indices"].to(DEV), None, True, None,
+                             ext, g["sm_scale"], 0.0, sliding_window_size=W)
+    torch.cuda.synchronize()
+    got = o.float().cpu()
+    assert torch.isfinite(got).all()
+    want = g["expect_triton_f32"]
+    ok = ~torch.isnan(want).any(-1).any(-1)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-4
+    assert (got[ok] - want[ok]).abs().max().item() < tol
+    ref = oracle.extend_attention_window(g["q_extend"], g["k_extend"], g["v_extend"], g["k_buffer"], g["v_buffer"],
+                                         g["qo_indptr"], g["kv_indptr"], g["kv_indices"], W, g["sm_scale"])
+    assert (got - ref).abs().max().item() < tol
+    # a window no row reaches beyond is no window
+    o2 = torch.empty_like(o)
+    ops.extend_attention_fwd(q, d(g["k_extend"]), d(g["v_extend"]), o2, d(g["k_buffer"]), d(g["v_buffer"]),
+                             g["qo_indptr"].to(DEV), g["kv_indptr"].to(DEV), g["kv_indices"].to(DEV), None, True, None,
+                             ext, g["sm_scale"], 0.0, sliding_window_size=10 ** 6)
+    o3 = torch.empty_like(o)
+    ops.extend_attention_fwd(q, d(g["k_extend"]), d(g["v_extend"]), o3, d(g["k_buffer"]), d(g["v_buffer"]),
+                             g["qo_indptr"].to(DEV), g["kv_indptr"].to(DEV), g["kv_indices"].to(DEV), None, True, None,
+                             ext, g["sm_scale"], 0.0)
+    assert (o2.float() - o3.float()).abs().max().item() < tol
+
+
 def test_extend_masked_tree_from_builder():
     """The mask laid out by build_tree_kernel_efficient drives the extend: every draft token attends the prefix and
     its own ancestors only, which the restatement reproduces from the same bytes."""

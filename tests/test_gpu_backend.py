@@ -162,6 +162,73 @@ def test_backend_extend_matches_oracle():
     assert (o.float().cpu().view(T, Hq, D) - want).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("graph_state", [False, True])
+def test_backend_sliding_window(graph_state):
+    """A model with sliding-window layers (model_runner.sliding_window_size = W, layer.sliding_window_size = W): decode
+    attends to the last W + 1 tokens of each request, extend to the window of the cached prefix under the reference's
+    mask plus the causal new tokens (triton_backend.py:75-131, 759-816); a full-attention layer of the same model keeps
+    the whole sequence.  Eager and fixed-address (graph) metadata."""
+    import oracle
+    from sglang_security_amd.attention import SglkAttnBackend
+
+    Hq, Hkv, D, B, W = 8, 2, 128, 4, 16
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    mr.sliding_window_size = W
+    g = torch.Generator().manual_seed(5)
+    lens = [5, 17, 18, 90]                       # shorter than, equal to and longer than the window
+    for b, L in enumerate(lens):
+        r2t.req_to_token[b, :L] = alloc.alloc(L).int()
+    for buf in (kv.k_buffer[0], kv.v_buffer[0]):
+        buf.copy_(torch.randn(buf.shape, generator=g).to(torch.bfloat16))
+    seq_lens = torch.tensor(lens, device=DEV)
+    q = torch.randn(B, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    fb = types.SimpleNamespace(forward_mode=_Mode(True), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                               seq_lens=seq_lens, seq_lens_sum=sum(lens), out_cache_loc=None, token_to_kv_pool=kv)
+    be = SglkAttnBackend(mr)
+    if graph_state:
+        be.init_cuda_graph_state(8)
+        be.init_forward_metadata_capture_cuda_graph(B, B, fb.req_pool_indices, seq_lens)
+        be.init_forward_metadata_replay_cuda_graph(B, fb.req_pool_indices, seq_lens, sum(lens))
+    else:
+        be.init_forward_metadata(fb)
+    kb, vb = kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu()
+    ones = torch.ones(B, dtype=torch.int32)
+    for window_layer in (True, False):
+        layer = _layer(0, Hq, Hkv, D)
+        layer.sliding_window_size = W if window_layer else -1
+        o = be.forward(q, None, None, layer, fb, save_kv_cache=False)
+        keep = [min(L, W + 1) if window_layer else L for L in lens]
+        ptr = torch.tensor([0] + list(torch.tensor(keep).cumsum(0)), dtype=torch.int32)
+        ind = torch.cat([r2t.req_to_token[b, lens[b] - keep[b]: lens[b]].cpu() for b in range(B)])
+        want = oracle.decode_attention(q.cpu().view(B, Hq, D), kb, vb, ptr, ind, ones, layer.scaling)
+        assert (o.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
+    if graph_state:
+        return
+    # extend over a cached prefix
+    pre, ext = [40, 3, 0, 17], [12, 30, 9, 5]
+    for b in range(B):
+        r2t.req_to_token[b, : pre[b] + ext[b]] = alloc.alloc(pre[b] + ext[b]).int()
+    T = sum(ext)
+    qe = torch.randn(T, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    ke = torch.randn(T, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    ve = torch.randn(T, Hkv * D, generator=g).to(torch.bfloat16).to(DEV)
+    fb2 = types.SimpleNamespace(forward_mode=_Mode(False), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                                seq_lens=torch.tensor([p + e for p, e in zip(pre, ext)], device=DEV),
+                                extend_prefix_lens=torch.tensor(pre, device=DEV), extend_seq_lens=torch.tensor(ext, device=DEV),
+                                out_cache_loc=None, token_to_kv_pool=kv)
+    be.init_forward_metadata(fb2)
+    layer = _layer(0, Hq, Hkv, D)
+    layer.sliding_window_size = W
+    o = be.forward(qe, ke, ve, layer, fb2, save_kv_cache=False)
+    wpre = [min(p, W + 1) for p in pre]
+    qo = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32)
+    kp = torch.tensor([0] + list(torch.tensor(wpre).cumsum(0)), dtype=torch.int32)
+    ki = torch.cat([r2t.req_to_token[b, pre[b] - wpre[b]: pre[b]].cpu() for b in range(B)])
+    want = oracle.extend_attention_window(qe.cpu().view(T, Hq, D), ke.cpu().view(T, Hkv, D), ve.cpu().view(T, Hkv, D), kb, vb,
+                                          qo, kp, ki, W, layer.scaling)
+    assert (o.float().cpu().view(T, Hq, D) - want).abs().max().item() < 2e-2
+
+
 def test_awq_linear_method():
     import oracle
     from sglang_security_amd.quantization import AWQConfig, AWQLinearMethod

@@ -245,6 +245,24 @@ def test_oracle_extend_masked_golden(golden, case):
     torch.testing.assert_close(got, g["expect_triton_f32"], rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("case", ["w8", "w4_h64"])
+def test_oracle_extend_window_golden(golden, case):
+    """The sliding-window restatement against the reference Triton kernel (interpreter run, gen_golden.py), called as
+    the reference's backend calls it (only the window's prefix tokens listed).  Rows whose whole listed prefix lies
+    outside the window come out NaN in the reference (its running maximum stays -inf through the prefix stage and
+    exp(-inf - -inf) poisons the row); the restatement gives those rows the attention over their new tokens, and only
+    the rows the reference gets finite are compared."""
+    import oracle
+    g = golden("extend_window_" + case)
+    got = oracle.extend_attention_window(g["q_extend"], g["k_extend"], g["v_extend"], g["k_buffer"], g["v_buffer"],
+                                         g["qo_indptr"], g["kv_indptr"], g["kv_indices"], int(g["window"]), g["sm_scale"])
+    want = g["expect_triton_f32"]
+    ok = ~torch.isnan(want).any(-1).any(-1)
+    assert 0 < int(ok.sum()) < want.shape[0]
+    assert torch.isfinite(got).all()
+    torch.testing.assert_close(got[ok], want[ok], rtol=2e-4, atol=2e-4)
+
+
 def test_oracle_moe_fused_gate_matches_torch_formula():
     """Without ties (fp32) the kernel restatement equals biased_grouped_topk_impl (topk.py:170-211), restated inline."""
     import oracle
