@@ -824,50 +824,63 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   const int heads_here = min(16, heads - ht * 16);
   const auto ro = ws.rsrc_o();
   const auto rl = ws.rsrc_lse();
-  for (int base = 0; base < heads_here * 128; base += 256) {  // block-uniform trip count
-    const int idx = base + threadIdx.x;
-    const bool ok = idx < heads_here * 128;
-    const int hh = ok ? idx >> 7 : 0, d = idx & 127;
-    const int hq = kvh * heads + ht * 16 + hh;
-    const int row0 = (b * Hq + hq) * prefix_splits;
-    // prefix partials (global), loads issued together
-    float tv[kSharedMaxSplits], tl[kSharedMaxSplits];
+  // Two trips' worth of prefix partials are requested before either is merged: every trip's loads are a journey to
+  // memory (agent-scope loads), and with four query heads per kv head a block has exactly two trips.
+  for (int base0 = 0; base0 < heads_here * 128; base0 += 512) {  // block-uniform trip count
+    float tv[2][kSharedMaxSplits], tl[2][kSharedMaxSplits];
 #pragma unroll
-    for (int sp = 0; sp < kSharedMaxSplits; ++sp) {
-      const bool live = ok && !failed && sp < aps;
-      tv[sp] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, (row0 + sp) * 512 + d * 4, 0, kSc1))
-                    : 0.f;
-      tl[sp] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (row0 + sp) * 4, 0, kSc1))
-                    : -INFINITY;
-    }
-    float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
+    for (int u = 0; u < 2; ++u) {
+      const int idx = base0 + 256 * u + threadIdx.x;
+      const bool ok = idx < heads_here * 128;
+      const int hh = ok ? idx >> 7 : 0, d = idx & 127;
+      const int hq = kvh * heads + ht * 16 + hh;
+      const int row0 = (b * Hq + hq) * prefix_splits;
 #pragma unroll
-    for (int sp = 0; sp < kSharedMaxSplits + kWavesPerBlock; ++sp) {
-      float v, l;
-      if (sp < kSharedMaxSplits) {
-        v = tv[sp];
-        l = tl[sp];
-      } else {
-        v = reinterpret_cast<const float*>(lds_all + (sp - kSharedMaxSplits) * kTileBytes)[hh * 128 + d];
-        l = tail_lse[sp - kSharedMaxSplits][hh];
-      }
-      if (l > -INFINITY) {
-        const float n_max = fmaxf(l, e_max);
-        const float old = expf(e_max - n_max), w = expf(l - n_max);
-        acc = acc * old + w * v;
-        e_sum = e_sum * old + w;
-        e_max = n_max;
+      for (int sp = 0; sp < kSharedMaxSplits; ++sp) {
+        const bool live = ok && !failed && sp < aps;
+        tv[u][sp] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ro, (row0 + sp) * 512 + d * 4, 0, kSc1))
+                         : 0.f;
+        tl[u][sp] = live ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, (row0 + sp) * 4, 0, kSc1))
+                         : -INFINITY;
       }
     }
-    const float res = failed ? __builtin_nanf("") : acc / e_sum;
-    if (ok) st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d, res);
-    if (xsum_out) {
-      // a head is 128 consecutive idx = two waves: pair them through LDS
-      const float r = wave_sum(ok ? Conv<T>::to_f32(Conv<T>::from_f32(res)) : 0.f);
-      __syncthreads();  // the previous trip's sums have been read
-      if (lane == 0) xr[wid] = r;
-      __syncthreads();
-      if ((threadIdx.x & 127) == 0 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[wid] + xr[wid + 1];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int base = base0 + 256 * u;
+      if (base >= heads_here * 128) break;  // block-uniform
+      const int idx = base + threadIdx.x;
+      const bool ok = idx < heads_here * 128;
+      const int hh = ok ? idx >> 7 : 0, d = idx & 127;
+      const int hq = kvh * heads + ht * 16 + hh;
+      float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < kSharedMaxSplits + kWavesPerBlock; ++sp) {
+        float v, l;
+        if (sp < kSharedMaxSplits) {
+          v = tv[u][sp];
+          l = tl[u][sp];
+        } else {
+          v = reinterpret_cast<const float*>(lds_all + (sp - kSharedMaxSplits) * kTileBytes)[hh * 128 + d];
+          l = tail_lse[sp - kSharedMaxSplits][hh];
+        }
+        if (l > -INFINITY) {
+          const float n_max = fmaxf(l, e_max);
+          const float old = expf(e_max - n_max), w = expf(l - n_max);
+          acc = acc * old + w * v;
+          e_sum = e_sum * old + w;
+          e_max = n_max;
+        }
+      }
+      const float res = failed ? __builtin_nanf("") : acc / e_sum;
+      if (ok) st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d, res);
+      if (xsum_out) {
+        // a head is 128 consecutive idx = two waves: pair them through LDS
+        const float r = wave_sum(ok ? Conv<T>::to_f32(Conv<T>::from_f32(res)) : 0.f);
+        __syncthreads();  // the previous trip's sums have been read
+        if (lane == 0) xr[wid] = r;
+        __syncthreads();
+        if ((threadIdx.x & 127) == 0 && ok) xsum_out[(int64_t)hq * xs_stride + b] = xr[wid] + xr[wid + 1];
+      }
     }
   }
   ATTN_STAMP(3);
