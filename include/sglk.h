@@ -189,6 +189,27 @@ SGLK_API int sglk_extend_attention_masked(const void* q_extend, const void* k_ex
                                           int64_t v_stride_n, int64_t v_stride_h, int max_extend_len,
                                           float sm_scale, float logit_cap, int dtype, void* stream);
 
+/* sglk_extend_attention with the cached prefix split over kv_splits blocks per (sequence, query block, head) and a
+ * second launch that merges the partials by log-sum-exp: for batches with few (query block, head) pairs -- a single
+ * request extending a short tail over a long cached prefix, the shape of a radix-cache hit -- where one block per pair
+ * leaves most of the chip idle and walks the whole prefix serially.  No counterpart in the reference, whose kernel
+ * walks the prefix once per query block (extend_attention.py:96-210); same result within fp tolerance (the merge is
+ * merge_state arithmetic in split order).  16-bit types, head size 128, contiguous new tokens, no mask.
+ * workspace: sglk_extend_attention_split_workspace_bytes(total_rows, Hq, kv_splits) bytes, 16-byte aligned, where
+ * total_rows = qo_indptr[B] (the number of query rows); kv_splits == 1 is sglk_extend_attention. */
+SGLK_API int64_t sglk_extend_attention_split_workspace_bytes(int64_t total_rows, int Hq, int kv_splits);
+SGLK_API int sglk_extend_attention_split(const void* q_extend, const void* k_extend, const void* v_extend,
+                                         void* o_extend, const void* k_buffer, const void* v_buffer,
+                                         const int32_t* qo_indptr, const int32_t* kv_indptr,
+                                         const int32_t* kv_indices, int B, int Hq, int Hkv, int D, int Dv,
+                                         int64_t q_stride_t, int64_t q_stride_h, int64_t ke_stride_t,
+                                         int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h,
+                                         int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n,
+                                         int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                                         int max_extend_len, float sm_scale, float logit_cap, int causal,
+                                         int kv_splits, float* workspace, int64_t total_rows, int dtype,
+                                         void* stream);
+
 /* sglk_extend_attention for a sliding-window layer (extend_attention.py:179-184,323 as called by
  * triton_backend.py:759-790).  The caller lists, as the reference's backend does (update_sliding_window_buffer,
  * triton_backend.py:75-103), only the last min(prefix_len, window + 1) prefix tokens of every request in kv_indices;

@@ -50,6 +50,8 @@ _SIGS = {
                                     i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                                     i32, f32, f32, i32, i32, p]),
     "sglk_extend_attention_masked": (i32, [p] * 11 + [i32] * 6 + [i64] * 12 + [i32, f32, f32, i32, p]),
+    "sglk_extend_attention_split_workspace_bytes": (i64, [i64, i32, i32]),
+    "sglk_extend_attention_split": (i32, [p] * 9 + [i32] * 5 + [i64] * 12 + [i32, f32, f32, i32, i32, p, i64, i32, p]),
     "sglk_extend_attention_window": (i32, [p] * 11 + [i32] * 7 + [i64] * 12 + [i32, f32, f32, i32, i32, p]),
     "sglk_prefill_attention_paged": (i32, [p] * 7 + [i32] * 5 + [i64] * 8 + [i32, f32, f32, i32, i32, p]),
     "sglk_merge_state": (i32, [p, p, p, p, p, p, i64, i32, i32, i32, p]),

@@ -24,12 +24,17 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     const int32_t* __restrict__ kv_indices, int Hq, int Hkv, int64_t q_stride_t, int64_t q_stride_h,
     int64_t ke_stride_t, int64_t ke_stride_h, int64_t ve_stride_t, int64_t ve_stride_h, int64_t o_stride_t,
     int64_t o_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
-    float logit_cap, int causal) {
+    float logit_cap, int causal, int kv_splits, float* __restrict__ part_o, float* __restrict__ part_lse) {
+  // kv_splits > 1 (new-token form only): blockIdx.x = query block * kv_splits + split; split s walks its slice of the
+  // cached prefix, the last split also the new tokens; every split leaves a normalised fp32 partial + log-sum-exp per
+  // (query row, head) in part_o [T, Hq, kv_splits, 128] / part_lse [T, Hq, kv_splits] for extend_merge_kernel.  A
+  // single request's short extend over a long prefix has too few (query block, head) pairs to fill the chip otherwise.
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int b = blockIdx.z, h = blockIdx.y;
   const int q0 = qo_indptr[b];
   const int ext_len = qo_indptr[b + 1] - q0;
-  const int block_q0 = blockIdx.x * 64 * NC;
+  const int split = kv_splits > 1 ? (int)blockIdx.x % kv_splits : 0;
+  const int block_q0 = (kv_splits > 1 ? (int)blockIdx.x / kv_splits : (int)blockIdx.x) * 64 * NC;
   if (block_q0 >= ext_len) return;  // block-uniform
   const int pstart = kv_indptr[b];
   const int plen = kv_indptr[b + 1] - pstart;
@@ -72,14 +77,22 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
                                    logit_cap);
     }
   } else {
-  if (plen > 0) {
+  int p0 = 0, p1 = plen;
+  if (kv_splits > 1) {
+    const int per = (((plen + kv_splits - 1) / kv_splits) + 31) / 32 * 32;
+    p0 = min(per * split, plen);
+    p1 = min(p0 + per, plen);
+  }
+  if (p1 > p0) {
     st.template run<false, true>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
                                  reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
-                                 v_stride_n, kv_indices + pstart, 0, plen, qpos, wave_qmax, sm_scale, logit_cap);
+                                 v_stride_n, kv_indices + pstart, p0, p1, qpos, wave_qmax, sm_scale, logit_cap);
   }
   const uint16_t* ke = reinterpret_cast<const uint16_t*>(k_extend) + (int64_t)q0 * ke_stride_t + (int64_t)kvh * ke_stride_h;
   const uint16_t* ve = reinterpret_cast<const uint16_t*>(v_extend) + (int64_t)q0 * ve_stride_t + (int64_t)kvh * ve_stride_h;
-  if (causal) {
+  if (kv_splits > 1 && split != kv_splits - 1) {
+    // the new tokens belong to the last split
+  } else if (causal) {
     const int t_end = min(ext_len, block_q0 + 64 * NC);
     st.template run<true, false>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, t_end, qpos, wave_qmax, sm_scale,
                                  logit_cap);
@@ -89,6 +102,20 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
   }
   }
 
+  if (kv_splits > 1) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const float tot = st.total(c);
+      if (!col_ok[c]) continue;
+      const float inv = tot > 0.f ? 1.0f / tot : 0.f;
+      const int64_t row = ((int64_t)(q0 + qrow[c]) * Hq + h) * kv_splits + split;
+      float* dst = part_o + row * 128;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = st.oacc[c][n] * inv;
+      if (g == 0) part_lse[row] = tot > 0.f ? (st.m[c] + log2f(tot)) * 0.6931471805599453f : -INFINITY;
+    }
+    return;
+  }
   uint16_t* ob = reinterpret_cast<uint16_t*>(o_extend) + (int64_t)h * o_stride_h;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -104,6 +131,29 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
       *reinterpret_cast<short4v*>(dst + 16 * n + 4 * g) = pk;
     }
   }
+}
+
+// merges the kv_splits partials of one (query row, head) by log-sum-exp, in split order (merge_state arithmetic)
+template <typename T>
+__global__ void __launch_bounds__(128) extend_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_lse,
+                                                         void* __restrict__ o, int Hq, int kv_splits, int64_t o_stride_t,
+                                                         int64_t o_stride_h) {
+  const int64_t t = blockIdx.x;
+  const int h = blockIdx.y, d = threadIdx.x;
+  const int64_t row0 = (t * Hq + h) * kv_splits;
+  float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
+  for (int s = 0; s < kv_splits; ++s) {
+    const float l = part_lse[row0 + s];
+    if (l > -INFINITY) {
+      const float v = part_o[(row0 + s) * 128 + d];
+      const float n_max = fmaxf(l, e_max);
+      const float old = expf(e_max - n_max), w = expf(l - n_max);
+      acc = acc * old + w * v;
+      e_sum = e_sum * old + w;
+      e_max = n_max;
+    }
+  }
+  st<T>(o, t * o_stride_t + (int64_t)h * o_stride_h + d, e_sum > 0.f ? acc / e_sum : 0.f);
 }
 
 // one wave per (query row, head): any head size, any float type
@@ -209,7 +259,8 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                                  int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
                                  int max_extend_len, float sm_scale, float logit_cap, int causal, int dtype, void* stream,
                                  bool paged, const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
-                                 int skip_prefix_mask = 1, int window = 0) {
+                                 int skip_prefix_mask = 1, int window = 0, int kv_splits = 1, float* split_ws = nullptr,
+                                 int64_t total_rows = 0) {
   SGLK_CHECK(!custom_mask || (mask_indptr && !paged), "extend_attention: a custom mask needs mask_indptr and new K/V");
   SGLK_CHECK(q_extend && o_extend && qo_indptr && kv_indptr && (paged || (k_extend && v_extend)),
              "extend_attention: null pointer");
@@ -233,14 +284,29 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
   // One column tile per wave (64 query rows per block) keeps the kernel at two blocks per CU; two tiles per wave
   // halve the K/V re-reads but run at one wave per SIMD and measured 25 % slower (SGLK_EXTEND_NC=2 selects them).
   const char* env_nc = getenv("SGLK_EXTEND_NC");
-  if (fast && !(env_nc && atoi(env_nc) == 2)) {
+  if (kv_splits > 1) {
+    if (!fast || paged)
+      return fail(SGLK_EUNSUP, "extend_attention_split: 16-bit types with head size 128 and contiguous new tokens only");
+    float* part_o = split_ws;
+    float* part_lse = split_ws + total_rows * Hq * kv_splits * 128;
+    dim3 grid(((max_extend_len + 63) / 64) * kv_splits, Hq, B);
+    SGLK_DISPATCH_HALF(dtype, T, {
+      hipLaunchKernelGGL((extend_attention_mfma128<T, 1>), grid, dim3(256), kBlockAttnLds, s, q_extend, k_extend, v_extend,
+                         o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h,
+                         ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
+                         k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, kv_splits, part_o, part_lse);
+      hipLaunchKernelGGL((extend_merge_kernel<T>), dim3((unsigned)total_rows, Hq), dim3(128), 0, s, part_o, part_lse,
+                         o_extend, Hq, kv_splits, o_stride_t, o_stride_h);
+    });
+  } else if (fast && !(env_nc && atoi(env_nc) == 2)) {
     dim3 grid((max_extend_len + 63) / 64, Hq, B);
     SGLK_DISPATCH_HALF(dtype, T,
                        hipLaunchKernelGGL((extend_attention_mfma128<T, 1>), grid, dim3(256), kBlockAttnLds, s,
                                           q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                                           kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h, ke_stride_t,
                                           ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal));
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, 1, nullptr,
+                                          nullptr));
   } else if (fast) {
     dim3 grid((max_extend_len + 64 * kNC - 1) / (64 * kNC), Hq, B);
     SGLK_DISPATCH_HALF(dtype, T,
@@ -248,7 +314,8 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                                           q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
                                           kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h, ke_stride_t,
                                           ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal));
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, 1, nullptr,
+                                          nullptr));
   } else {
     dim3 grid(max_extend_len, Hq, B);
     const size_t lds = (size_t)D * sizeof(float);
@@ -308,6 +375,30 @@ extern "C" int sglk_extend_attention_masked(const void* q_extend, const void* k_
                                o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
                                sm_scale, logit_cap, 1, dtype, stream, false, custom_mask, mask_indptr,
                                skip_prefix_custom_mask ? 1 : 0);
+}
+
+extern "C" int64_t sglk_extend_attention_split_workspace_bytes(int64_t total_rows, int Hq, int kv_splits) {
+  if (total_rows <= 0 || Hq <= 0 || kv_splits <= 0) return 0;
+  return total_rows * Hq * kv_splits * (128 + 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int sglk_extend_attention_split(const void* q_extend, const void* k_extend, const void* v_extend,
+                                           void* o_extend, const void* k_buffer, const void* v_buffer,
+                                           const int32_t* qo_indptr, const int32_t* kv_indptr, const int32_t* kv_indices,
+                                           int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_t, int64_t q_stride_h,
+                                           int64_t ke_stride_t, int64_t ke_stride_h, int64_t ve_stride_t,
+                                           int64_t ve_stride_h, int64_t o_stride_t, int64_t o_stride_h, int64_t k_stride_n,
+                                           int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int max_extend_len,
+                                           float sm_scale, float logit_cap, int causal, int kv_splits, float* workspace,
+                                           int64_t total_rows, int dtype, void* stream) {
+  SGLK_CHECK(kv_splits >= 1 && kv_splits <= 64, "extend_attention_split: kv_splits must be in 1..64");
+  SGLK_CHECK(kv_splits == 1 || (workspace && aligned16(workspace) && total_rows > 0 && k_extend && v_extend),
+             "extend_attention_split: needs a 16-byte aligned workspace, the row count and the new K / V");
+  return extend_attention_impl(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                               B, Hq, Hkv, D, Dv, q_stride_t, q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h,
+                               o_stride_t, o_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, max_extend_len,
+                               sm_scale, logit_cap, causal, dtype, stream, false, nullptr, nullptr, 1, 0, kv_splits,
+                               workspace, total_rows);
 }
 
 extern "C" int sglk_extend_attention_window(const void* q_extend, const void* k_extend, const void* v_extend,

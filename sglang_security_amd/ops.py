@@ -210,6 +210,11 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
             int(max_len_extend), float(sm_scale), float(logit_cap), dtype_code(q_extend.dtype), _stream(q_extend)),
             "extend_attention_masked")
         return
+    splits = extend_attention_split_plan(T, Hq, B, max_len_extend, kv_indices.numel() if kv_indptr.numel() > 1 else 0, D,
+                                         q_extend.dtype) if (D == Dv and k_buffer is not None) else 1
+    if splits > 1:
+        return extend_attention_split(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
+                                      kv_indices, max_len_extend, sm_scale, logit_cap, is_causal, splits)
     check(lib().sglk_extend_attention(
         _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
         _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), B, Hq, Hkv, D, Dv,
@@ -218,6 +223,40 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
         int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0,
         dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention")
+
+
+def extend_attention_split_plan(T, Hq, B, max_len_extend, total_prefix, head_dim, dtype) -> int:
+    """How many ways to split the cached prefix (1 = the plain kernel): only where one block per (sequence, query block,
+    head) would leave most CUs without work and the prefixes are long enough to be worth a merge launch."""
+    if head_dim != 128 or dtype not in (torch.float16, torch.bfloat16) or B <= 0 or total_prefix <= 0:
+        return 1
+    blocks = ((int(max_len_extend) + 63) // 64) * Hq * B
+    avg_prefix = total_prefix // B
+    if blocks > 128 or avg_prefix < 256:
+        return 1
+    return int(max(1, min(8, 512 // blocks, avg_prefix // 128)))
+
+
+def extend_attention_split(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices,
+                           max_len_extend, sm_scale, logit_cap, is_causal, kv_splits, workspace=None):
+    """extend_attention_fwd with the cached prefix split kv_splits ways and a merge launch (sglk_extend_attention_split)."""
+    _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
+    T, Hq, D = q_extend.shape
+    Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
+    B = qo_indptr.shape[0] - 1
+    need = int(lib().sglk_extend_attention_split_workspace_bytes(T, Hq, kv_splits))
+    if workspace is None:
+        workspace = torch.empty(need // 4, dtype=torch.float32, device=q_extend.device)
+    elif workspace.numel() * workspace.element_size() < need:
+        raise SglkError(f"extend_attention_split: workspace too small ({need} bytes needed)")
+    check(lib().sglk_extend_attention_split(
+        _ptr(q_extend), _ptr(k_extend), _ptr(v_extend), _ptr(o_extend), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), B, Hq, Hkv, D, Dv,
+        q_extend.stride(0), q_extend.stride(1), k_extend.stride(0), k_extend.stride(1),
+        v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
+        k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
+        int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0, int(kv_splits), _ptr(workspace), T,
+        dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention_split")
 
 
 # ------------------------------------------------------------------------------------------- A3

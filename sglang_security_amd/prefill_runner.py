@@ -77,6 +77,27 @@ class LlamaPrefill:
         self.g_qo = torch.zeros(2, dtype=torch.int32, device=dev)
         self.g_kp = torch.zeros(2, dtype=torch.int32, device=dev)
         self.g_ki = torch.zeros(max(T, 1), dtype=torch.int32, device=dev)
+        # Short single-request extends (the tail after a prefix hit) take the decode step's layer fusion when the
+        # decoder has it: split-K partials handed to the consumer kernels, block sums from the producers, the gated
+        # activation in the gate_up epilogue -- 8 launches per layer instead of 11 and no in-kernel split-K reductions.
+        self.fused_rows = 0
+        if c.quant == "awq" and dec.enable_fusion(True) and getattr(dec, "fused_act", False):
+            g = min(T, DEQUANT_GEMM_MIN_TOKENS - 1)
+            shapes = {"qkv": (c.hidden, self.q_size + 2 * self.kv_size), "o": (self.q_size, c.hidden),
+                      "down": (c.inter, c.hidden)}
+            need = 0
+            for m in sorted({min(g, r) for r in (64, 128, 192, 255)}):
+                sp = {k: ops.awq_gemm_partial_splits(m, n, kk, c.group_size) for k, (kk, n) in shapes.items()}
+                if min(sp.values()) <= 0:
+                    need = 0
+                    break
+                need = max(need, max(sp[k] * g * n for k, (kk, n) in shapes.items()))
+            if need:
+                self.fused_rows = g
+                self._shapes = shapes
+                self.partial = torch.empty(need, dtype=torch.float32, device=dev)
+                self.xs_hidden = torch.zeros(c.hidden // 128, 256, dtype=torch.float32, device=dev)
+                self.xs_act = torch.zeros(c.inter // 128, 256, dtype=torch.float32, device=dev)
 
     def _linear(self, w, x, out):
         T = x.shape[0]
@@ -117,25 +138,76 @@ class LlamaPrefill:
         if T > self.max_tokens:
             raise ValueError(f"extend of {T} tokens, buffers hold {self.max_tokens}")
         single = qo_indptr.numel() == 2 and max_extend_len == T
-        if not (self.use_graph and single and T < DEQUANT_GEMM_MIN_TOKENS and kv_indices.numel() <= self.g_ki.numel()):
+        if not (single and T < DEQUANT_GEMM_MIN_TOKENS and kv_indices.numel() <= self.g_ki.numel()):
+            return self._extend(input_ids, positions, out_cache_loc, qo_indptr, kv_indptr, kv_indices, max_extend_len)
+        pre = int(kv_indptr[-1].item())  # cached prefix tokens (kv_indices may be a one-element placeholder without any)
+        fused = 0 < T <= self.fused_rows
+        if not (self.use_graph or fused):
             return self._extend(input_ids, positions, out_cache_loc, qo_indptr, kv_indptr, kv_indices, max_extend_len)
         self.g_ids[:T].copy_(input_ids)
         self.g_pos[:T].copy_(positions)
         self.g_loc[:T].copy_(out_cache_loc)
         self.g_qo.copy_(qo_indptr)
         self.g_kp.copy_(kv_indptr)
-        self.g_ki[: kv_indices.numel()].copy_(kv_indices)
-        g = self.graphs.get(T)
+        self.g_ki[:pre].copy_(kv_indices[:pre])
+        args = (self.g_ids[:T], self.g_pos[:T], self.g_loc[:T], self.g_qo, self.g_kp, self.g_ki, T)
+        run = self._extend_fused if fused else self._extend
+        if not self.use_graph:
+            return run(*args)
+        g = self.graphs.get((T, fused))
         if g is None:
-            args = (self.g_ids[:T], self.g_pos[:T], self.g_loc[:T], self.g_qo, self.g_kp, self.g_ki, T)
-            self._extend(*args)                      # first touch outside the capture (lazy initialisations)
+            run(*args)                               # first touch outside the capture (lazy initialisations)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._extend(*args)
-            self.graphs[T] = g
+                run(*args)
+            self.graphs[(T, fused)] = g
         g.replay()
         return self.hidden[:T], self.residual[:T]
+
+    def _extend_fused(self, input_ids, positions, out_cache_loc, qo_indptr, kv_indptr, kv_indices, max_extend_len):
+        """One request's short extend on the decode step's fused layer forms (same arithmetic as _extend: the consumer
+        kernels round the summed partials where the GEMM would have).  The rotation kernel leaves the rotated k and v
+        in the qkv buffer as well as in the pool, so the attention is the same call as in _extend."""
+        c = self.cfg
+        T = input_ids.shape[0]
+        hidden, residual = self.hidden[:T], self.residual[:T]
+        qkv, attn_out, act = self.qkv[:T], self.attn_out[:T], self.act[:T]
+        xs_h, xs_a = self.xs_hidden[:, :T], self.xs_act[:, :T]
+        P = self.partial
+        S = {k: ops.awq_gemm_partial_splits(T, n, kk, c.group_size) for k, (kk, n) in self._shapes.items()}
+        torch.index_select(self.dec.embed, 0, input_ids, out=hidden)
+        sm_scale = 1.0 / math.sqrt(c.head_dim)
+        q = qkv[:, : self.q_size].view(T, c.q_heads, c.head_dim)
+        k = qkv[:, self.q_size: self.q_size + self.kv_size].view(T, c.kv_heads, c.head_dim)
+        v = qkv[:, self.q_size + self.kv_size:].view(T, c.kv_heads, c.head_dim)
+        o = attn_out.view(T, c.q_heads, c.head_dim)
+        last = len(self.dec.layers) - 1
+        for li, L in enumerate(self.dec.layers):
+            if li == 0:
+                residual.copy_(hidden)
+                ops.fused_add_rmsnorm_ex(hidden, None, L["ln1"], c.eps, xsum_out=xs_h)
+            else:
+                ops.fused_add_rmsnorm_ex(hidden, residual, L["ln1"], c.eps, partials=P, splits=S["down"], xsum_out=xs_h)
+            w = L["qkv"]
+            ops.awq_gemm_partial(hidden, w.packed, w.scales, w.qzeros, P, xs_h)
+            kb, vb = self.kv.get_kv_buffer(li)
+            ops.rope_and_store_kv_partial(qkv, P, S["qkv"], self.dec.cos_sin, positions, kb, vb, out_cache_loc, c.q_heads,
+                                          c.kv_heads, c.head_dim, bias=L["qkv_bias"])
+            ops.extend_attention_fwd(q, k, v, o, kb, vb, qo_indptr, kv_indptr, kv_indices, None, True, None, max_extend_len,
+                                     sm_scale)
+            w = L["o"]
+            ops.awq_gemm_partial(attn_out, w.packed, w.scales, w.qzeros, P)
+            ops.fused_add_rmsnorm_ex(hidden, residual, L["ln2"], c.eps, partials=P, splits=S["o"], xsum_out=xs_h,
+                                     zero_out=self.xs_act)
+            il = L["gate_up_il"]
+            ops.awq_gemm_silu_mul(hidden, il[0], il[1], il[2], act, xs_h, xs_a)
+            w = L["down"]
+            if li == last:  # the caller wants the finished rows
+                ops.awq_gemm_xs(act, w.packed, w.scales, w.qzeros, xs_a, hidden, self.workspace)
+            else:
+                ops.awq_gemm_partial(act, w.packed, w.scales, w.qzeros, P, xs_a)
+        return hidden, residual
 
     def _extend(self, input_ids, positions, out_cache_loc, qo_indptr, kv_indptr, kv_indices, max_extend_len):
         c = self.cfg

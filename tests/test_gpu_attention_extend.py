@@ -397,6 +397,43 @@ def test_extend_window_golden(golden, case, dtype):
     assert (o2.float() - o3.float()).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("pre,ext,splits", [([1024], [128], 8), ([300, 0, 77], [40, 64, 5], 4), ([33], [1], 2),
+                                            ([500, 500], [70, 130], 3)])
+def test_extend_attention_split_kv(dtype, pre, ext, splits):
+    """The cached prefix split over several blocks per (sequence, query block, head) plus the merge launch: against the
+    oracle and against the plain kernel (same tolerance: only the order of the softmax merge differs).  Ragged
+    prefixes incl. an empty one (its prefix splits contribute nothing) and a prefix shorter than the split count x 32."""
+    import oracle
+
+    ops = _ops()
+    Hq, Hkv, D = 8, 2, 128
+    B = len(pre)
+    gen = torch.Generator().manual_seed(sum(pre) + sum(ext))
+    n = sum(pre) + 5
+    kb = torch.randn(n, Hkv, D, generator=gen).to(dtype)
+    vb = torch.randn(n, Hkv, D, generator=gen).to(dtype)
+    T = sum(ext)
+    q = torch.randn(T, Hq, D, generator=gen).to(dtype)
+    ke = torch.randn(T, Hkv, D, generator=gen).to(dtype)
+    ve = torch.randn(T, Hkv, D, generator=gen).to(dtype)
+    qo = torch.tensor([0] + list(torch.tensor(ext).cumsum(0)), dtype=torch.int32)
+    kp = torch.tensor([0] + list(torch.tensor(pre).cumsum(0)), dtype=torch.int32)
+    ki = (torch.randperm(n - 1, generator=gen)[: sum(pre)] + 1).to(torch.int32)
+    sm = 1.0 / math.sqrt(D)
+    want = oracle.extend_attention(q, ke, ve, kb, vb, qo, kp, ki, sm, 0.0, True)
+    d = lambda t: t.to(DEV)
+    o = torch.full((T, Hq, D), float("nan"), dtype=dtype, device=DEV)
+    ops.extend_attention_split(d(q), d(ke), d(ve), o, d(kb), d(vb), d(qo), d(kp), d(ki), max(ext), sm, 0.0, True, splits)
+    o1 = torch.empty_like(o)
+    ops.extend_attention_split(d(q), d(ke), d(ve), o1, d(kb), d(vb), d(qo), d(kp), d(ki), max(ext), sm, 0.0, True, 1)
+    torch.cuda.synchronize()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o.float()).all()
+    assert (o.float().cpu() - want).abs().max().item() < tol
+    assert (o.float() - o1.float()).abs().max().item() < tol
+
+
 def test_extend_masked_tree_from_builder():
     """The mask laid out by build_tree_kernel_efficient drives the extend: every draft token attends the prefix and
     its own ancestors only, which the restatement reproduces from the same bytes."""
