@@ -15,6 +15,10 @@ namespace sglk {
 namespace {
 
 constexpr int kNC = 2;
+#ifndef SGLK_EXTEND_PF
+#define SGLK_EXTEND_PF 1
+#endif
+constexpr int kExtPF = SGLK_EXTEND_PF;  // K / V tiles in flight ahead of the one being multiplied
 
 template <typename T, int NC>
 __global__ void __launch_bounds__(256) extend_attention_mfma128(
@@ -70,10 +74,10 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     if (causal) {
       const int t_end = min(plen, shift + block_q0 + 64 * NC);
       if (t_end > 0)
-        st.template run<true, true>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, t_end, qpos,
+        st.template run<true, true, kExtPF>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, t_end, qpos,
                                     wave_qmax + shift, sm_scale, logit_cap);
     } else if (plen > 0) {
-      st.template run<false, true>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, plen, qpos, 0, sm_scale,
+      st.template run<false, true, kExtPF>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, plen, qpos, 0, sm_scale,
                                    logit_cap);
     }
   } else {
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     p1 = min(p0 + per, plen);
   }
   if (p1 > p0) {
-    st.template run<false, true>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+    st.template run<false, true, kExtPF>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
                                  reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
                                  v_stride_n, kv_indices + pstart, p0, p1, qpos, wave_qmax, sm_scale, logit_cap);
   }
@@ -94,10 +98,10 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     // the new tokens belong to the last split
   } else if (causal) {
     const int t_end = min(ext_len, block_q0 + 64 * NC);
-    st.template run<true, false>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, t_end, qpos, wave_qmax, sm_scale,
+    st.template run<true, false, kExtPF>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, t_end, qpos, wave_qmax, sm_scale,
                                  logit_cap);
   } else {
-    st.template run<false, false>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, ext_len, qpos, wave_qmax, sm_scale,
+    st.template run<false, false, kExtPF>(lds, ke, ve, ke_stride_t, ve_stride_t, nullptr, 0, ext_len, qpos, wave_qmax, sm_scale,
                                   logit_cap);
   }
   }
