@@ -391,12 +391,15 @@ def gptq_repack(qweight, qzeros, group_size, zero_offset=1):
     return packed, zeros
 
 
-def awq_dequantize_packed(packed, scales, qzeros):
-    """awq_dequantize from the re-laid-out copy: [K, N] in the scale dtype."""
+def awq_dequantize_packed(packed, scales, qzeros, out=None):
+    """awq_dequantize from the re-laid-out copy: [K, N] in the scale dtype (into `out` when given)."""
     _need_gpu(packed, scales, qzeros)
     K, N = packed.shape[0], packed.shape[1] * 8
     group = K // scales.shape[0]
-    out = torch.empty((K, N), dtype=scales.dtype, device=packed.device)
+    if out is None:
+        out = torch.empty((K, N), dtype=scales.dtype, device=packed.device)
+    elif out.shape != (K, N) or out.dtype != scales.dtype or not out.is_contiguous() or out.device != packed.device:
+        raise SglkError("awq_dequantize_packed: out must be a contiguous [K, N] tensor of the scale dtype")
     check(lib().sglk_awq_dequantize_packed(_ptr(packed), _ptr(scales), _ptr(qzeros), _ptr(out), K, N, group,
                                            dtype_code(scales.dtype), _stream(packed)), "awq_dequantize_packed")
     return out
