@@ -26,6 +26,17 @@ extern "C" {
 #define SGLK_BF16 2
 #define SGLK_FP8_E4M3 3 /* OCP e4m3fn: the native fp8 of gfx950 */
 
+/* fp8 KV cache: a pool whose elements are one byte each (python/sglang/srt/mem_cache/memory_pool.py:119-123 stores
+ * them as uint8; the pool type is float8_e5m2fnuz on ROCm, float8_e5m2 / float8_e4m3fn on CUDA,
+ * model_executor/model_runner.py:847-854).  The attention entry points that say so take
+ * `dtype | (SGLK_KV_* << SGLK_KV_SHIFT)`: q and o are of type `dtype`, k_buffer / v_buffer hold the named format, the
+ * pool strides count bytes, and every element is converted exactly to fp32 as `.to(q.dtype)` does in the reference's
+ * kernels (no scale is applied on the read side, as in triton_ops/decode_attention.py). */
+#define SGLK_KV_E4M3FN 1
+#define SGLK_KV_E5M2 2
+#define SGLK_KV_E5M2FNUZ 3
+#define SGLK_KV_SHIFT 8
+
 /* error codes */
 #define SGLK_OK 0
 #define SGLK_EINVAL (-1)  /* bad shape / alignment / dtype: the reference raises RuntimeError here */
@@ -77,7 +88,11 @@ SGLK_API int sglk_decode_metadata(const int32_t* req_to_token, int64_t row_strid
  * Strides are in elements; the last dimension of every tensor is contiguous.
  * Matrix-core kernels serve 16-bit types with head size 128, head size 64 with an even number of contiguous kv heads
  * (k_stride_h == v_stride_h == 64: pairs of kv heads are walked as one 128-element row) and the absorbed-MLA shape
- * 576 / 512 with v_buffer a view of k_buffer; every other shape or stride takes a generic kernel. */
+ * 576 / 512 with v_buffer a view of k_buffer; every other shape or stride takes a generic kernel.
+ * fp8 pools: dtype | (SGLK_KV_* << SGLK_KV_SHIFT) with fp16 / bf16 queries, pool strides in bytes; head size 128 runs
+ * the matrix-core kernel (8-byte row pieces widened to the query type through a 256-entry table on their way into
+ * LDS), other shapes the generic kernel.  The same holds for the _xs and shared-prefix entry points below (an fp8
+ * pool takes the per-request kernels there). */
 SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o,
                                    const int32_t* kv_indptr, const int32_t* kv_indices,
                                    float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
@@ -160,7 +175,10 @@ SGLK_API int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_str
  * contiguous new tokens.  Replaces extend_attention_fwd,
  * python/sglang/srt/layers/attention/triton_ops/extend_attention.py:306-438
  * (== extend_attention_cpu, sgl-kernel/csrc/cpu/extend.cpp:481-621).  For a custom mask see
- * sglk_extend_attention_masked. */
+ * sglk_extend_attention_masked.
+ * fp8 pools: dtype | (SGLK_KV_* << SGLK_KV_SHIFT): k_buffer / v_buffer hold one-byte codes (strides in bytes), the new
+ * tokens' k_extend / v_extend stay in the query type.  Accepted by every extend entry point of this section
+ * (masked, window, split, paged prefill). */
 SGLK_API int sglk_extend_attention(const void* q_extend, const void* k_extend, const void* v_extend,
                                    void* o_extend, const void* k_buffer, const void* v_buffer,
                                    const int32_t* qo_indptr, const int32_t* kv_indptr,
@@ -260,6 +278,18 @@ SGLK_API int sglk_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, c
                                 const void* loc, int loc_is64, int64_t tokens, int row_k, int row_v,
                                 int64_t kbuf_stride_n, int64_t vbuf_stride_n, int64_t k_stride_t,
                                 int64_t v_stride_t, int elem_bytes, void* stream);
+
+/* The same write into an fp8 pool (format SGLK_KV_*): byte = fp8(k[t] / k_scale), rounded as torch's
+ * Tensor.to(float8 type) rounds (nearest even, denormals kept; out of range: NaN for e4m3fn and e5m2fnuz, infinity for
+ * e5m2; the fnuz format has no negative zero).  k / v are rows of `src_dtype` (SGLK_F32 / F16 / BF16).  A scale <= 0
+ * means "no scale"; with one, the quotient is formed as the reference's device forms `cache_k.div_(k_scale)`: product
+ * with the fp32 reciprocal, rounded to src_dtype, before the fp8 rounding.  Strides in elements of their own arrays.
+ * Replaces the fp8 branch of MHATokenToKVPool.set_kv_buffer, memory_pool.py:389-400. */
+SGLK_API int sglk_set_kv_buffer_fp8(void* k_buffer, void* v_buffer, const void* k, const void* v,
+                                    const void* loc, int loc_is64, int64_t tokens, int row_k, int row_v,
+                                    int64_t kbuf_stride_n, int64_t vbuf_stride_n, int64_t k_stride_t,
+                                    int64_t v_stride_t, float k_scale, float v_scale, int src_dtype,
+                                    int kv_format, void* stream);
 
 /* ------------------------------------------------------------------ E1: elementwise ----------- */
 

@@ -570,3 +570,74 @@ def moe_fused_gate(gating, bias, topk, num_expert_group, topk_group, n_share_exp
         ids = torch.cat([ids, (E + torch.arange(n) % n_share_experts_fusion).unsqueeze(1)], dim=1)
         w = torch.cat([w, ssum / routed_scaling_factor], dim=1)
     return (w / ssum).float(), ids.to(torch.int32)
+
+
+# ---------------------------------------------------------------------------------------------- fp8 KV cache
+# The reference stores an fp8 KV cache as the bytes of `cache_k.to(self.dtype)` (mem_cache/memory_pool.py:389-400,
+# after `cache_k.div_(k_scale)` when a scale is given) and its attention kernels read them back with `.to(q.dtype)`
+# (triton_ops/decode_attention.py: k / v loads feed tl.dot / tl.sum in the query type).  On ROCm the pool type is
+# torch.float8_e5m2fnuz (model_executor/model_runner.py:847-851), on CUDA float8_e5m2 or float8_e4m3fn (:851-854).
+# Restated here as integer arithmetic on the fp32 bit pattern: round to nearest even into the format's mantissa,
+# denormals included; out of range becomes NaN (e4m3fn, e5m2fnuz) or infinity (e5m2); the fnuz format has no negative
+# zero and one NaN (0x80).  tests/test_oracle_golden.py compares both directions with torch's own conversions over every
+# byte, every bf16 and every fp16 bit pattern.
+KV_FP8_FORMATS = {"e4m3fn": (4, 3, 7), "e5m2": (5, 2, 15), "e5m2fnuz": (5, 2, 16)}  # exponent bits, mantissa bits, bias
+
+
+def kv_fp8_decode(raw: np.ndarray, fmt: str) -> np.ndarray:
+    """uint8 codes -> float32 values."""
+    E, M, B = KV_FP8_FORMATS[fmt]
+    b = np.asarray(raw, dtype=np.uint8).astype(np.int64)
+    sign = np.where(b >> 7, -1.0, 1.0)
+    e = (b >> M) & ((1 << E) - 1)
+    m = b & ((1 << M) - 1)
+    val = np.where(e > 0, (1.0 + m / float(1 << M)) * np.exp2((e - B).astype(np.float64)),
+                   m / float(1 << M) * 2.0 ** (1 - B))
+    val = sign * val
+    if fmt == "e4m3fn":
+        val = np.where((b & 0x7F) == 0x7F, np.nan, val)
+    elif fmt == "e5m2":
+        val = np.where(e == 31, np.where(m == 0, sign * np.inf, np.nan), val)
+    else:
+        val = np.where(b == 0x80, np.nan, val)
+    return val.astype(np.float32)
+
+
+def kv_fp8_encode(x: np.ndarray, fmt: str) -> np.ndarray:
+    """float32 values -> uint8 codes (torch's Tensor.to(float8) rounding and overflow rules)."""
+    E, M, B = KV_FP8_FORMATS[fmt]
+    bits = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.int64)
+    sign = (bits >> 31) & 1
+    a = bits & 0x7FFFFFFF
+    shift = 23 - M
+    # normal results: add the rounding bias (ties to even), re-bias the exponent, keep the top bits
+    rounded = a + ((1 << (shift - 1)) - 1) + ((a >> shift) & 1)
+    code_n = (rounded >> shift) - ((127 - B) << M)
+    # denormal results (below 2^(1-B)): the integer nearest to |x| / 2^(1-B-M), ties to even
+    small = a < ((1 - B + 127) << 23)
+    mag = np.where(small, a, 0).astype(np.uint32).view(np.float32).astype(np.float64)
+    code_d = np.rint(mag / 2.0 ** (1 - B - M)).astype(np.int64)
+    code = np.where(small, code_d, code_n)
+    if fmt == "e4m3fn":
+        code = np.minimum(code, 0x7F)                      # past 464: the NaN code
+        code = np.where(a > 0x7F800000, 0x7F, code)
+        out = code | (sign << 7)
+    elif fmt == "e5m2":
+        code = np.minimum(code, 0x7C)                      # infinity
+        code = np.where(a > 0x7F800000, 0x7F, code)
+        out = code | (sign << 7)
+    else:
+        over = (code >= 0x80) | (a >= 0x7F800000)
+        out = np.where(over, 0x80, np.where(code == 0, 0, code | (sign << 7)))
+    return out.astype(np.uint8)
+
+
+def set_kv_buffer_fp8(cache: torch.Tensor, scale, fmt: str) -> np.ndarray:
+    """Bytes the pool receives for rows `cache` (bf16 / fp16 / fp32): memory_pool.py:389-396.  The division by the
+    scale is the in-place `div_` of a tensor in the model's type by a Python number, which the device the reference
+    runs on evaluates as a product with the fp32 reciprocal, rounded to the tensor's type; then the fp8 rounding."""
+    x = cache.detach().cpu()
+    if scale is not None:
+        inv = np.float32(1.0) / np.float32(scale)
+        x = torch.from_numpy(x.float().numpy() * inv).to(x.dtype)
+    return kv_fp8_encode(x.float().numpy(), fmt)

@@ -56,6 +56,7 @@ _SIGS = {
     "sglk_prefill_attention_paged": (i32, [p] * 7 + [i32] * 5 + [i64] * 8 + [i32, f32, f32, i32, i32, p]),
     "sglk_merge_state": (i32, [p, p, p, p, p, p, i64, i32, i32, i32, p]),
     "sglk_set_kv_buffer": (i32, [p, p, p, p, p, i32, i64, i32, i32, i64, i64, i64, i64, i32, p]),
+    "sglk_set_kv_buffer_fp8": (i32, [p, p, p, p, p, i32, i64, i32, i32, i64, i64, i64, i64, f32, f32, i32, i32, p]),
     "sglk_rmsnorm": (i32, [p, p, p, i64, i32, i64, i64, f32, i32, i32, p]),
     "sglk_fused_add_rmsnorm": (i32, [p, p, p, i64, i32, f32, i32, i32, p]),
     "sglk_act_and_mul": (i32, [p, p, i64, i32, i32, i32, p]),

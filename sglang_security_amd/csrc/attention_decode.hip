@@ -17,6 +17,8 @@
 // Everything else (fp32, odd head sizes, MLA 576/512) takes the generic wave-per-(request, head,
 // split) kernel.  Partials are merged by log-sum-exp in a second kernel, as in the reference
 // (triton_ops/decode_attention.py:497-557).
+#include <type_traits>
+
 #include "attention_tile.h"
 #include "common.h"
 
@@ -224,7 +226,7 @@ __global__ void __launch_bounds__(256) prepare_for_decode_kernel(const int32_t* 
 // ---------------------------------------------------------------------------------------------
 // generic stage 1: one wave per (request, query head, split); any head size, any float type
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DV_PER_LANE>
+template <typename T, typename KV, int DV_PER_LANE>
 __global__ void __launch_bounds__(64) decode_stage1_generic(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(64) decode_stage1_generic(
     float s = 0.f;
     if (valid) {
       const int64_t kb = loc * k_stride_n + (int64_t)kvh * k_stride_h;
-      for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(k_buffer, kb + d);
+      for (int d = 0; d < D; ++d) s += qs[d] * KvElem<KV>::ld(k_buffer, kb + d);
       s *= sm_scale;
       if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
     } else {
@@ -275,7 +277,7 @@ __global__ void __launch_bounds__(64) decode_stage1_generic(
 #pragma unroll
       for (int i = 0; i < DV_PER_LANE; ++i) {
         const int d = lane + 64 * i;
-        if (d < Dv) acc[i] += pj * ld<T>(v_buffer, vb + d);
+        if (d < Dv) acc[i] += pj * KvElem<KV>::ld(v_buffer, vb + d);
       }
     }
   }
@@ -356,7 +358,7 @@ __device__ __forceinline__ int tail_splits(int len, int max_splits) {
 // the pair64 heads of its first kv head followed by the pair64 heads of its second.  A query row is placed in the half
 // of the 128-wide operand that faces its own kv head, the other half is zero, so S is exactly q . k of its own head;
 // O = P . [v_first, v_second] holds the head's output in the same half, which alone is stored (rows of 64).
-template <typename T>
+template <typename T, typename KV = T>
 __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     const void* __restrict__ q, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
@@ -368,6 +370,12 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   const int wid = threadIdx.x >> 6;
   char* kl = lds_all + wid * kLdsPerWave;
   char* vl = kl + kTileBytes;
+  // fp8 pool: code -> value table behind the waves' tiles, built before any wave may leave
+  [[maybe_unused]] uint16_t* lut = reinterpret_cast<uint16_t*>(lds_all + kWavesPerBlock * kLdsPerWave);
+  if constexpr (!std::is_same<KV, T>::value) {
+    lut[threadIdx.x] = Conv<T>::from_f32(KvElem<KV>::value(threadIdx.x));  // 256 threads, 256 codes
+    __syncthreads();
+  }
 
   const int b = blockIdx.x;
   const int kvh = blockIdx.y / head_tiles, ht = blockIdx.y - kvh * head_tiles;
@@ -396,9 +404,14 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
   else
     wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
                       : nullptr);
-  wa.run(kl, vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-         reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
-         kv_indices + start, s0, s1, sm_scale, logit_cap);
+  if constexpr (std::is_same<KV, T>::value)
+    wa.run(kl, vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+           reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+           kv_indices + start, s0, s1, sm_scale, logit_cap);
+  else
+    wa.run8(kl, vl, lut, reinterpret_cast<const uint8_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+            reinterpret_cast<const uint8_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+            kv_indices + start, s0, s1, sm_scale, logit_cap);
   const float m = wa.m;
   const float4v(&oacc)[8] = wa.oacc;
 
@@ -973,6 +986,9 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
                              int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
                              int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
                              int dtype, float* xsum_out, int64_t xs_stride, void* stream) {
+  const int kvf = dtype >> SGLK_KV_SHIFT;  // fp8 pool format, 0: pool elements of the query type
+  dtype &= (1 << SGLK_KV_SHIFT) - 1;
+  SGLK_CHECK(kvf == 0 || dtype == SGLK_F16 || dtype == SGLK_BF16, "decode_attention: an fp8 pool needs fp16 / bf16 queries");
   SGLK_CHECK(!xsum_out || (Dv == 128 && xs_stride >= B), "decode_attention: block sums need Dv == 128 and xs_stride >= B");
   SGLK_CHECK(q && k_buffer && v_buffer && o && kv_indptr && kv_indices && attn_logits && attn_lse && num_kv_splits,
              "decode_attention: null pointer");
@@ -983,21 +999,37 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
   if (B == 0) return SGLK_OK;
   hipStream_t s = (hipStream_t)stream;
   const int group = Hq / Hkv;
-  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
+  const bool fast = kvf == 0 && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q) &&
                     aligned16(k_buffer) && aligned16(v_buffer) && aligned16(attn_logits) && (q_stride_b % 8 == 0) &&
                     (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) && (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) &&
                     (v_stride_h % 8 == 0);
   // head size 64 with an even number of kv heads whose rows are contiguous: pairs of kv heads on the 128-wide kernel
-  const bool pair64 = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 64 && Dv == 64 && Hkv % 2 == 0 &&
+  const bool pair64 = kvf == 0 && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 64 && Dv == 64 && Hkv % 2 == 0 &&
                       k_stride_h == 64 && v_stride_h == 64 && aligned16(q) && aligned16(k_buffer) && aligned16(v_buffer) &&
                       aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
                       (v_stride_n % 8 == 0);
   // absorbed MLA: V is a view of the first 512 elements of the 576-element K rows (memory_pool.py:492-521)
-  const bool mla = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == kMlaD && Dv == kMlaDv && v_buffer == k_buffer &&
+  const bool mla = kvf == 0 && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == kMlaD && Dv == kMlaDv && v_buffer == k_buffer &&
                    v_stride_n == k_stride_n && v_stride_h == k_stride_h && aligned16(q) && aligned16(k_buffer) &&
                    aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
                    (k_stride_h % 8 == 0);
-  if (mla) {
+  // an fp8 pool of head size 128 on the same tile kernel: rows widened through a table on their way into LDS
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  const bool fast8 = kvf != 0 && D == 128 && Dv == 128 && aligned16(q) && al8(k_buffer) && al8(v_buffer) &&
+                     aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
+                     (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) && (v_stride_h % 8 == 0);
+  if (fast8) {
+    const int head_tiles = (group + 15) / 16;
+    dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
+    const size_t lds = (size_t)kWavesPerBlock * kLdsPerWave + 512;
+    SGLK_DISPATCH_HALF(dtype, T, {
+      SGLK_DISPATCH_KV(kvf, T, KV, {
+        hipLaunchKernelGGL((decode_stage1_mfma128<T, KV>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer, v_buffer,
+                           kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles,
+                           q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, 0);
+      });
+    });
+  } else if (mla) {
     const int head_tiles = (group + 15) / 16;
     dim3 grid(B, Hkv * head_tiles, max_kv_splits);
     SGLK_DISPATCH_HALF(dtype, T,
@@ -1027,23 +1059,31 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
     dim3 grid(B, Hq, max_kv_splits);
     const size_t lds = (size_t)D * sizeof(float);
     const int per_lane = (Dv + 63) / 64;
-#define SGLK_GEN(N)                                                                                               \
-  hipLaunchKernelGGL((decode_stage1_generic<T, N>), grid, dim3(64), lds, s, q, k_buffer, v_buffer, kv_indptr,     \
-                     kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, D, Dv, q_stride_b, \
+#define SGLK_GEN(N)                                                                                                \
+  hipLaunchKernelGGL((decode_stage1_generic<T, KV, N>), grid, dim3(64), lds, s, q, k_buffer, v_buffer, kv_indptr,  \
+                     kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, D, Dv, q_stride_b,  \
                      q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap)
-    SGLK_DISPATCH_FLOAT(dtype, T, {
-      if (per_lane <= 1) {
-        SGLK_GEN(1);
-      } else if (per_lane <= 2) {
-        SGLK_GEN(2);
-      } else if (per_lane <= 4) {
-        SGLK_GEN(4);
-      } else if (per_lane <= 8) {
-        SGLK_GEN(8);
-      } else {
-        SGLK_GEN(16);
-      }
-    });
+#define SGLK_GEN_ANY()   \
+  if (per_lane <= 1) {   \
+    SGLK_GEN(1);         \
+  } else if (per_lane <= 2) { \
+    SGLK_GEN(2);         \
+  } else if (per_lane <= 4) { \
+    SGLK_GEN(4);         \
+  } else if (per_lane <= 8) { \
+    SGLK_GEN(8);         \
+  } else {               \
+    SGLK_GEN(16);        \
+  }
+    if (kvf == 0) {
+      SGLK_DISPATCH_FLOAT(dtype, T, {
+        using KV = T;
+        SGLK_GEN_ANY();
+      });
+    } else {
+      SGLK_DISPATCH_HALF(dtype, T, { SGLK_DISPATCH_KV(kvf, T, KV, { SGLK_GEN_ANY(); }); });
+    }
+#undef SGLK_GEN_ANY
 #undef SGLK_GEN
   }
   SGLK_LAUNCH_CHECK();

@@ -8,6 +8,8 @@
 // Fast path (16-bit, D = Dv = 128): one block per (sequence, query head, 64*NC query rows); the four waves
 // share every 32-token K/V tile through LDS and each multiplies it against NC tiles of 16 query rows on
 // the matrix cores.  Everything else takes a wave-per-(query row, head) kernel.
+#include <type_traits>
+
 #include "attention_tile.h"
 #include "common.h"
 
@@ -20,7 +22,7 @@ constexpr int kNC = 2;
 #endif
 constexpr int kExtPF = SGLK_EXTEND_PF;  // K / V tiles in flight ahead of the one being multiplied
 
-template <typename T, int NC>
+template <typename T, int NC, typename KV = T>
 __global__ void __launch_bounds__(256) extend_attention_mfma128(
     const void* __restrict__ q_extend, const void* __restrict__ k_extend, const void* __restrict__ v_extend,
     void* __restrict__ o_extend, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
@@ -40,6 +42,10 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
   const int split = kv_splits > 1 ? (int)blockIdx.x % kv_splits : 0;
   const int block_q0 = (kv_splits > 1 ? (int)blockIdx.x / kv_splits : (int)blockIdx.x) * 64 * NC;
   if (block_q0 >= ext_len) return;  // block-uniform
+  // fp8 pool: code -> value table behind the two stages (visible after the barrier that opens every run())
+  constexpr bool KV8 = !std::is_same<KV, T>::value;
+  [[maybe_unused]] uint16_t* lut = reinterpret_cast<uint16_t*>(lds + kBlockAttnLds);
+  if constexpr (KV8) lut[threadIdx.x] = Conv<T>::from_f32(KvElem<KV>::value(threadIdx.x));  // 256 threads, 256 codes
   const int pstart = kv_indptr[b];
   const int plen = kv_indptr[b + 1] - pstart;
   const int kvh = h / (Hq / Hkv);
@@ -69,16 +75,20 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     const int shift = plen - ext_len;
 #pragma unroll
     for (int c = 0; c < NC; ++c) qpos[c] += shift;
-    const uint16_t* kb = reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h;
-    const uint16_t* vb = reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h;
+    // (an fp8 pool: byte pointers and byte strides, carried in the 16-bit pointer type of run())
+    constexpr int kEl = KV8 ? 1 : 2;
+    const uint16_t* kb = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(k_buffer) + (int64_t)kvh * k_stride_h * kEl);
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(v_buffer) + (int64_t)kvh * v_stride_h * kEl);
     if (causal) {
       const int t_end = min(plen, shift + block_q0 + 64 * NC);
       if (t_end > 0)
-        st.template run<true, true, kExtPF>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, t_end, qpos,
-                                    wave_qmax + shift, sm_scale, logit_cap);
+        st.template run<true, true, kExtPF, typename BlockAttn<T, NC>::NoHook, KV8>(
+            lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, t_end, qpos, wave_qmax + shift, sm_scale,
+            logit_cap, typename BlockAttn<T, NC>::NoHook(), lut);
     } else if (plen > 0) {
-      st.template run<false, true, kExtPF>(lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, plen, qpos, 0, sm_scale,
-                                   logit_cap);
+      st.template run<false, true, kExtPF, typename BlockAttn<T, NC>::NoHook, KV8>(
+          lds, kb, vb, k_stride_n, v_stride_n, kv_indices + pstart, 0, plen, qpos, 0, sm_scale, logit_cap,
+          typename BlockAttn<T, NC>::NoHook(), lut);
     }
   } else {
   int p0 = 0, p1 = plen;
@@ -88,9 +98,12 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
     p1 = min(p0 + per, plen);
   }
   if (p1 > p0) {
-    st.template run<false, true, kExtPF>(lds, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-                                 reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n,
-                                 v_stride_n, kv_indices + pstart, p0, p1, qpos, wave_qmax, sm_scale, logit_cap);
+    constexpr int kEl = KV8 ? 1 : 2;
+    st.template run<false, true, kExtPF, typename BlockAttn<T, NC>::NoHook, KV8>(
+        lds, reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(k_buffer) + (int64_t)kvh * k_stride_h * kEl),
+        reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(v_buffer) + (int64_t)kvh * v_stride_h * kEl),
+        k_stride_n, v_stride_n, kv_indices + pstart, p0, p1, qpos, wave_qmax, sm_scale, logit_cap,
+        typename BlockAttn<T, NC>::NoHook(), lut);
   }
   const uint16_t* ke = reinterpret_cast<const uint16_t*>(k_extend) + (int64_t)q0 * ke_stride_t + (int64_t)kvh * ke_stride_h;
   const uint16_t* ve = reinterpret_cast<const uint16_t*>(v_extend) + (int64_t)q0 * ve_stride_t + (int64_t)kvh * ve_stride_h;
@@ -161,7 +174,7 @@ __global__ void __launch_bounds__(128) extend_merge_kernel(const float* __restri
 }
 
 // one wave per (query row, head): any head size, any float type
-template <typename T, int DV_PER_LANE>
+template <typename T, typename KV, int DV_PER_LANE>
 __global__ void __launch_bounds__(64) extend_attention_generic(
     const void* __restrict__ q_extend, const void* __restrict__ k_extend, const void* __restrict__ v_extend,
     void* __restrict__ o_extend, const void* __restrict__ k_buffer, const void* __restrict__ v_buffer,
@@ -218,7 +231,11 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
     const bool shown = valid && in_window && (!mrow || (in_prefix && skip_prefix_mask) || mrow[tok] != 0);
     if (shown) {
       s = 0.f;
-      for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(kp, kb + d);
+      if (in_prefix) {
+        for (int d = 0; d < D; ++d) s += qs[d] * KvElem<KV>::ld(kp, kb + d);
+      } else {
+        for (int d = 0; d < D; ++d) s += qs[d] * ld<T>(kp, kb + d);
+      }
       s *= sm_scale;
       if (logit_cap > 0.f) s = logit_cap * tanhf(s / logit_cap);
     }
@@ -234,11 +251,11 @@ __global__ void __launch_bounds__(64) extend_attention_generic(
     for (int j = 0; j < cnt; ++j) {
       const float pj = __shfl(p, j, 64);
       const int64_t vj = __shfl((long long)vb, j, 64);
-      const void* vsrc = (paged || (t0 + j) < plen) ? v_buffer : v_extend;
+      const bool from_pool = paged || (t0 + j) < plen;
 #pragma unroll
       for (int i = 0; i < DV_PER_LANE; ++i) {
         const int d = lane + 64 * i;
-        if (d < Dv) acc[i] += pj * ld<T>(vsrc, vj + d);
+        if (d < Dv) acc[i] += pj * (from_pool ? KvElem<KV>::ld(v_buffer, vj + d) : ld<T>(v_extend, vj + d));
       }
     }
     (void)vp;
@@ -265,6 +282,9 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
                                  bool paged, const uint8_t* custom_mask = nullptr, const int64_t* mask_indptr = nullptr,
                                  int skip_prefix_mask = 1, int window = 0, int kv_splits = 1, float* split_ws = nullptr,
                                  int64_t total_rows = 0) {
+  const int kvf = dtype >> SGLK_KV_SHIFT;  // fp8 pool format, 0: pool elements of the query type
+  dtype &= (1 << SGLK_KV_SHIFT) - 1;
+  SGLK_CHECK(kvf == 0 || dtype == SGLK_F16 || dtype == SGLK_BF16, "extend_attention: an fp8 pool needs fp16 / bf16 queries");
   SGLK_CHECK(!custom_mask || (mask_indptr && !paged), "extend_attention: a custom mask needs mask_indptr and new K/V");
   SGLK_CHECK(q_extend && o_extend && qo_indptr && kv_indptr && (paged || (k_extend && v_extend)),
              "extend_attention: null pointer");
@@ -274,77 +294,85 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
   SGLK_CHECK(max_extend_len >= 0, "extend_attention: negative max_extend_len");
   if (B == 0 || max_extend_len == 0) return SGLK_OK;
   // a batch without any cached prefix may pass no pool at all
+  SGLK_CHECK(kvf == 0 || (k_buffer && v_buffer), "extend_attention: an fp8 pool format without a pool");
   if (!k_buffer) k_buffer = k_extend;
   if (!v_buffer) v_buffer = v_extend;
   if (paged) k_extend = v_extend = nullptr;  // the kernels take a null k_extend as "every token is in the pool"
   hipStream_t s = (hipStream_t)stream;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
-  const bool fast = !custom_mask && window <= 0 && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && aligned16(q_extend) &&
-                    (paged || (aligned16(k_extend) && aligned16(v_extend))) && aligned16(k_buffer) && aligned16(v_buffer) &&
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  // the pool side of the tile kernel's requirements: 16-byte row pieces of 16-bit elements, or 8-byte pieces of codes
+  const bool pool_ok = (kvf ? (al8(k_buffer) && al8(v_buffer)) : (aligned16(k_buffer) && aligned16(v_buffer))) &&
+                       mult8(k_stride_n) && mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h);
+  const bool fast = !custom_mask && window <= 0 && (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 &&
+                    aligned16(q_extend) && (paged || (aligned16(k_extend) && aligned16(v_extend))) && pool_ok &&
                     ((uintptr_t)o_extend % 8 == 0) && mult8(q_stride_t) && mult8(q_stride_h) && mult8(ke_stride_t) &&
-                    mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && mult8(k_stride_n) &&
-                    mult8(k_stride_h) && mult8(v_stride_n) && mult8(v_stride_h) && o_stride_t % 4 == 0 &&
+                    mult8(ke_stride_h) && mult8(ve_stride_t) && mult8(ve_stride_h) && o_stride_t % 4 == 0 &&
                     o_stride_h % 4 == 0;
   // One column tile per wave (64 query rows per block) keeps the kernel at two blocks per CU; two tiles per wave
   // halve the K/V re-reads but run at one wave per SIMD and measured 25 % slower (SGLK_EXTEND_NC=2 selects them).
   const char* env_nc = getenv("SGLK_EXTEND_NC");
+  const size_t tile_lds = kBlockAttnLds + (kvf ? kKv8LutBytes : 0);
+#define SGLK_EXT_TILE(NCV, GRID, SPLITS, PO, PL)                                                                       \
+  SGLK_DISPATCH_HALF(dtype, T, {                                                                                       \
+    SGLK_DISPATCH_KV(kvf, T, KV, {                                                                                     \
+      hipLaunchKernelGGL((extend_attention_mfma128<T, NCV, KV>), GRID, dim3(256), tile_lds, s, q_extend, k_extend,      \
+                         v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, q_stride_t, \
+                         q_stride_h, ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h,        \
+                         k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, SPLITS, PO, PL);  \
+    });                                                                                                                \
+  })
   if (kv_splits > 1) {
     if (!fast || paged)
       return fail(SGLK_EUNSUP, "extend_attention_split: 16-bit types with head size 128 and contiguous new tokens only");
     float* part_o = split_ws;
     float* part_lse = split_ws + total_rows * Hq * kv_splits * 128;
     dim3 grid(((max_extend_len + 63) / 64) * kv_splits, Hq, B);
-    SGLK_DISPATCH_HALF(dtype, T, {
-      hipLaunchKernelGGL((extend_attention_mfma128<T, 1>), grid, dim3(256), kBlockAttnLds, s, q_extend, k_extend, v_extend,
-                         o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h,
-                         ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
-                         k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, kv_splits, part_o, part_lse);
-      hipLaunchKernelGGL((extend_merge_kernel<T>), dim3((unsigned)total_rows, Hq), dim3(128), 0, s, part_o, part_lse,
-                         o_extend, Hq, kv_splits, o_stride_t, o_stride_h);
-    });
+    SGLK_EXT_TILE(1, grid, kv_splits, part_o, part_lse);
+    SGLK_LAUNCH_CHECK();
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((extend_merge_kernel<T>), dim3((unsigned)total_rows, Hq), dim3(128), 0, s, part_o,
+                                          part_lse, o_extend, Hq, kv_splits, o_stride_t, o_stride_h));
   } else if (fast && !(env_nc && atoi(env_nc) == 2)) {
     dim3 grid((max_extend_len + 63) / 64, Hq, B);
-    SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((extend_attention_mfma128<T, 1>), grid, dim3(256), kBlockAttnLds, s,
-                                          q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
-                                          kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h, ke_stride_t,
-                                          ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, 1, nullptr,
-                                          nullptr));
+    SGLK_EXT_TILE(1, grid, 1, (float*)nullptr, (float*)nullptr);
   } else if (fast) {
     dim3 grid((max_extend_len + 64 * kNC - 1) / (64 * kNC), Hq, B);
-    SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((extend_attention_mfma128<T, kNC>), grid, dim3(256), kBlockAttnLds, s,
-                                          q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr,
-                                          kv_indptr, kv_indices, Hq, Hkv, q_stride_t, q_stride_h, ke_stride_t,
-                                          ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, 1, nullptr,
-                                          nullptr));
+    SGLK_EXT_TILE(kNC, grid, 1, (float*)nullptr, (float*)nullptr);
   } else {
     dim3 grid(max_extend_len, Hq, B);
     const size_t lds = (size_t)D * sizeof(float);
     const int per_lane = (Dv + 63) / 64;
 #define SGLK_GEN(N)                                                                                                   \
-  hipLaunchKernelGGL((extend_attention_generic<T, N>), grid, dim3(64), lds, s, q_extend, k_extend, v_extend, o_extend, \
+  hipLaunchKernelGGL((extend_attention_generic<T, KV, N>), grid, dim3(64), lds, s, q_extend, k_extend, v_extend, o_extend, \
                      k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices, Hq, Hkv, D, Dv, q_stride_t, q_stride_h,     \
                      ke_stride_t, ke_stride_h, ve_stride_t, ve_stride_h, o_stride_t, o_stride_h, k_stride_n,           \
                      k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, causal, custom_mask, mask_indptr,        \
                      skip_prefix_mask, window)
-    SGLK_DISPATCH_FLOAT(dtype, T, {
-      if (per_lane <= 1) {
-        SGLK_GEN(1);
-      } else if (per_lane <= 2) {
-        SGLK_GEN(2);
-      } else if (per_lane <= 4) {
-        SGLK_GEN(4);
-      } else if (per_lane <= 8) {
-        SGLK_GEN(8);
-      } else {
-        SGLK_GEN(16);
-      }
-    });
+#define SGLK_GEN_ANY()   \
+  if (per_lane <= 1) {   \
+    SGLK_GEN(1);         \
+  } else if (per_lane <= 2) { \
+    SGLK_GEN(2);         \
+  } else if (per_lane <= 4) { \
+    SGLK_GEN(4);         \
+  } else if (per_lane <= 8) { \
+    SGLK_GEN(8);         \
+  } else {               \
+    SGLK_GEN(16);        \
+  }
+    if (kvf == 0) {
+      SGLK_DISPATCH_FLOAT(dtype, T, {
+        using KV = T;
+        SGLK_GEN_ANY();
+      });
+    } else {
+      SGLK_DISPATCH_HALF(dtype, T, { SGLK_DISPATCH_KV(kvf, T, KV, { SGLK_GEN_ANY(); }); });
+    }
+#undef SGLK_GEN_ANY
 #undef SGLK_GEN
   }
+#undef SGLK_EXT_TILE
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

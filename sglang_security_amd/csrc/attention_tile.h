@@ -184,6 +184,19 @@ __device__ __forceinline__ void store_new_kv(const QkvPartials& qp, int token, i
 // ---------------------------------------------------------------------------------------------------
 static constexpr int kBlockAttnLds = 2 * 2 * kTileBytes;  // two stages of (K tile + V tile)
 
+// fp8 pools: eight one-byte codes -> eight values of the 16-bit type through a 256-entry table in LDS
+// (lut[code] = the code's exact value: every fp8 value, denormal, infinity and NaN has one in fp16 and in bf16)
+static constexpr int kKv8LutBytes = 512;
+__device__ __forceinline__ int4v kv8_widen(const uint16_t* lut, int lo, int hi) {
+  int4v out;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const uint32_t word = (uint32_t)(p < 2 ? lo : hi) >> (16 * (p & 1));
+    out[p] = (int)((uint32_t)lut[word & 0xFFu] | ((uint32_t)lut[(word >> 8) & 0xFFu] << 16));
+  }
+  return out;
+}
+
 template <typename T, int NC>
 struct BlockAttn {
   float m[NC];      // running maximum per column (log2 domain), replicated over the four lane groups
@@ -222,11 +235,13 @@ struct BlockAttn {
     __device__ __forceinline__ void operator()() const {}
   };
   // after_fetch runs once the first tiles' loads are on their way (e.g. to assemble the Q operand in their shadow)
-  template <bool CAUSAL, bool GATHER, int PF = 1, typename Hook = NoHook>
+  // KV8: the rows are 128 one-byte codes of an fp8 pool (kbase / vbase byte pointers, strides in bytes): they travel
+  // as 8-byte pieces and are widened through `lut` when parked.
+  template <bool CAUSAL, bool GATHER, int PF = 1, typename Hook = NoHook, bool KV8 = false>
   __device__ __forceinline__ void run(char* lds, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
                                       int64_t v_stride_n, const int32_t* idx, int t_begin, int t_end,
                                       const int (&qpos)[NC], int wave_qmax, float sm_scale, float logit_cap,
-                                      Hook after_fetch = Hook()) {
+                                      Hook after_fetch = Hook(), const uint16_t* lut = nullptr) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hl = lane & 15, g = lane >> 4;
@@ -250,8 +265,15 @@ struct BlockAttn {
     auto fetch = [&](int4v(&kr)[2], int4v(&vr)[2], const int64_t(&ri)[2]) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        kr[i] = *reinterpret_cast<const int4v*>(kbase + ri[i] * k_stride_n + chunk * 8);
-        vr[i] = *reinterpret_cast<const int4v*>(vbase + ri[i] * v_stride_n + chunk * 8);
+        if constexpr (KV8) {
+          const int2v a = *reinterpret_cast<const int2v*>(reinterpret_cast<const uint8_t*>(kbase) + ri[i] * k_stride_n + chunk * 8);
+          const int2v b = *reinterpret_cast<const int2v*>(reinterpret_cast<const uint8_t*>(vbase) + ri[i] * v_stride_n + chunk * 8);
+          kr[i] = int4v{a[0], a[1], 0, 0};
+          vr[i] = int4v{b[0], b[1], 0, 0};
+        } else {
+          kr[i] = *reinterpret_cast<const int4v*>(kbase + ri[i] * k_stride_n + chunk * 8);
+          vr[i] = *reinterpret_cast<const int4v*>(vbase + ri[i] * v_stride_n + chunk * 8);
+        }
       }
     };
     // One K / V fragment read from LDS feeds all NC column tiles of the wave.
@@ -337,8 +359,13 @@ struct BlockAttn {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int r = frow + 16 * i;
-            *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[p][i];
-            *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[p][i];
+            if constexpr (KV8) {
+              *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kv8_widen(lut, kreg[p][i][0], kreg[p][i][1]);
+              *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = kv8_widen(lut, vreg[p][i][0], vreg[p][i][1]);
+            } else {
+              *reinterpret_cast<int4v*>(kl + k_off(r, chunk)) = kreg[p][i];
+              *reinterpret_cast<int4v*>(vl + v_off(r, chunk * 16)) = vreg[p][i];
+            }
           }
           __syncthreads();
           if (t0 + PF * kTile < t_end) {  // flies while tiles are multiplied
@@ -551,6 +578,61 @@ struct WaveAttn {
       park(other, kl, vl);
       if (t0 + 3 * kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, slots_next, kTile);
       if (t0 + 4 * kTile < s1) slots_next = load_slots(idx, t0 + 4 * kTile, s0, s1);
+      step(kl, vl, t0 + kTile, s1, true, sm_scale, logit_cap);
+    }
+  }
+
+  // ---- fp8 pools ---------------------------------------------------------------------------------------------
+  // A pool row of 128 one-byte elements travels as 8-byte pieces (16 lanes per row) and is widened to T on its way into
+  // the LDS tile, through a 256-entry table the block builds once (lut[code] = the code's exact value in T: every
+  // fp8 value, its denormals, infinities and NaNs have one), so the tile step above runs unchanged.
+  struct Rows8 {
+    int2v k[8], v[8];
+  };
+
+  static __device__ __forceinline__ void fetch8(Rows8& r, const uint8_t* kbase, const uint8_t* vbase, int64_t k_stride_n,
+                                                int64_t v_stride_n, int slots, int off) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t slot = __shfl(slots, off + 4 * i + g, 64);
+      r.k[i] = *reinterpret_cast<const int2v*>(kbase + slot * k_stride_n + chunk * 8);
+      r.v[i] = *reinterpret_cast<const int2v*>(vbase + slot * v_stride_n + chunk * 8);
+    }
+  }
+
+  static __device__ __forceinline__ void park8(const Rows8& r, char* kl, char* vl, const uint16_t* lut) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, chunk = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = 4 * i + g;
+      *reinterpret_cast<int4v*>(kl + k_off(row, chunk)) = kv8_widen(lut, r.k[i][0], r.k[i][1]);
+      *reinterpret_cast<int4v*>(vl + v_off(row, chunk * 16)) = kv8_widen(lut, r.v[i][0], r.v[i][1]);
+    }
+  }
+
+  // run() over an fp8 pool (strides in bytes)
+  __device__ __forceinline__ void run8(char* kl, char* vl, const uint16_t* lut, const uint8_t* kbase, const uint8_t* vbase,
+                                       int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
+                                       float sm_scale, float logit_cap) {
+    if (s1 <= s0) return;
+    Rows8 r;
+    int slots = load_slots(idx, s0, s0, s1);
+    int slots_next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
+    fetch8(r, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
+    for (int t0 = s0; t0 < s1; t0 += 2 * kTile) {
+      park8(r, kl, vl, lut);
+      if (t0 + kTile < s1) fetch8(r, kbase, vbase, k_stride_n, v_stride_n, slots, kTile);  // flies during the step
+      step(kl, vl, t0, s1, true, sm_scale, logit_cap);
+      if (t0 + kTile >= s1) break;
+      park8(r, kl, vl, lut);
+      slots = slots_next;
+      if (t0 + 2 * kTile < s1) {
+        fetch8(r, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
+        if (t0 + 4 * kTile < s1) slots_next = load_slots(idx, t0 + 4 * kTile, s0, s1);
+      }
       step(kl, vl, t0 + kTile, s1, true, sm_scale, logit_cap);
     }
   }

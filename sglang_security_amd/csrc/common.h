@@ -101,6 +101,93 @@ __device__ __forceinline__ void st(void* p, int64_t i, float v) {
   reinterpret_cast<R*>(p)[i] = Conv<T>::from_f32(v);
 }
 
+// ---- fp8 KV cache formats (SGLK_KV_* of sglk.h) ------------------------------------------------
+// The pool bytes are what torch's Tensor.to(float8 type) writes (mem_cache/memory_pool.py:389-400) and the kernels read
+// them back as `.to(query type)` does (triton_ops/decode_attention.py).  Both directions are integer arithmetic on
+// the fp32 bit pattern, the same for the three formats (gfx950's conversion instructions know the two OCP formats only,
+// and the reference's pool type on ROCm is the fnuz one, model_runner.py:847-851).
+template <int F>
+struct Fp8 {  // tag type: pool elements of format F
+  static constexpr int M = F == SGLK_KV_E4M3FN ? 3 : 2;                             // mantissa bits
+  static constexpr int B = F == SGLK_KV_E4M3FN ? 7 : (F == SGLK_KV_E5M2 ? 15 : 16);  // exponent bias
+};
+
+template <int F>
+__device__ __forceinline__ float kv8_to_f32(uint32_t b) {
+  constexpr int M = Fp8<F>::M, B = Fp8<F>::B;
+  const uint32_t mag = b & 0x7Fu;
+  float v;
+  if ((mag >> M) != 0) {
+    uint32_t bits = (mag << (23 - M)) + ((uint32_t)(127 - B) << 23);
+    if (F == SGLK_KV_E4M3FN && mag == 0x7Fu) bits = 0x7FC00000u;
+    if (F == SGLK_KV_E5M2 && mag >= 0x7Cu) bits = 0x7F800000u | ((mag & 3u) << 21);
+    v = __uint_as_float(bits);
+  } else {
+    v = (float)mag * __uint_as_float((uint32_t)(127 + 1 - B - M) << 23);  // denormals: mantissa * 2^(1 - B - M)
+  }
+  if (F == SGLK_KV_E5M2FNUZ) return b == 0x80u ? __uint_as_float(0x7FC00000u) : ((b & 0x80u) ? -v : v);
+  return (b & 0x80u) ? -v : v;
+}
+
+template <int F>
+__device__ __forceinline__ uint32_t f32_to_kv8(float x) {
+  constexpr int M = Fp8<F>::M, B = Fp8<F>::B, shift = 23 - M;
+  const uint32_t bits = __float_as_uint(x), sign = bits >> 31, a = bits & 0x7FFFFFFFu;
+  uint32_t code;
+  if (a < ((uint32_t)(1 - B + 127) << 23)) {
+    // below the smallest normal: the integer nearest to |x| / 2^(1 - B - M), ties to even, read off the mantissa of
+    // |x| + 2^(24 - B - M)
+    const float magic = __uint_as_float((uint32_t)(24 - B - M + 127) << 23);
+    code = __float_as_uint(__fadd_rn(__uint_as_float(a), magic)) - __float_as_uint(magic);
+  } else {
+    const uint32_t r = a + ((1u << (shift - 1)) - 1u) + ((a >> shift) & 1u);
+    code = (r >> shift) - ((uint32_t)(127 - B) << M);
+  }
+  if (F == SGLK_KV_E5M2FNUZ) {
+    if (code >= 0x80u || a >= 0x7F800000u) return 0x80u;  // out of range and NaN: the one NaN code
+    return code ? (code | (sign << 7)) : 0u;              // no negative zero
+  }
+  code = code < (F == SGLK_KV_E4M3FN ? 0x7Fu : 0x7Cu) ? code : (F == SGLK_KV_E4M3FN ? 0x7Fu : 0x7Cu);
+  if (a > 0x7F800000u) code = 0x7Fu;
+  return code | (sign << 7);
+}
+
+// element loads of a K / V pool: KV is the query type T (16- or 32-bit floats) or Fp8<F> (one byte per element)
+template <typename KV>
+struct KvElem {
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) { return ::sglk::ld<KV>(p, i); }
+};
+template <int F>
+struct KvElem<Fp8<F>> {
+  static __device__ __forceinline__ float ld(const void* p, int64_t i) {
+    return kv8_to_f32<F>(reinterpret_cast<const uint8_t*>(p)[i]);
+  }
+  static __device__ __forceinline__ float value(uint32_t code) { return kv8_to_f32<F>(code); }
+};
+
+// kvf: 0 (pool elements of type T) or SGLK_KV_*; binds KV accordingly
+#define SGLK_DISPATCH_KV(kvf, T, KV, ...)                                   \
+  switch (kvf) {                                                            \
+    case 0: {                                                               \
+      using KV = T;                                                         \
+      __VA_ARGS__;                                                          \
+    } break;                                                                \
+    case SGLK_KV_E4M3FN: {                                                  \
+      using KV = ::sglk::Fp8<SGLK_KV_E4M3FN>;                               \
+      __VA_ARGS__;                                                          \
+    } break;                                                                \
+    case SGLK_KV_E5M2: {                                                    \
+      using KV = ::sglk::Fp8<SGLK_KV_E5M2>;                                 \
+      __VA_ARGS__;                                                          \
+    } break;                                                                \
+    case SGLK_KV_E5M2FNUZ: {                                                \
+      using KV = ::sglk::Fp8<SGLK_KV_E5M2FNUZ>;                             \
+      __VA_ARGS__;                                                          \
+    } break;                                                                \
+    default:                                                                \
+      return ::sglk::fail(SGLK_EINVAL, "unknown KV pool format %d", kvf);   \
+  }
+
 // ---- wave (64 lanes) reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

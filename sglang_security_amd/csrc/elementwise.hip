@@ -490,6 +490,45 @@ __global__ void __launch_bounds__(256) set_kv_kernel(char* k_buffer, char* v_buf
   }
 }
 
+// The same scatter into an fp8 pool (memory_pool.py:389-400): optional division by a scale, evaluated as the product
+// with the fp32 reciprocal and rounded to the source type (what `cache_k.div_(k_scale)` gives on the device), then
+// the fp8 rounding of Tensor.to().  One block per token; a thread converts four neighbouring elements into one word
+// when the row allows it.
+template <typename T, int F>
+__device__ __forceinline__ uint32_t kv8_from(const void* src, int64_t i, float inv, bool scaled) {
+  float x = ld<T>(src, i);
+  if (scaled) x = (float)Conv<T>::to_f32(Conv<T>::from_f32(__fmul_rn(x, inv)));
+  return f32_to_kv8<F>(x);
+}
+template <typename T, int F>
+__global__ void __launch_bounds__(256) set_kv_fp8_kernel(uint8_t* k_buffer, uint8_t* v_buffer, const void* k, const void* v,
+                                                         const void* loc, int loc_is64, int row_k, int row_v,
+                                                         int64_t kbuf_stride, int64_t vbuf_stride, int64_t k_stride,
+                                                         int64_t v_stride, float k_inv, float v_inv, int k_scaled,
+                                                         int v_scaled, int vec) {
+  const int64_t t = blockIdx.x;
+  const int64_t slot = ld_idx(loc, loc_is64, t);
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    uint8_t* dst = which ? v_buffer + slot * vbuf_stride : k_buffer + slot * kbuf_stride;
+    const void* src = which ? v : k;
+    const int64_t s0 = t * (which ? v_stride : k_stride);
+    const int row = which ? row_v : row_k;
+    const float inv = which ? v_inv : k_inv;
+    const bool scaled = which ? v_scaled != 0 : k_scaled != 0;
+    if (vec) {
+      for (int i = threadIdx.x; i < (row >> 2); i += 256) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w |= kv8_from<T, F>(src, s0 + 4 * i + e, inv, scaled) << (8 * e);
+        reinterpret_cast<uint32_t*>(dst)[i] = w;
+      }
+    } else {
+      for (int i = threadIdx.x; i < row; i += 256) dst[i] = (uint8_t)kv8_from<T, F>(src, s0 + i, inv, scaled);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // merge_state (merge_attn_states.cu:31-106 of the reference)
 // ---------------------------------------------------------------------------------------------
@@ -744,6 +783,36 @@ int sglk_set_kv_buffer(void* k_buffer, void* v_buffer, const void* k, const void
                   (vs % 16 == 0) && aligned16(k_buffer) && aligned16(v_buffer) && aligned16(k) && aligned16(v);
   hipLaunchKernelGGL(set_kv_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (char*)k_buffer,
                      (char*)v_buffer, (const char*)k, (const char*)v, loc, loc_is64, rk, rv, kb, vb, ks, vs, vec);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_set_kv_buffer_fp8(void* k_buffer, void* v_buffer, const void* k, const void* v, const void* loc, int loc_is64,
+                           int64_t tokens, int row_k, int row_v, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                           int64_t k_stride_t, int64_t v_stride_t, float k_scale, float v_scale, int src_dtype,
+                           int kv_format, void* stream) {
+  SGLK_CHECK(k_buffer && v_buffer && k && v && loc, "set_kv_buffer_fp8: null pointer");
+  SGLK_CHECK(tokens >= 0 && row_k > 0 && row_v > 0, "set_kv_buffer_fp8: bad shape");
+  SGLK_CHECK(kbuf_stride_n >= row_k && vbuf_stride_n >= row_v && k_stride_t >= row_k && v_stride_t >= row_v,
+             "set_kv_buffer_fp8: a stride is shorter than its row");
+  if (tokens == 0) return SGLK_OK;
+  const int vec = row_k % 4 == 0 && row_v % 4 == 0 && kbuf_stride_n % 4 == 0 && vbuf_stride_n % 4 == 0 &&
+                  (uintptr_t)k_buffer % 4 == 0 && (uintptr_t)v_buffer % 4 == 0;
+  const int ks = k_scale > 0.f, vs = v_scale > 0.f;
+  const float ki = ks ? 1.0f / k_scale : 1.0f, vi = vs ? 1.0f / v_scale : 1.0f;
+#define SGLK_SETKV8(F)                                                                                                 \
+  hipLaunchKernelGGL((set_kv_fp8_kernel<T, F>), dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream,              \
+                     (uint8_t*)k_buffer, (uint8_t*)v_buffer, k, v, loc, loc_is64, row_k, row_v, kbuf_stride_n,          \
+                     vbuf_stride_n, k_stride_t, v_stride_t, ki, vi, ks, vs, vec)
+  SGLK_DISPATCH_FLOAT(src_dtype, T, {
+    switch (kv_format) {
+      case SGLK_KV_E4M3FN: SGLK_SETKV8(SGLK_KV_E4M3FN); break;
+      case SGLK_KV_E5M2: SGLK_SETKV8(SGLK_KV_E5M2); break;
+      case SGLK_KV_E5M2FNUZ: SGLK_SETKV8(SGLK_KV_E5M2FNUZ); break;
+      default: return fail(SGLK_EINVAL, "set_kv_buffer_fp8: unknown KV pool format %d", kv_format);
+    }
+  });
+#undef SGLK_SETKV8
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -106,7 +106,8 @@ class MHATokenToKVPool:
         self.size = size
         self.page_size = page_size
         self.dtype = dtype
-        self.store_dtype = dtype
+        # an fp8 cache is kept as bytes and handed out as float8 views (memory_pool.py:119-123, 363-374)
+        self.store_dtype = torch.uint8 if ops.kv_format_code(dtype) else dtype
         self.head_num = head_num
         self.head_dim = head_dim
         self.v_head_dim = v_head_dim or head_dim
@@ -115,9 +116,9 @@ class MHATokenToKVPool:
         self.start_layer = start_layer or 0
         self.end_layer = end_layer if end_layer is not None else layer_num - 1
         # [size + page_size, head_num, head_dim] per layer; the padded slot 0 absorbs dummy writes
-        self.k_buffer = [torch.zeros((size + page_size, head_num, head_dim), dtype=dtype, device=device)
+        self.k_buffer = [torch.zeros((size + page_size, head_num, head_dim), dtype=self.store_dtype, device=device)
                          for _ in range(layer_num)]
-        self.v_buffer = [torch.zeros((size + page_size, head_num, self.v_head_dim), dtype=dtype, device=device)
+        self.v_buffer = [torch.zeros((size + page_size, head_num, self.v_head_dim), dtype=self.store_dtype, device=device)
                          for _ in range(layer_num)]
 
     def get_kv_size_bytes(self):
@@ -126,24 +127,34 @@ class MHATokenToKVPool:
         return k, v
 
     def get_key_buffer(self, layer_id: int):
-        return self.k_buffer[layer_id - self.start_layer]
+        b = self.k_buffer[layer_id - self.start_layer]
+        return b.view(self.dtype) if self.store_dtype != self.dtype else b
 
     def get_value_buffer(self, layer_id: int):
-        return self.v_buffer[layer_id - self.start_layer]
+        b = self.v_buffer[layer_id - self.start_layer]
+        return b.view(self.dtype) if self.store_dtype != self.dtype else b
 
     def get_kv_buffer(self, layer_id: int):
         return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
 
     def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor,
                       k_scale: Optional[float] = None, v_scale: Optional[float] = None):
-        """memory_pool.py:378-412 (the scale arguments belong to the fp8 KV cache, which this pool does not hold)."""
-        if k_scale is not None or v_scale is not None:
-            raise NotImplementedError("scaled (fp8) KV cache")
+        """memory_pool.py:378-412.  An fp8 pool divides the rows by the scales (if given) and rounds them to its
+        format in one kernel; the reference applies the scales only when the rows' type differs from the pool's
+        (:389-396), and so does this."""
         layer_id = layer.layer_id if hasattr(layer, "layer_id") else int(layer)
+        kb, vb = self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
         if cache_k.dtype != self.dtype:
+            if self.store_dtype != self.dtype:
+                ops.set_kv_buffer(kb, vb, loc, cache_k, cache_v, k_scale, v_scale)
+                return
+            if k_scale is not None:
+                cache_k = cache_k / k_scale
+            if v_scale is not None:
+                cache_v = cache_v / v_scale
             cache_k = cache_k.to(self.dtype)
             cache_v = cache_v.to(self.dtype)
-        ops.set_kv_buffer(self.get_key_buffer(layer_id), self.get_value_buffer(layer_id), loc, cache_k, cache_v)
+        ops.set_kv_buffer(kb, vb, loc, cache_k, cache_v)
 
 
 class MLATokenToKVPool:
@@ -156,24 +167,26 @@ class MLATokenToKVPool:
         self.size = size
         self.page_size = page_size
         self.dtype = dtype
-        self.store_dtype = dtype
+        # an fp8 cache is kept as bytes and handed out as float8 views (memory_pool.py:528-533, 576-593)
+        self.store_dtype = torch.uint8 if ops.kv_format_code(dtype) else dtype
         self.kv_lora_rank = kv_lora_rank
         self.qk_rope_head_dim = qk_rope_head_dim
         self.layer_num = layer_num
         self.device = device
         self.start_layer = start_layer or 0
         self.end_layer = end_layer if end_layer is not None else layer_num - 1
-        self.kv_buffer = [torch.zeros((size + page_size, 1, kv_lora_rank + qk_rope_head_dim), dtype=dtype, device=device)
-                          for _ in range(layer_num)]
+        self.kv_buffer = [torch.zeros((size + page_size, 1, kv_lora_rank + qk_rope_head_dim), dtype=self.store_dtype,
+                                      device=device) for _ in range(layer_num)]
 
     def get_kv_size_bytes(self):
         return sum(t.numel() * t.element_size() for t in self.kv_buffer)
 
     def get_key_buffer(self, layer_id: int):
-        return self.kv_buffer[layer_id - self.start_layer]
+        b = self.kv_buffer[layer_id - self.start_layer]
+        return b.view(self.dtype) if self.store_dtype != self.dtype else b
 
     def get_value_buffer(self, layer_id: int):
-        return self.kv_buffer[layer_id - self.start_layer][..., : self.kv_lora_rank]
+        return self.get_key_buffer(layer_id)[..., : self.kv_lora_rank]
 
     def get_kv_buffer(self, layer_id: int):
         return self.get_key_buffer(layer_id), self.get_value_buffer(layer_id)
@@ -181,9 +194,11 @@ class MLATokenToKVPool:
     def set_kv_buffer(self, layer, loc: torch.Tensor, cache_k: torch.Tensor, cache_v: torch.Tensor):
         """memory_pool.py:595-611: cache_k is the whole latent row; cache_v is ignored (it is a view of the same data)."""
         layer_id = layer.layer_id if hasattr(layer, "layer_id") else int(layer)
-        buf = self.kv_buffer[layer_id - self.start_layer]
-        row = cache_k.to(self.dtype).reshape(loc.numel(), 1, -1)
-        ops.set_kv_buffer(buf, buf, loc, row, row)
+        buf = self.get_key_buffer(layer_id)
+        row = cache_k.reshape(loc.numel(), 1, -1)
+        if self.store_dtype == self.dtype:
+            row = row.to(self.dtype)
+        ops.set_kv_buffer(buf, buf, loc, row, row)   # an fp8 pool rounds the rows as Tensor.to(float8) does
 
     def set_mla_kv_buffer(self, layer, loc: torch.Tensor, cache_k_nope: torch.Tensor, cache_k_rope: torch.Tensor):
         """memory_pool.py:613-625 (set_mla_kv_buffer_triton :446-508): the row is [nope | rope]."""

@@ -104,6 +104,30 @@ def common_prefix_len(req_to_token, req_pool_indices, seq_lens, out):
 
 
 # ------------------------------------------------------------------------------------------- A1
+# fp8 KV cache: pool tensors of these types (memory_pool.py:119-123 keeps them as uint8 and hands out float8 views)
+_KV_FORMATS = {torch.float8_e4m3fn: 1, torch.float8_e5m2: 2, torch.float8_e5m2fnuz: 3}
+_KV_SHIFT = 8
+
+
+def kv_format_code(dtype) -> int:
+    """SGLK_KV_* of a pool dtype, 0 when the pool holds the model's own float type."""
+    return _KV_FORMATS.get(dtype, 0)
+
+
+def _attn_dtype(q, k_buffer, v_buffer=None) -> int:
+    """dtype argument of the attention entry points: the query type, plus the pool's fp8 format when it has one."""
+    code = dtype_code(q.dtype)
+    if k_buffer is None or k_buffer.dtype == q.dtype:
+        return code
+    f = kv_format_code(k_buffer.dtype)
+    if f == 0 or (v_buffer is not None and v_buffer.dtype != k_buffer.dtype):
+        raise SglkError(f"attention: pool dtype {k_buffer.dtype} with queries of {q.dtype}: the pool holds the query type "
+                        f"or one of {sorted(str(t) for t in _KV_FORMATS)}")
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise SglkError("attention: an fp8 pool needs fp16 / bf16 queries")
+    return code | (f << _KV_SHIFT)
+
+
 def _last_dim_contig(t, name):
     if t.stride(-1) != 1:
         raise SglkError(f"{name}: last dimension must be contiguous")
@@ -118,8 +142,8 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
     assert q.shape[0] <= attn_logits.shape[0]
     for t, n in ((q, "q"), (k_buffer, "k_buffer"), (v_buffer, "v_buffer"), (o, "o")):
         _last_dim_contig(t, n)
-    if not (q.dtype == k_buffer.dtype == v_buffer.dtype == o.dtype):
-        raise SglkError("decode_attention: q, k_buffer, v_buffer, o must share a dtype")
+    if q.dtype != o.dtype or k_buffer.dtype != v_buffer.dtype:
+        raise SglkError("decode_attention: q and o share a dtype, k_buffer and v_buffer share a dtype")
     if attn_logits.dtype != torch.float32 or attn_lse.dtype != torch.float32 or not attn_logits.is_contiguous():
         raise SglkError("decode_attention: attn_logits / attn_lse must be contiguous fp32")
     if kv_indptr.dtype != torch.int32 or kv_indices.dtype != torch.int32 or num_kv_splits.dtype != torch.int32:
@@ -132,7 +156,7 @@ def decode_attention_fwd(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_l
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(attn_logits),
         _ptr(attn_lse), _ptr(num_kv_splits), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
-        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _stream(q)), "decode_attention")
+        float(sm_scale), float(logit_cap), _attn_dtype(q, k_buffer, v_buffer), _stream(q)), "decode_attention")
 
 
 def decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits) -> int:
@@ -167,7 +191,8 @@ def decode_attention_shared_prefix(q, k_buffer, v_buffer, o, kv_indptr, kv_indic
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr),
         _ptr(prefix_lens), G, _ptr(workspace), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
-        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _stream(q)), "decode_attention_shared_prefix")
+        float(sm_scale), float(logit_cap), _attn_dtype(q, k_buffer, v_buffer), _stream(q)),
+        "decode_attention_shared_prefix")
 
 
 # ------------------------------------------------------------------------------------------- A2
@@ -197,7 +222,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
             v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
             k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
             int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0,
-            dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention_window")
+            _attn_dtype(q_extend, k_buffer, v_buffer), _stream(q_extend)), "extend_attention_window")
         return
     if custom_mask is not None:
         check(lib().sglk_extend_attention_masked(
@@ -207,8 +232,8 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
             q_extend.stride(0), q_extend.stride(1), k_extend.stride(0), k_extend.stride(1),
             v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
             k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
-            int(max_len_extend), float(sm_scale), float(logit_cap), dtype_code(q_extend.dtype), _stream(q_extend)),
-            "extend_attention_masked")
+            int(max_len_extend), float(sm_scale), float(logit_cap), _attn_dtype(q_extend, k_buffer, v_buffer),
+            _stream(q_extend)), "extend_attention_masked")
         return
     splits = extend_attention_split_plan(T, Hq, B, max_len_extend, kv_indices.numel() if kv_indptr.numel() > 1 else 0, D,
                                          q_extend.dtype) if (D == Dv and k_buffer is not None) else 1
@@ -222,7 +247,7 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
         v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
         int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0,
-        dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention")
+        _attn_dtype(q_extend, k_buffer, v_buffer), _stream(q_extend)), "extend_attention")
 
 
 def extend_attention_split_plan(T, Hq, B, max_len_extend, total_prefix, head_dim, dtype) -> int:
@@ -256,7 +281,7 @@ def extend_attention_split(q_extend, k_extend, v_extend, o_extend, k_buffer, v_b
         v_extend.stride(0), v_extend.stride(1), o_extend.stride(0), o_extend.stride(1),
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1),
         int(max_len_extend), float(sm_scale), float(logit_cap), 1 if is_causal else 0, int(kv_splits), _ptr(workspace), T,
-        dtype_code(q_extend.dtype), _stream(q_extend)), "extend_attention_split")
+        _attn_dtype(q_extend, k_buffer, v_buffer), _stream(q_extend)), "extend_attention_split")
 
 
 # ------------------------------------------------------------------------------------------- A3
@@ -271,9 +296,28 @@ def merge_state(v_a, s_a, v_b, s_b, v_merged, s_merged):
 
 
 # ------------------------------------------------------------------------------------------- P1
-def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v):
-    """k_buffer[loc] = cache_k; v_buffer[loc] = cache_v -- memory_pool.py:378-412."""
+def set_kv_buffer(k_buffer, v_buffer, loc, cache_k, cache_v, k_scale=None, v_scale=None):
+    """k_buffer[loc] = cache_k; v_buffer[loc] = cache_v -- memory_pool.py:378-412.  Into an fp8 pool (float8 views or
+    their uint8 storage with kv_format given by the float8 dtype) the rows are divided by the scales, if any, and
+    rounded as Tensor.to(float8) rounds (:389-396)."""
     _need_gpu(k_buffer, v_buffer, loc, cache_k, cache_v)
+    fmt = kv_format_code(k_buffer.dtype)
+    if fmt and cache_k.dtype != k_buffer.dtype:
+        if v_buffer.dtype != k_buffer.dtype or cache_v.dtype != cache_k.dtype:
+            raise SglkError("set_kv_buffer: K and V pools (and K and V rows) must share a dtype")
+        T = loc.shape[0]
+        ck, cv = cache_k.reshape(T, -1), cache_v.reshape(T, -1)
+        if ck.stride(1) != 1 or cv.stride(1) != 1:
+            raise SglkError("set_kv_buffer: cache_k/cache_v rows must be contiguous")
+        kb, vb = k_buffer.view(k_buffer.shape[0], -1), v_buffer.view(v_buffer.shape[0], -1)
+        check(lib().sglk_set_kv_buffer_fp8(_ptr(kb), _ptr(vb), _ptr(ck), _ptr(cv), _ptr(loc), _is64(loc), T, ck.shape[1],
+                                           cv.shape[1], kb.stride(0), vb.stride(0), ck.stride(0), cv.stride(0),
+                                           float(k_scale) if k_scale is not None else 0.0,
+                                           float(v_scale) if v_scale is not None else 0.0, dtype_code(cache_k.dtype), fmt,
+                                           _stream(k_buffer)), "set_kv_buffer_fp8")
+        return
+    if k_scale is not None or v_scale is not None:
+        raise SglkError("set_kv_buffer: scales belong to an fp8 pool")
     if cache_k.dtype != k_buffer.dtype:
         cache_k = cache_k.to(k_buffer.dtype)
         cache_v = cache_v.to(v_buffer.dtype)
@@ -811,7 +855,7 @@ def decode_attention_fwd_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, att
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(attn_logits),
         _ptr(attn_lse), _ptr(num_kv_splits), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
-        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _ptr(xsum_out),
+        float(sm_scale), float(logit_cap), _attn_dtype(q, k_buffer, v_buffer), _ptr(xsum_out),
         0 if xsum_out is None else xsum_out.stride(0), _stream(q)), "decode_attention_xs")
 
 
@@ -825,7 +869,7 @@ def decode_attention_shared_prefix_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_in
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr),
         _ptr(prefix_lens), G, _ptr(workspace), max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1),
         k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
-        float(sm_scale), float(logit_cap), dtype_code(q.dtype), _ptr(xsum_out),
+        float(sm_scale), float(logit_cap), _attn_dtype(q, k_buffer, v_buffer), _ptr(xsum_out),
         0 if xsum_out is None else xsum_out.stride(0), _stream(q)), "decode_attention_shared_prefix_xs")
 
 
@@ -860,7 +904,7 @@ def prefill_attention_paged(q, o, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_i
     check(lib().sglk_prefill_attention_paged(
         _ptr(q), _ptr(o), _ptr(kb), _ptr(vb), _ptr(qo_indptr), _ptr(kv_indptr), _ptr(kv_indices), B, Hq, Hkv, D, Dv,
         q.stride(0), q.stride(1), o.stride(0), o.stride(1), kb.stride(0), kb.stride(1), vb.stride(0), vb.stride(1),
-        int(max_q_len), float(sm_scale), float(logit_cap), 1 if causal else 0, dtype_code(q.dtype), _stream(q)),
+        int(max_q_len), float(sm_scale), float(logit_cap), 1 if causal else 0, _attn_dtype(q, kb, vb), _stream(q)),
         "prefill_attention_paged")
 
 

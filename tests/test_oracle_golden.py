@@ -283,3 +283,33 @@ def test_oracle_moe_fused_gate_matches_torch_formula():
     out, idx = oracle.moe_fused_gate(x, b, k + 1, ng, tg, 4, 2.5)
     assert torch.equal(idx[:, -1].long(), E + torch.arange(n) % 4)
     torch.testing.assert_close(out[:, -1], torch.full((n,), 0.4))
+
+
+@pytest.mark.parametrize("fmt,dt", [("e4m3fn", torch.float8_e4m3fn), ("e5m2", torch.float8_e5m2),
+                                    ("e5m2fnuz", torch.float8_e5m2fnuz)])
+def test_oracle_kv_fp8_against_torch_conversions(fmt, dt):
+    """The fp8 KV cache is `cache_k.to(float8 type)` on the way in and `.to(q.dtype)` on the way out
+    (mem_cache/memory_pool.py:389-400): torch's conversions are the reference's arithmetic.  The integer restatement in
+    oracle/ agrees with them on every byte, every bf16 and every fp16 bit pattern, and on a wide fp32 sample."""
+    import numpy as np
+
+    import oracle
+
+    codes = torch.arange(256, dtype=torch.uint8)
+    want = codes.view(dt).float().numpy()
+    got = oracle.kv_fp8_decode(codes.numpy(), fmt)
+    assert np.array_equal(np.isnan(want), np.isnan(got))
+    ok = ~np.isnan(want)
+    assert np.array_equal(want[ok].view(np.uint32), got[ok].view(np.uint32))   # signed zeros included
+    pats = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+    for src in (torch.bfloat16, torch.float16):
+        x = pats.view(src)
+        assert np.array_equal(x.to(dt).view(torch.uint8).numpy(), oracle.kv_fp8_encode(x.float().numpy(), fmt))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1 << 18, generator=g) * torch.exp(torch.randn(1 << 18, generator=g) * 6)
+    assert np.array_equal(x.to(dt).view(torch.uint8).numpy(), oracle.kv_fp8_encode(x.numpy(), fmt))
+    # a scaled write divides in the rows' own type first (product with the fp32 reciprocal, as the device does)
+    rows = (torch.randn(64, 32, generator=g) * 4).to(torch.bfloat16)
+    inv = np.float32(1.0) / np.float32(0.37)
+    want8 = torch.from_numpy(rows.float().numpy() * inv).to(torch.bfloat16).to(dt).view(torch.uint8).numpy()
+    assert np.array_equal(oracle.set_kv_buffer_fp8(rows, 0.37, fmt), want8)
