@@ -577,7 +577,8 @@ struct Wide {
 // Development builds only (tools/build_abl.sh): SGLK_ABL bit 64 compiles per-phase clock stamps into the wide kernel
 // (tools/bench_gemm.py --fused --stamps reads them), the other bits remove one component of its main loop each
 // (1 matrix instructions, 2 dequantisation, 4 LDS fragment reads, 16 rescale, 32 stage barrier, 128 activation DMA,
-// 256 weight loads, 512 half of the activation DMA) for timing experiments.  The product build has SGLK_ABL == 0.
+// 256 weight loads, 512 half of the activation DMA, 32768 plain instead of write-through output stores) for timing
+// experiments.  The product build has SGLK_ABL == 0.
 #ifndef SGLK_ABL
 #define SGLK_ABL 0
 #endif
@@ -1069,7 +1070,12 @@ stages_done:
         const float sv = Conv<T>::to_f32(Conv<T>::from_f32(gb / (1.0f + __expf(-gb))));
         const uint16_t ob = Conv<T>::from_f32(sv * ub);
         const int row = 32 * rt + e + 8 * j + 4 * h;
-        if (m0 + row < M) out[(int64_t)(m0 + row) * out_stride + ncol] = ob;
+        if constexpr ((SGLK_ABL & 32768) != 0) {
+          if (m0 + row < M) out[(int64_t)(m0 + row) * out_stride + ncol] = ob;
+        } else {  // write-through, as the partials below
+          if (m0 + row < M)
+            __hip_atomic_store(&out[(int64_t)(m0 + row) * out_stride + ncol], ob, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (xsum_out) {
           float v = Conv<T>::to_f32(ob);
 #pragma unroll
@@ -1106,7 +1112,14 @@ stages_done:
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int m = mrow + 8 * j + e;
-        if (m < M) dst[(int64_t)m * N + n] = fin[j][e];
+        // write-through (agent scope): the partials are the next kernel's input, and 6-8 MB of them left dirty in
+        // the L2s lengthen this kernel's end by the write-back (measured 0.6-0.7 us per launch); non-temporal
+        // stores shorten it as much but make the consumer's reads slower
+        if constexpr ((SGLK_ABL & 32768) != 0) {
+          if (m < M) dst[(int64_t)m * N + n] = fin[j][e];
+        } else {
+          if (m < M) __hip_atomic_store(&dst[(int64_t)m * N + n], fin[j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SGLK_STAMP(14);
