@@ -494,6 +494,26 @@ SGLK_API int sglk_dense_gemm_prefill(const void* x, const void* w, const void* b
 SGLK_API int sglk_dense_repack(const void* w, void* packed, int N, int K, int64_t w_stride, void* stream);
 SGLK_API int sglk_dense_gemm_packed(const void* x, const void* packed, const void* bias, void* out, int M, int N,
                                     int K, int64_t x_stride, int64_t out_stride, int dtype, void* stream);
+/* Split-K forms of the packed product for weights of a few thousand rows (the decoder-layer projections of a 16-bit
+ * model, layers/linear.py UnquantizedLinearMethod.apply: one block per 64 columns would leave most CUs idle).
+ * _ws: workspace of sglk_dense_gemm_workspace_bytes() bytes (contents don't matter), fp32 slabs summed in split order
+ * by a second launch; falls back to the unsplit form when the shape does not split or the workspace is too small.
+ * _partial: the slabs partial[split][M][N] (sglk_dense_gemm_partial_splits(M, N, K) of them, 0 = shape not covered) are
+ * left to the consumer kernel (sglk_fused_add_rmsnorm_ex, sglk_rope_and_store_kv_partial), which adds them up in split
+ * order and rounds once: the value the GEMM would have stored.  No counterpart in the reference. */
+SGLK_API int sglk_dense_gemm_partial_splits(int M, int N, int K);
+SGLK_API int sglk_dense_gemm_packed_partial(const void* x, const void* packed, float* partial, int M, int N, int K,
+                                            int64_t x_stride, int dtype, void* stream);
+SGLK_API int sglk_dense_gemm_packed_ws(const void* x, const void* packed, const void* bias, void* out, int M, int N,
+                                       int K, int64_t x_stride, int64_t out_stride, void* workspace,
+                                       int64_t workspace_bytes, int dtype, void* stream);
+/* gate_up product with the gated activation in the launch that sums the splits: packed = the [2d, K] weight (gate
+ * rows, then up rows), out [M, d] = round(round(act(round(gate))) * round(up)), the values the product followed by
+ * sglk_act_and_mul stores (layers/activation.py SiluAndMul / GeluAndMul over the merged projection).  act: 0 silu,
+ * 1 gelu (tanh), 2 gelu.  workspace >= sglk_dense_gemm_partial_splits(M, N, K) * M * N * 4 bytes. */
+SGLK_API int sglk_dense_gemm_packed_act(const void* x, const void* packed, void* out, int M, int N, int K,
+                                        int64_t x_stride, int64_t out_stride, int act, void* workspace,
+                                        int64_t workspace_bytes, int dtype, void* stream);
 /* The same product with a scratch buffer (sglk_dense_gemm_workspace_bytes(), contents don't matter): narrow
  * outputs (the decoder-layer projections of the bf16 configuration) are split along K over enough blocks to fill
  * the chip, fp32 partials summed in split order by a second launch.  Falls back to the form above when the

@@ -87,6 +87,10 @@ _SIGS = {
     "sglk_dense_gemm_prefill": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_dense_repack": (i32, [p, p, i32, i32, i64, p]),
     "sglk_dense_gemm_packed": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i32, p]),
+    "sglk_dense_gemm_partial_splits": (i32, [i32, i32, i32]),
+    "sglk_dense_gemm_packed_partial": (i32, [p, p, p, i32, i32, i32, i64, i32, p]),
+    "sglk_dense_gemm_packed_ws": (i32, [p, p, p, p, i32, i32, i32, i64, i64, p, i64, i32, p]),
+    "sglk_dense_gemm_packed_act": (i32, [p, p, p, i32, i32, i32, i64, i64, i32, p, i64, i32, p]),
     "sglk_dense_gemm_nt_ws": (i32, [p, p, p, p, i32, i32, i32, i64, i64, i64, p, i64, i32, p]),
     "sglk_per_token_quant_fp8": (i32, [p, p, p, i64, i32, i32, p]),
     "sglk_per_token_group_quant_fp8": (i32, [p, p, p, i64, i32, i32, f32, f32, f32, i32, i32, p]),

@@ -155,8 +155,11 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
         const int m = m0 + 16 * mt + 4 * g + r;
         if (direct) {
           if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(oacc[s][mt][r] + bv);
-        } else {
-          partial[((int64_t)blockIdx.y * Mpad + m) * N + n] = oacc[s][mt][r];
+        } else if (m < Mpad) {
+          // written through (agent scope): megabytes of partials left dirty in the L2s would be written back at the
+          // kernel's end, inside its duration (see the wide int4 GEMM)
+          __hip_atomic_store(&partial[((int64_t)blockIdx.y * Mpad + m) * N + n], oacc[s][mt][r], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
         }
       }
   }
@@ -198,6 +201,57 @@ __global__ void __launch_bounds__(256) dense_reduce_kernel(const float* __restri
   *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + n) = o;
 }
 
+// The same sum for a gate_up product, with the gated activation applied on the way out: out[m][j] =
+// round(round(act(round(gate[m][j]))) * round(up[m][j])) for gate = columns [0, d), up = columns [d, 2d) -- the values
+// the reduction above followed by act_and_mul stores (activation.cu:22-50: the activation returns T, then T * T).
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) dense_reduce_act_kernel(const float* __restrict__ partial, uint16_t* __restrict__ out,
+                                                               int M, int Mpad, int N, int splits, int64_t out_stride) {
+  const int d = N / 2, nv = d / 8;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * nv) return;
+  const int m = (int)(idx / nv), n = (int)(idx - (int64_t)m * nv) * 8;
+  float ga[8], ua[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ga[j] = ua[j] = 0.f;
+  for (int s0 = 0; s0 < splits; s0 += 2) {  // two splits' loads in flight
+    float4v a[2][2], b[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float* pr = partial + ((int64_t)min(s0 + u, splits - 1) * Mpad + m) * N + n;
+      a[u][0] = *reinterpret_cast<const float4v*>(pr);
+      a[u][1] = *reinterpret_cast<const float4v*>(pr + 4);
+      b[u][0] = *reinterpret_cast<const float4v*>(pr + d);
+      b[u][1] = *reinterpret_cast<const float4v*>(pr + d + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (s0 + u < splits) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ga[j] += a[u][0][j];
+          ga[4 + j] += a[u][1][j];
+          ua[j] += b[u][0][j];
+          ua[4 + j] += b[u][1][j];
+        }
+      }
+  }
+  short8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float gv = Conv<T>::to_f32(Conv<T>::from_f32(ga[j])), uv = Conv<T>::to_f32(Conv<T>::from_f32(ua[j]));
+    float av;
+    if constexpr (ACT == 0) {
+      av = gv / (1.0f + __expf(-gv));
+    } else {
+      const float k = 0.7978845608028654f;
+      av = ACT == 1 ? 0.5f * gv * (1.0f + tanhf(k * (gv + 0.044715f * gv * gv * gv))) : 0.5f * gv * (1.0f + erff(gv * 0.7071067811865476f));
+    }
+    o[j] = (short)Conv<T>::from_f32(Conv<T>::to_f32(Conv<T>::from_f32(av)) * uv);
+  }
+  *reinterpret_cast<short8*>(out + (int64_t)m * out_stride + n) = o;
+}
+
 // row-major [N, K] -> packed: 16-byte piece (strip, kb, c, lane = 16 g + i16) = w[16 strip + i16][128 kb + 32 c + 8 g ..]
 __global__ void __launch_bounds__(256) dense_repack_kernel(const uint16_t* __restrict__ w, uint16_t* __restrict__ packed,
                                                            int N, int K, int64_t w_stride) {
@@ -221,7 +275,7 @@ static int dense_splits(int M, int N, int K) {
   const int blocks = (N + 63) / 64 * ((M + 63) / 64);
   if (blocks >= 768) return 1;
   int splits = std::min((1024 + blocks - 1) / blocks, std::max(kblocks / 4, 1));
-  return std::max(std::min(splits, 16), 1);
+  return std::max(std::min(splits, 8), 1);  // measured on the 8B shapes: 8 x 1792 k beats 16 x 896 k on the down projection
 }
 
 }  // namespace sglk
@@ -303,6 +357,114 @@ int sglk_dense_gemm_packed(const void* x, const void* packed, const void* bias, 
                                           (uint16_t*)out, (float*)nullptr, M, mblocks * 64, N, K, K / 128, x_stride,
                                           (int64_t)0, out_stride));
   }
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+// ---- split-K forms of the packed product, for weights of a few thousand rows (the decoder layers of a 16-bit model):
+// one block per 64 columns would leave most CUs idle, so K is split and the fp32 slabs partial[split][M][N] are summed
+// either by a second launch here (_ws) or by the kernel that consumes them (_partial: sglk_fused_add_rmsnorm_ex,
+// sglk_rope_and_store_kv_partial add the splits up in split order and round once, as the int4 path's layer fusion does).
+int sglk_dense_gemm_partial_splits(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  const int splits = dense_splits(M, N, K), kblocks = K / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  return (kblocks + per - 1) / per;  // every split non-empty
+}
+
+static int dense_packed_split_launch(const void* x, const void* packed, float* partial, int M, int Mpad, int N, int K,
+                                     int64_t x_stride, int dtype, hipStream_t s) {
+  const int splits = dense_splits(M, N, K), kblocks = K / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;
+  static const int env_ns = getenv("SGLK_DENSE_NS") ? atoi(getenv("SGLK_DENSE_NS")) : 0;
+  // two strips per wave (128 columns per block) halve the activation re-reads; not where that leaves a fractional
+  // round of blocks on the 256 CUs below two full rounds (measured on the 8B shapes: o and down 256 blocks, gate_up
+  // 672: faster; qkv 384: slower than 768 blocks of 64 columns)
+  const int blocks2 = (N + 127) / 128 * used * ((M + 63) / 64);
+  const bool two = env_ns ? env_ns == 2 : (N % 128 == 0 && (blocks2 % 256 == 0 || blocks2 >= 512));
+  if (two) {
+    dim3 grid((N + 127) / 128, used, (M + 63) / 64);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 2, 2, true>), grid, dim3(256), 0, s, (const uint16_t*)x,
+                                          (const uint16_t*)packed, (const uint16_t*)nullptr, (uint16_t*)nullptr, partial,
+                                          M, Mpad, N, K, per, x_stride, (int64_t)0, (int64_t)0));
+  } else {
+    dim3 grid((N + 63) / 64, used, (M + 63) / 64);
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((dense_gemm_nt_kernel<T, 1, 4, true>), grid, dim3(256), 0, s, (const uint16_t*)x,
+                                          (const uint16_t*)packed, (const uint16_t*)nullptr, (uint16_t*)nullptr, partial,
+                                          M, Mpad, N, K, per, x_stride, (int64_t)0, (int64_t)0));
+  }
+  SGLK_LAUNCH_CHECK();
+  return used;
+}
+
+int sglk_dense_gemm_packed_partial(const void* x, const void* packed, float* partial, int M, int N, int K,
+                                   int64_t x_stride, int dtype, void* stream) {
+  SGLK_CHECK(x && packed && partial, "dense_gemm_packed_partial: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0,
+             "dense_gemm_packed_partial: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(x) && aligned16(packed) && aligned16(partial) && x_stride % 8 == 0,
+             "dense_gemm_packed_partial: rows must be 16-byte aligned");
+  const int rc = dense_packed_split_launch(x, packed, partial, M, M, N, K, x_stride, dtype, (hipStream_t)stream);
+  return rc < 0 ? rc : SGLK_OK;
+}
+
+int sglk_dense_gemm_packed_ws(const void* x, const void* packed, const void* bias, void* out, int M, int N, int K,
+                              int64_t x_stride, int64_t out_stride, void* workspace, int64_t workspace_bytes, int dtype,
+                              void* stream) {
+  SGLK_CHECK(x && packed && out, "dense_gemm_packed: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0, "dense_gemm_packed: bad shape");
+  const int splits = (N % 16 == 0 && K % 128 == 0) ? sglk_dense_gemm_partial_splits(M, N, K) : 1;
+  const int64_t need = (int64_t)splits * M * N * (int64_t)sizeof(float);
+  if (splits <= 1 || !workspace || workspace_bytes < need || !aligned16(workspace) || !aligned16(out) || N % 8 != 0 ||
+      out_stride % 8 != 0)
+    return sglk_dense_gemm_packed(x, packed, bias, out, M, N, K, x_stride, out_stride, dtype, stream);
+  SGLK_CHECK(aligned16(x) && aligned16(packed) && x_stride % 8 == 0, "dense_gemm_packed: rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int used = dense_packed_split_launch(x, packed, (float*)workspace, M, M, N, K, x_stride, dtype, s);
+  if (used < 0) return used;
+  const int64_t vecs = (int64_t)M * (N / 8);
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((dense_reduce_kernel<T>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
+                                        (const float*)workspace, (const uint16_t*)bias, (uint16_t*)out, M, M, N, used,
+                                        out_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_dense_gemm_packed_act(const void* x, const void* packed, void* out, int M, int N, int K, int64_t x_stride,
+                               int64_t out_stride, int act, void* workspace, int64_t workspace_bytes, int dtype,
+                               void* stream) {
+  SGLK_CHECK(x && packed && out && workspace, "dense_gemm_packed_act: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && N % 32 == 0 && K % 128 == 0,
+             "dense_gemm_packed_act: N=%d must be a multiple of 32, K=%d of 128", N, K);
+  SGLK_CHECK(act >= 0 && act <= 2, "dense_gemm_packed_act: act is 0 (silu), 1 (gelu tanh) or 2 (gelu)");
+  const int splits = sglk_dense_gemm_partial_splits(M, N, K);
+  SGLK_CHECK(splits >= 1 && workspace_bytes >= (int64_t)splits * M * N * (int64_t)sizeof(float),
+             "dense_gemm_packed_act: workspace too small (%lld bytes needed)", (long long)splits * M * N * 4);
+  SGLK_CHECK(aligned16(x) && aligned16(packed) && aligned16(workspace) && aligned16(out) && x_stride % 8 == 0 &&
+                 out_stride % 8 == 0,
+             "dense_gemm_packed_act: rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int used = dense_packed_split_launch(x, packed, (float*)workspace, M, M, N, K, x_stride, dtype, s);
+  if (used < 0) return used;
+  const int64_t vecs = (int64_t)M * (N / 16);
+  const dim3 grid((unsigned)((vecs + 255) / 256));
+#define SGLK_RA(A)                                                                                                  \
+  hipLaunchKernelGGL((dense_reduce_act_kernel<T, A>), grid, dim3(256), 0, s, (const float*)workspace, (uint16_t*)out, M, \
+                     M, N, used, out_stride)
+  SGLK_DISPATCH_HALF(dtype, T, {
+    if (act == 0) {
+      SGLK_RA(0);
+    } else if (act == 1) {
+      SGLK_RA(1);
+    } else {
+      SGLK_RA(2);
+    }
+  });
+#undef SGLK_RA
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

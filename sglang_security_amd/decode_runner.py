@@ -259,9 +259,40 @@ class LlamaDecoder:
         # the new token's position = tokens cached so far; private slots are pre-assigned per request
         ops.prepare_for_decode(self.req_to_token, self.req_pool_indices, self.seq_lens, self.positions, self.out_cache_loc)
 
+    def _enable_dense_fusion(self) -> bool:
+        """16-bit weights: every layer projection in the sequential-streaming layout (a second copy: the extend path
+        keeps multiplying by the row-major one), K split over the chip, and the split sums of qkv / o / down handed to
+        the kernels that consume them (rotation + pool write, fused add + norm) instead of a reduction launch each."""
+        c = self.cfg
+        ok = (c.quant == "bf16" and c.hidden % 128 == 0 and c.inter % 128 == 0 and self.q_size % 128 == 0
+              and (self.q_size + 2 * self.kv_size) % 16 == 0 and getattr(self, "tp_group", None) is None)
+        if ok:
+            shapes = {"qkv": (c.hidden, self.q_size + 2 * self.kv_size), "o": (self.q_size, c.hidden),
+                      "down": (c.inter, c.hidden)}
+            self.part_splits = {k: ops.dense_gemm_partial_splits(self.B, n, kk) for k, (kk, n) in shapes.items()}
+            ok = all(v > 0 for v in self.part_splits.values())
+        if ok:
+            need = max(self.part_splits[k] * self.B * n for k, (kk, n) in shapes.items())
+            self.partial = torch.empty(need, dtype=torch.float32, device=self.device)
+            # the gate_up slabs live in the workspace until the launch that sums them applies the activation
+            gu = max(ops.dense_gemm_partial_splits(self.B, 2 * c.inter, c.hidden), 1) * self.B * 2 * c.inter * 4
+            if self.workspace.numel() * self.workspace.element_size() < gu:
+                self.workspace = torch.zeros(gu, dtype=torch.uint8, device=self.device)
+            for L in self.layers:
+                for name in ("qkv", "o", "gate_up", "down"):
+                    w = L[name]
+                    if w.wpacked is None:
+                        w.wpacked = ops.dense_repack(w.weight)
+        self.fused_dense = bool(ok)
+        return self.fused_dense
+
     def enable_fusion(self, on: bool = True) -> bool:
         """Decoder-layer fusion (AWQ, 16-bit, head size 128, shapes the partial GEMM covers)."""
         c = self.cfg
+        self.fused_dense = False
+        if on and c.quant == "bf16":
+            self.fused = False
+            return self._enable_dense_fusion()
         ok = (on and c.quant == "awq" and c.head_dim == 128 and c.hidden % 128 == 0 and c.inter % 128 == 0
               and not c.qkv_bias)
         if ok:
@@ -307,7 +338,12 @@ class LlamaDecoder:
         xs = {"qkv": self.xs_hidden, "o": self.xs_attn, "gate_up": self.xs_hidden, "down": self.xs_act}[name]
         for L in self.layers:
             w = L[name]
-            if not self.fused:
+            if getattr(self, "fused_dense", False):
+                if name == "gate_up":
+                    ops.dense_gemm_packed_act(src, w.wpacked, self.act, 0, self.workspace)
+                else:
+                    ops.dense_gemm_packed_partial(src, w.wpacked, self.partial)
+            elif not self.fused:
                 if c.quant == "fp8" and getattr(self, "fp8_fold_quant", True):
                     self._fp8_mm(name, w, dst)
                 else:
@@ -388,6 +424,40 @@ class LlamaDecoder:
         self._lm_head()
         self._sample()
 
+    def step_fused_dense(self):
+        """The decode step over 16-bit weights in the streaming layout: 9 launches per layer (norm, qkv, rotation + pool
+        write, attention, o, norm, gate_up, its split sum + activation, down), the split sums of qkv / o / down folded
+        into their consumers.  Same arithmetic as the unfused sequence: the consumers add the splits in split order
+        and round once, where the reduction launch would have."""
+        c = self.cfg
+        self.prepare_for_decode()
+        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
+                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
+        sm_scale = 1.0 / math.sqrt(c.head_dim)
+        q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
+        o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
+        P, S = self.partial, self.part_splits
+        for li, L in enumerate(self.layers):
+            if li == 0:
+                self.residual.copy_(self.hidden)
+                ops.fused_add_rmsnorm_ex(self.hidden, None, L["ln1"], c.eps)
+            else:
+                ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln1"], c.eps, partials=P, splits=S["down"])
+            self._timed("qkv", lambda: ops.dense_gemm_packed_partial(self.hidden, L["qkv"].wpacked, P))
+            ops.rope_and_store_kv_partial(self.qkv, P, S["qkv"], self.cos_sin, self.positions, self.k_pool[li],
+                                          self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim,
+                                          bias=L["qkv_bias"])
+            self.attention(li, q_view, o_view, sm_scale)
+            self._timed("o", lambda: ops.dense_gemm_packed_partial(self.attn_out, L["o"].wpacked, P))
+            ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, partials=P, splits=S["o"])
+            self._timed("gate_up", lambda: ops.dense_gemm_packed_act(self.hidden, L["gate_up"].wpacked, self.act, 0,
+                                                                     self.workspace))
+            self._timed("down", lambda: ops.dense_gemm_packed_partial(self.act, L["down"].wpacked, P))
+        ops.fused_add_rmsnorm_ex(self.hidden, self.residual, self.final_norm, c.eps, partials=P, splits=S["down"])
+        self._lm_head()
+        self._sample()
+
     def _lm_head(self):
         if self.lm_head.wpacked is not None:
             ops.dense_gemm_packed(self.hidden, self.lm_head.wpacked, None, self.logits)
@@ -445,6 +515,8 @@ class LlamaDecoder:
     def step(self):
         if self.fused:
             return self.step_fused()
+        if getattr(self, "fused_dense", False):
+            return self.step_fused_dense()
         if self.cfg.quant == "fp8" and getattr(self, "fp8_fold_quant", True) and not self.cfg.qkv_bias:
             return self.step_fp8()
         c = self.cfg

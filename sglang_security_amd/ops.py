@@ -523,6 +523,55 @@ def dense_gemm_packed(x, packed, bias=None, out=None):
     return out
 
 
+def dense_gemm_partial_splits(M, N, K) -> int:
+    """How many fp32 slabs dense_gemm_packed_partial leaves for an [M, K] x [N, K]^T product (0: shape not covered)."""
+    return int(lib().sglk_dense_gemm_partial_splits(M, N, K))
+
+
+def dense_gemm_packed_partial(x, packed, partial):
+    """Split-K partial sums partial[split][M][N] (fp32) of x @ W^T for a dense_repack weight; the consumer kernel
+    (fused_add_rmsnorm_ex, rope_and_store_kv_partial) adds the splits up."""
+    _need_gpu(x, packed, partial)
+    M, K = x.shape
+    N = packed.shape[0]
+    if packed.shape[1] != K or not packed.is_contiguous():
+        raise SglkError("dense_gemm_packed_partial: the packed weight must be a contiguous [N, K] tensor from dense_repack")
+    splits = dense_gemm_partial_splits(M, N, K)
+    if splits <= 0 or partial.dtype != torch.float32 or partial.numel() < splits * M * N:
+        raise SglkError("dense_gemm_packed_partial: shape not covered or partial buffer too small")
+    check(lib().sglk_dense_gemm_packed_partial(_ptr(x), _ptr(packed), _ptr(partial), M, N, K, x.stride(0),
+                                               dtype_code(x.dtype), _stream(x)), "dense_gemm_packed_partial")
+    return splits
+
+
+def dense_gemm_packed_ws(x, packed, bias, out, workspace):
+    """dense_gemm_packed with K split over enough blocks to fill the chip (fp32 slabs in `workspace`, summed by a second
+    launch); the unsplit form when the shape does not split."""
+    _need_gpu(x, packed, out)
+    M, K = x.shape
+    N = packed.shape[0]
+    if packed.shape[1] != K or not packed.is_contiguous():
+        raise SglkError("dense_gemm_packed_ws: the packed weight must be a contiguous [N, K] tensor from dense_repack")
+    check(lib().sglk_dense_gemm_packed_ws(_ptr(x), _ptr(packed), _ptr(bias), _ptr(out), M, N, K, x.stride(0), out.stride(0),
+                                          _ptr(workspace), 0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                          dtype_code(x.dtype), _stream(x)), "dense_gemm_packed_ws")
+    return out
+
+
+def dense_gemm_packed_act(x, packed, out, act, workspace):
+    """out[M, d] = act(x @ Wg^T) * (x @ Wu^T) for the merged [2d, K] gate_up weight in the dense_repack layout: the
+    gated activation runs in the launch that sums the K splits (act: 0 silu, 1 gelu tanh, 2 gelu)."""
+    _need_gpu(x, packed, out, workspace)
+    M, K = x.shape
+    N = packed.shape[0]
+    if packed.shape[1] != K or not packed.is_contiguous() or out.shape != (M, N // 2):
+        raise SglkError("dense_gemm_packed_act: packed is a contiguous [2d, K] tensor from dense_repack, out is [M, d]")
+    check(lib().sglk_dense_gemm_packed_act(_ptr(x), _ptr(packed), _ptr(out), M, N, K, x.stride(0), out.stride(0), int(act),
+                                           _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                           dtype_code(x.dtype), _stream(x)), "dense_gemm_packed_act")
+    return out
+
+
 def dense_gemm_workspace_bytes(M, N, K) -> int:
     return int(lib().sglk_dense_gemm_workspace_bytes(M, N, K))
 

@@ -244,7 +244,8 @@ def test_decode_step_other_weight_formats(quant):
     dec = LlamaDecoder(cfg, batch=6, pool_slots=1 + 64 + 6 * 24, max_ctx=96, device=DEV, seed=0)
     dec.setup_shared_prefix_batch(prefix_len=64, suffix_len=5)
     dec.enable_shared_prefix(True)
-    assert not dec.enable_fusion(True)            # the layer fusion is the AWQ path's
+    if quant == "fp8":
+        assert not dec.enable_fusion(True)        # no layer fusion for the fp8 step
     for _ in range(2):
         dec.step()
     torch.cuda.synchronize()
@@ -299,3 +300,73 @@ def test_gate_up_with_activation_epilogue(dtype, M, K, inter):
     out2 = torch.empty_like(out)
     ops.awq_gemm_silu_mul(xd, ops.awq_repack(qi), si, zi, out2, xs_in, None)
     assert (out2.float() - out.float()).abs().max().item() <= 2e-2 * max(1.0, out.float().abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K,N", [(64, 4096, 6144), (64, 4096, 4096), (64, 14336, 4096), (64, 4096, 28672), (7, 512, 256),
+                                   (33, 1024, 48)])
+def test_dense_packed_split_k_forms(dtype, M, K, N):
+    """The streaming-layout product split along K: slabs summed by the second launch (_ws) and slabs left to the
+    consumer (_partial) give the bits of the row-major split-K product (same splits, same order of accumulation),
+    and agree with the oracle's 16-bit product."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(dtype).to(DEV)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dtype).to(DEV)
+    packed = ops.dense_repack(w)
+    ws = torch.empty(max(ops.dense_gemm_workspace_bytes(M, N, K), ops.dense_gemm_partial_splits(M, N, K) * M * N * 4, 16)
+                     // 4, dtype=torch.float32, device=DEV)
+    ref = torch.empty(M, N, dtype=dtype, device=DEV)
+    ops.dense_gemm_nt(x, w, None, ref, ws)
+    out = torch.full((M, N), float("nan"), dtype=dtype, device=DEV)
+    ops.dense_gemm_packed_ws(x, packed, None, out, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    want = oracle.half_matmul(x.cpu(), w.cpu().t().contiguous()).float()
+    torch.testing.assert_close(out.float().cpu(), want, atol=1e-2, rtol=1e-2)
+    splits = ops.dense_gemm_partial_splits(M, N, K)
+    assert splits >= 1
+    part = torch.full((splits * M * N + 8,), float("nan"), dtype=torch.float32, device=DEV)
+    assert ops.dense_gemm_packed_partial(x, packed, part) == splits
+    torch.cuda.synchronize()
+    assert torch.isnan(part[splits * M * N:]).all()                      # nothing past the slabs
+    acc = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    for s_ in range(splits):                                             # split order, fp32, one rounding
+        acc += part[s_ * M * N: (s_ + 1) * M * N].view(M, N)
+    assert torch.equal(acc.to(dtype), ref)
+    if N % 32 == 0:
+        # the gate_up form: the activation in the launch that sums the splits == product, then act_and_mul
+        for act in (0, 1, 2):
+            want_act = torch.empty(M, N // 2, dtype=dtype, device=DEV)
+            ops.act_and_mul(want_act, ref, act)
+            got_act = torch.full((M, N // 2), float("nan"), dtype=dtype, device=DEV)
+            ops.dense_gemm_packed_act(x, packed, got_act, act, ws)
+            torch.cuda.synchronize()
+            assert torch.equal(got_act, want_act)
+
+
+def test_dense_fused_decode_step_matches_unfused():
+    """16-bit weights: the step over the streaming layout with the split sums folded into their consumers against the
+    plain op sequence over the row-major weights.  The arithmetic is the same (same splits, summed in the same order,
+    rounded once), so logits and pool rows agree bit for bit."""
+    from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
+
+    cfg = LlamaConfig.tiny("bf16")
+    decs = []
+    for fused in (False, True):
+        dec = LlamaDecoder(cfg, batch=6, pool_slots=1 + 64 + 6 * 24, max_ctx=96, device=DEV, seed=0)
+        dec.setup_shared_prefix_batch(prefix_len=64, suffix_len=5)
+        dec.enable_shared_prefix(True)
+        assert dec.enable_fusion(fused) == fused
+        assert dec.fused_dense == fused and not dec.fused
+        decs.append(dec)
+    ref, fus = decs
+    for _ in range(3):
+        ref.step()
+        fus.step()
+        torch.cuda.synchronize()
+        assert torch.equal(ref.logits, fus.logits)
+        assert torch.equal(ref.next_ids, fus.next_ids)
+    assert torch.equal(ref.k_pool[1], fus.k_pool[1]) and torch.equal(ref.v_pool[1], fus.v_pool[1])

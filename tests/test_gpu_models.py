@@ -68,13 +68,18 @@ def _ref_logits(dec, ids):
     return _r(hidden @ lm_t), hidden
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("shape", ["tiny_qwen", "tiny"])
-def test_decode_steps_match_torch(shape):
+def test_decode_steps_match_torch(shape, fused):
+    """fused: the 16-bit step over the streaming weight layout with the split sums folded into their consumers (head
+    size 64 with a qkv bias included), where the shape allows it."""
     from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
 
     cfg = getattr(LlamaConfig, shape)("bf16")
     B, T = 3, 9
     dec = LlamaDecoder(cfg, batch=B, pool_slots=1 + B * 32, max_ctx=32, device=DEV, seed=1)
+    if fused and not dec.enable_fusion(True):
+        pytest.skip("shape outside the fused 16-bit step")
     dec.setup_shared_prefix_batch(prefix_len=0, suffix_len=0, share=False)   # nothing cached yet
     ids = torch.randint(0, cfg.vocab, (B, T), generator=torch.Generator().manual_seed(7)).to(DEV)
     for t in range(T):
