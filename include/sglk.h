@@ -563,6 +563,40 @@ SGLK_API int sglk_fp8_scaled_mm_ws(const void* a, const void* b_nk, const float*
                                    int K, int64_t a_stride, int64_t b_stride, int64_t out_stride,
                                    void* workspace, int64_t workspace_bytes, int out_dtype,
                                    void* stream);
+/* The same product on a weight re-laid-out once at load time for sequential streaming (the decode step reads every
+ * weight whole, once per step): packed = [N / 16][K / 128][2][64 lanes][16 bytes], same byte count as b_nk, made by
+ * sglk_fp8_repack (N % 16 == 0, K % 128 == 0).  A wave streams its strip of 16 weight rows straight into the
+ * matrix-core operands, the quantised activations go through LDS; narrow outputs are split along K through the
+ * workspace (sglk_fp8_mm_packed_workspace_bytes(), contents don't matter; without it the product runs unsplit).
+ * Same arithmetic contract as sglk_fp8_scaled_mm (fp32 accumulation, scales_a[m] * scales_b[n], + bias).  No
+ * counterpart in the reference, which hands the row-major weight to cutlass / torch._scaled_mm
+ * (layers/quantization/fp8_utils.py:454-693). */
+SGLK_API int sglk_fp8_repack(const void* w_nk, void* packed, int N, int K, int64_t w_stride, void* stream);
+SGLK_API int64_t sglk_fp8_mm_packed_workspace_bytes(int M, int N, int K);
+SGLK_API int sglk_fp8_scaled_mm_packed(const void* a, const void* packed, const float* scales_a,
+                                       const float* scales_b, const void* bias, void* out, int M, int N,
+                                       int K, int64_t a_stride, int64_t out_stride, void* workspace,
+                                       int64_t workspace_bytes, int out_dtype, void* stream);
+/* The streaming product's raw split sums partial[split][M][N] (sglk_fp8_mm_packed_partial_splits(M, N, K) slabs, 0 =
+ * shape not covered; one slab when the shape does not split) left to the kernel that consumes the product:
+ * sglk_rmsnorm_quant_fp8_partial and sglk_rope_and_store_kv_partial_scaled form
+ * round(sum * scales_a[m] * scales_b[n] + bias[n]) exactly as the reduction launch of sglk_fp8_scaled_mm_packed does
+ * and carry on (fused add + norm + per-token quantisation; rotation + pool write).  row_scale may alias the `scales`
+ * output of sglk_rmsnorm_quant_fp8_partial.  No counterpart in the reference, which runs these steps as separate ops. */
+SGLK_API int sglk_fp8_mm_packed_partial_splits(int M, int N, int K);
+SGLK_API int sglk_fp8_mm_packed_partial(const void* a, const void* packed, float* partial, int M, int N, int K,
+                                        int64_t a_stride, void* stream);
+SGLK_API int sglk_rmsnorm_quant_fp8_partial(const float* partials, int splits, int64_t part_stride,
+                                            const float* row_scale, const float* col_scale, const void* bias,
+                                            void* residual, const void* weight, void* q, float* scales,
+                                            int64_t rows, int hidden, float eps, int gemma, int dtype, void* stream);
+SGLK_API int sglk_rope_and_store_kv_partial_scaled(void* qkv, const float* partials, int splits, int64_t part_stride,
+                                                   const void* bias, const float* row_scale, const float* col_scale,
+                                                   const float* cos_sin_cache, const int64_t* positions,
+                                                   void* k_buffer, void* v_buffer, const void* loc, int loc_is64,
+                                                   int64_t tokens, int q_heads, int kv_heads, int head_size,
+                                                   int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                                                   int interleave, int dtype, void* stream);
 /* DeepSeek block-scaled form: scales_a [M, K/128] (stride given, row- or M-major), scales_b
  * [N/128, K/128] or its transpose.  Replaces fp8_blockwise_scaled_mm,
  * sgl-kernel/csrc/gemm/fp8_blockwise_gemm_kernel.cu:345-423. */

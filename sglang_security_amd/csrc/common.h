@@ -188,6 +188,40 @@ struct KvElem<Fp8<F>> {
       return ::sglk::fail(SGLK_EINVAL, "unknown KV pool format %d", kvf);   \
   }
 
+// ---- split-K partial sums handed to a consumer kernel -------------------------------------------
+// acc[0..7] = sum over splits (in split order) of the 8 floats at partials[s][off .. off+7]; up to eight splits'
+// loads are in flight together
+__device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int splits, int64_t part_stride,
+                                             int64_t off, float (&acc)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int s0 = 0; s0 < splits; s0 += 8) {
+    float4v a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float* pr = partials + (int64_t)min(s0 + u, splits - 1) * part_stride + off;
+      a[u] = *reinterpret_cast<const float4v*>(pr);
+      b[u] = *reinterpret_cast<const float4v*>(pr + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (s0 + u < splits) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[j] += a[u][j];
+          acc[4 + j] += b[u][j];
+        }
+      }
+    }
+  }
+}
+
+// value an fp8 product's split sum stores: raw sum * scale of the activation row * scale of the weight column + bias,
+// in this order of operations wherever it is formed (the reduction launch and the consumer kernels give the same bits)
+__device__ __forceinline__ float scaled_sum(float acc, float row_scale, float col_scale, float bias) {
+  return __fmaf_rn(__fmul_rn(acc, row_scale), col_scale, bias);
+}
+
 // ---- wave (64 lanes) reductions ----------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -138,33 +138,6 @@ static int launch_rmsnorm(void* out, const void* x, void* residual, const void* 
 //     may be written to xsum[block][row] for the following fused AWQ GEMM.
 // 16-bit types, hidden % 128 == 0, hidden <= 8192.
 // ---------------------------------------------------------------------------------------------
-// acc[0..7] = sum over splits (in split order) of the 8 floats at partials[s][off .. off+7]; up to eight splits'
-// loads are in flight together
-__device__ __forceinline__ void sum_partials(const float* __restrict__ partials, int splits, int64_t part_stride,
-                                             int64_t off, float (&acc)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int s0 = 0; s0 < splits; s0 += 8) {
-    float4v a[8], b[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const float* pr = partials + (int64_t)min(s0 + u, splits - 1) * part_stride + off;
-      a[u] = *reinterpret_cast<const float4v*>(pr);
-      b[u] = *reinterpret_cast<const float4v*>(pr + 4);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (s0 + u < splits) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[j] += a[u][j];
-          acc[4 + j] += b[u][j];
-        }
-      }
-    }
-  }
-}
-
 template <typename T>
 __global__ void __launch_bounds__(1024) rmsnorm_fused_kernel(void* __restrict__ xio, void* __restrict__ residual,
                                                             const void* __restrict__ w, int hidden, float eps, int gemma,
@@ -266,7 +239,8 @@ __global__ void __launch_bounds__(1024) rope_store_partial_kernel(
     void* __restrict__ qkv, const float* __restrict__ partials, int splits, int64_t part_stride,
     const void* __restrict__ bias, const float* __restrict__ cos_sin, const int64_t* __restrict__ positions,
     void* __restrict__ k_buffer, void* __restrict__ v_buffer, const void* loc, int loc_is64, int q_heads, int kv_heads,
-    int head_size, int rot, int64_t kbuf_stride_n, int64_t vbuf_stride_n, int interleave, int heads_per_block) {
+    int head_size, int rot, int64_t kbuf_stride_n, int64_t vbuf_stride_n, int interleave, int heads_per_block,
+    const float* __restrict__ row_scale, const float* __restrict__ col_scale) {
   // block (t, part) owns heads [h0, h1) of token t's row (q heads, then k heads, then v heads): heads are independent,
   // so a row is spread over several blocks when there are fewer tokens than CUs
   extern __shared__ __attribute__((aligned(16))) uint16_t rowS[];  // heads_per_block * head_size
@@ -280,13 +254,18 @@ __global__ void __launch_bounds__(1024) rope_store_partial_kernel(
   const int64_t pos = positions[t];
   const int64_t slot = ld_idx(loc, loc_is64, t);
   const uint16_t* br = reinterpret_cast<const uint16_t*>(bias);
+  // raw sums of an fp8 product: scaled by the row's and the column's dequantisation scales, as that product's own
+  // split sum does (scaled_sum)
+  const float rs = row_scale ? row_scale[t] : 1.f;
   for (int v = threadIdx.x; v < (ncol >> 3); v += blockDim.x) {
     float acc[8];
     sum_partials(partials, splits, part_stride, t * row_len + c0 + 8 * v, acc);
     short8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      o[j] = (short)Conv<T>::from_f32(acc[j] + (br ? Conv<T>::to_f32(br[c0 + 8 * v + j]) : 0.f));
+    for (int j = 0; j < 8; ++j) {
+      const float bj = br ? Conv<T>::to_f32(br[c0 + 8 * v + j]) : 0.f;
+      o[j] = (short)Conv<T>::from_f32(col_scale ? scaled_sum(acc[j], rs, col_scale[c0 + 8 * v + j], bj) : acc[j] + bj);
+    }
     reinterpret_cast<short8*>(rowS)[v] = o;
   }
   __syncthreads();
@@ -882,12 +861,14 @@ int sglk_act_and_mul_xs(void* out, const void* x, int64_t rows, int d, int act, 
   return SGLK_OK;
 }
 
-int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits, int64_t part_stride, const void* bias,
-                                   const float* cos_sin_cache, const int64_t* positions, void* k_buffer, void* v_buffer,
-                                   const void* loc, int loc_is64, int64_t tokens, int q_heads, int kv_heads,
-                                   int head_size, int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
-                                   int interleave, int dtype, void* stream) {
+int sglk_rope_and_store_kv_partial_scaled(void* qkv, const float* partials, int splits, int64_t part_stride,
+                                          const void* bias, const float* row_scale, const float* col_scale,
+                                          const float* cos_sin_cache, const int64_t* positions, void* k_buffer,
+                                          void* v_buffer, const void* loc, int loc_is64, int64_t tokens, int q_heads,
+                                          int kv_heads, int head_size, int rot_dim, int64_t kbuf_stride_n,
+                                          int64_t vbuf_stride_n, int interleave, int dtype, void* stream) {
   SGLK_CHECK(qkv && partials, "rope_and_store_kv_partial: null pointer");
+  SGLK_CHECK((row_scale == nullptr) == (col_scale == nullptr), "rope_and_store_kv_partial: both scale vectors or neither");
   const int64_t row_len = (int64_t)(q_heads + 2 * kv_heads) * head_size;
   SGLK_CHECK(splits >= 1 && row_len % 8 == 0 && part_stride >= tokens * row_len && part_stride % 4 == 0 &&
                  aligned16(partials) && aligned16(qkv),
@@ -908,9 +889,20 @@ int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits,
                                         dim3((unsigned)std::min<int64_t>(1024, std::max<int64_t>(64, (cols / 8 + 63) / 64 * 64))),
                                         (size_t)cols * 2, (hipStream_t)stream, qkv, partials, splits, part_stride, bias,
                                         cos_sin_cache, positions, k_buffer, v_buffer, loc, loc_is64, q_heads, kv_heads,
-                                        head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave, hpb));
+                                        head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave, hpb, row_scale,
+                                        col_scale));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_rope_and_store_kv_partial(void* qkv, const float* partials, int splits, int64_t part_stride, const void* bias,
+                                   const float* cos_sin_cache, const int64_t* positions, void* k_buffer, void* v_buffer,
+                                   const void* loc, int loc_is64, int64_t tokens, int q_heads, int kv_heads,
+                                   int head_size, int rot_dim, int64_t kbuf_stride_n, int64_t vbuf_stride_n,
+                                   int interleave, int dtype, void* stream) {
+  return sglk_rope_and_store_kv_partial_scaled(qkv, partials, splits, part_stride, bias, nullptr, nullptr, cos_sin_cache,
+                                               positions, k_buffer, v_buffer, loc, loc_is64, tokens, q_heads, kv_heads,
+                                               head_size, rot_dim, kbuf_stride_n, vbuf_stride_n, interleave, dtype, stream);
 }
 
 int sglk_argmax(const void* x, int64_t* out, int64_t rows, int cols, int64_t row_stride, int dtype, void* stream) {

@@ -126,9 +126,19 @@ __device__ __forceinline__ float block_max_1024(float v, float* red) {
 template <typename T>
 __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restrict__ xin, void* __restrict__ residual,
                                                              const void* __restrict__ w, uint8_t* __restrict__ q,
-                                                             float* __restrict__ scales, int hidden, float eps, int gemma) {
+                                                             float* __restrict__ scales, int hidden, float eps, int gemma,
+                                                             const float* __restrict__ partials, int splits,
+                                                             int64_t part_stride, const float* __restrict__ row_scale,
+                                                             const float* __restrict__ col_scale,
+                                                             const void* __restrict__ bias) {
+  // partials: the input row arrives as the raw split sums of the preceding fp8 product, partials[s][row][:], and is
+  // formed here as that product's own split sum forms it: round_T(sum * row_scale[row] * col_scale[n] + bias[n]).
+  // row_scale may be the very array `scales` (the product's activation scales, replaced by this kernel's own): it is
+  // read before the block's first barrier and written after its last.
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
+  const float rsc = (partials && row_scale) ? row_scale[row] : 1.f;
+  const uint16_t* bsrc = reinterpret_cast<const uint16_t*>(bias);
   const uint16_t* x = reinterpret_cast<const uint16_t*>(xin) + row * hidden;
   uint16_t* res = residual ? reinterpret_cast<uint16_t*>(residual) + row * hidden : nullptr;
   const uint16_t* wr = reinterpret_cast<const uint16_t*>(w);
@@ -140,9 +150,20 @@ __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restr
   for (int it = 0; it < MAXV; ++it) {
     const int v = threadIdx.x + it * 1024;
     if (v < nvec) {
-      const short8 xv = reinterpret_cast<const short8*>(x)[v];
+      if (partials) {
+        float acc[8];
+        sum_partials(partials, splits, part_stride, row * hidden + 8 * v, acc);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) keep[it][j] = Conv<T>::to_f32((uint16_t)xv[j]);
+        for (int j = 0; j < 8; ++j) {
+          const float bj = bsrc ? Conv<T>::to_f32(bsrc[8 * v + j]) : 0.f;
+          const float val = col_scale ? scaled_sum(acc[j], rsc, col_scale[8 * v + j], bj) : acc[j] + bj;
+          keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32(val));  // the value the product would have stored
+        }
+      } else {
+        const short8 xv = reinterpret_cast<const short8*>(x)[v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) keep[it][j] = Conv<T>::to_f32((uint16_t)xv[j]);
+      }
       if (res) {
         const short8 rv = reinterpret_cast<const short8*>(res)[v];
         short8 ro;
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(256) void fp8_splitk_reduce_kernel(const float* __r
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float bn = bias ? ld<TO>(bias, n + j) : 0.f;
-    st<TO>(out, (int64_t)m * out_stride + n + j, acc[j] * am * (sb ? sb[n + j] : 1.f) + bn);
+    st<TO>(out, (int64_t)m * out_stride + n + j, scaled_sum(acc[j], am, sb ? sb[n + j] : 1.f, bn));
   }
 }
 
@@ -522,6 +543,158 @@ int launch_mm(const MmArgs& p, hipStream_t s, int batch = 1) {
   }
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+
+// ---- streaming form of the per-token / per-channel scaled product at decode batch sizes --------------------------
+// out[M, N] = (x[M, K] . W[N, K]^T) * sa[m] * sb[n] (+ bias) with the weight re-laid-out once at load time
+// (sglk_fp8_repack) so that every wave instruction reads 1 KiB of consecutive memory:
+//   packed = [N / 16 strips][K / 128 k-blocks][2 halves][64 lanes][16 bytes],
+//   piece (strip, kb, h, lane = 16 g + i16) = W[16 strip + i16][128 kb + 32 g + 16 h .. + 16]
+// (inside a 128-byte k-block lane group g owns bytes [32 g, 32 g + 32) of its row for both operands, as in the
+// kernel above).  A wave streams its strip straight into the matrix-core operand registers, PF k-blocks ahead; the
+// quantised activations, which every wave re-reads, go through an LDS tile (64 rows x 128 bytes per k-block, 16-byte
+// chunks XOR-swizzled by (row >> 1) & 7: the 64 lanes of an operand read fall on every bank group four times, the
+// minimum).  Narrow outputs split K over blockIdx.y and leave raw fp32 sums in partial[split][M][N], written through.
+__device__ __forceinline__ int fs_off(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+__device__ __forceinline__ long lo64(int4v v) { return (long)(uint32_t)v.x | ((long)v.y << 32); }
+__device__ __forceinline__ long hi64(int4v v) { return (long)(uint32_t)v.z | ((long)v.w << 32); }
+
+template <typename TO, int NS, int PF>
+__global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ wp,
+                                                            const float* __restrict__ sa, const float* __restrict__ sb,
+                                                            const void* __restrict__ bias, void* __restrict__ out,
+                                                            float* __restrict__ partial, int M, int N, int K,
+                                                            int kb_per_split, int64_t x_stride, int64_t out_stride) {
+  __shared__ __attribute__((aligned(16))) char xs[2 * 64 * 128];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int kblocks = K / 128;
+  const int m0 = blockIdx.z * 64;
+  const int kb0 = blockIdx.y * kb_per_split;
+  const int nkb = min(kb_per_split, kblocks - kb0);
+  const int n0 = (blockIdx.x * 4 + wid) * 16 * NS + i16;
+
+  // activations: thread (row xr, quarter xq) moves bytes [32 xq, 32 xq + 32) of its row, two k-blocks ahead
+  const int xr = threadIdx.x >> 2, xq = threadIdx.x & 3;
+  const bool xrow_ok = (m0 + xr) < M;
+  const uint8_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
+  int4v xreg[2][2];
+  auto x_fetch = [&](int4v(&r2)[2], int kb) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      r2[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * (int64_t)kb + 16 * c) : int4v{0, 0, 0, 0};
+  };
+  auto x_park = [&](const int4v(&r2)[2], int buf) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) *reinterpret_cast<int4v*>(xs + buf * 8192 + fs_off(xr, 2 * xq + c)) = r2[c];
+  };
+
+  const uint8_t* wsrc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int strip = min((n0 + 16 * s) >> 4, (N >> 4) - 1);
+    wsrc[s] = wp + ((int64_t)strip * kblocks + kb0) * 2048 + 16 * lane;
+  }
+  auto wload = [](const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const int4v*>(p)); };
+  int4v wq[PF][NS][2];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < nkb) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) wq[p][s][h] = wload(wsrc[s] + 2048 * p + 1024 * h);
+    }
+
+  f32x4 oacc[NS][4];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) oacc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  static_assert(PF % 2 == 0, "the activation registers alternate with the parity of the k-block");
+  x_fetch(xreg[0], kb0);
+  if (nkb > 1) x_fetch(xreg[1], kb0 + 1);
+  x_park(xreg[0], 0);
+  __syncthreads();
+
+  for (int base = 0; base < nkb; base += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int j = base + p;
+      if (j < nkb) {
+        const int buf = j & 1;
+        if (j + 2 < nkb) x_fetch(xreg[p & 1], kb0 + j + 2);  // block j's own registers were parked a step ago
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int4v af = *reinterpret_cast<const int4v*>(xs + buf * 8192 + fs_off(16 * mt + i16, 2 * g + h));
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              oacc[s][mt] = mma_f8<0>(lo64(af), lo64(wq[p][s][h]), oacc[s][mt]);
+              oacc[s][mt] = mma_f8<0>(hi64(af), hi64(wq[p][s][h]), oacc[s][mt]);
+            }
+          }
+        if (j + PF < nkb) {
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) wq[p][s][h] = wload(wsrc[s] + 2048 * (int64_t)(j + PF) + 1024 * h);
+        }
+        if (j + 1 < nkb) x_park(xreg[(p + 1) & 1], buf ^ 1);
+        __syncthreads();
+      }
+    }
+  }
+
+  // lane (i16, g) holds rows m0 + 16 mt + 4 g + r of column n0 + 16 s
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int n = n0 + 16 * s;
+    if (n >= N) continue;
+    const float sbn = partial ? 1.f : sb[n];
+    const float bn = (!partial && bias) ? ld<TO>(bias, n) : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 16 * mt + 4 * g + r;
+        if (m >= M) continue;
+        if (partial)
+          __hip_atomic_store(&partial[((int64_t)blockIdx.y * M + m) * N + n], oacc[s][mt][r], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        else
+          st<TO>(out, (int64_t)m * out_stride + n, oacc[s][mt][r] * sa[m] * sbn + bn);
+      }
+  }
+}
+
+// row-major e4m3 [N, K] -> the streaming layout above
+__global__ void __launch_bounds__(256) fp8_repack_kernel(const uint8_t* __restrict__ w, uint8_t* __restrict__ packed, int N,
+                                                         int K, int64_t w_stride) {
+  const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int kblocks = K / 128;
+  if (piece >= (int64_t)(N / 16) * kblocks * 128) return;
+  const int lane = (int)(piece & 63), h = (int)((piece >> 6) & 1);
+  const int64_t sk = piece >> 7;
+  const int kb = (int)(sk % kblocks), strip = (int)(sk / kblocks);
+  const int i16 = lane & 15, g = lane >> 4;
+  *reinterpret_cast<int4v*>(packed + piece * 16) =
+      *reinterpret_cast<const int4v*>(w + (int64_t)(16 * strip + i16) * w_stride + 128 * kb + 32 * g + 16 * h);
+}
+
+// K splits of the streaming form (measured on the 8B shapes, one strip per wave): outputs of 256 blocks or more run
+// unsplit (no reduction launch); narrower ones split until about 512 blocks, at most 8 ways, at least 1024 of k each
+static int fp8_stream_splits(int M, int N, int K) {
+  const char* env = getenv("SGLK_FP8_STREAM_SPLITS");
+  const int kblocks = K / 128;
+  if (env && atoi(env) > 0) return std::min(atoi(env), kblocks);
+  if (N % 4 != 0) return 1;
+  const int blocks = (N + 63) / 64 * ((M + 63) / 64);
+  if (blocks >= 256) return 1;
+  return std::max(1, std::min({(512 + blocks - 1) / blocks, std::max(K / 1024, 1), 8}));
 }
 
 }  // namespace
@@ -586,7 +759,30 @@ int sglk_rmsnorm_quant_fp8(const void* x, void* residual, const void* weight, vo
   if (rows == 0) return SGLK_OK;
   SGLK_DISPATCH_HALF(dtype, T,
                      hipLaunchKernelGGL((rmsnorm_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
-                                        x, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma));
+                                        x, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma,
+                                        (const float*)nullptr, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
+                                        (const void*)nullptr));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_rmsnorm_quant_fp8_partial(const float* partials, int splits, int64_t part_stride, const float* row_scale,
+                                   const float* col_scale, const void* bias, void* residual, const void* weight, void* q,
+                                   float* scales, int64_t rows, int hidden, float eps, int gemma, int dtype,
+                                   void* stream) {
+  SGLK_CHECK(partials && weight && q && scales, "rmsnorm_quant_fp8_partial: null pointer");
+  SGLK_CHECK((row_scale == nullptr) == (col_scale == nullptr), "rmsnorm_quant_fp8_partial: both scale vectors or neither");
+  SGLK_CHECK(rows >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 4 * 1024 * 8,
+             "rmsnorm_quant_fp8_partial: hidden=%d must be a multiple of 8, at most 32768", hidden);
+  SGLK_CHECK(splits >= 1 && part_stride >= rows * hidden && part_stride % 4 == 0 && aligned16(partials),
+             "rmsnorm_quant_fp8_partial: bad partial layout");
+  SGLK_CHECK(aligned16(weight) && (!residual || aligned16(residual)) && ((uintptr_t)q & 7) == 0,
+             "rmsnorm_quant_fp8_partial: tensors must be 16-byte aligned");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((rmsnorm_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                        (const void*)nullptr, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma,
+                                        partials, splits, part_stride, row_scale, col_scale, bias));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
@@ -641,6 +837,88 @@ int64_t sglk_fp8_mm_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   const int splits = fp8_splits(M, N, K);
   return splits > 1 ? (int64_t)splits * M * N * (int64_t)sizeof(float) : 0;
+}
+
+int sglk_fp8_repack(const void* w_nk, void* packed, int N, int K, int64_t w_stride, void* stream) {
+  SGLK_CHECK(w_nk && packed, "fp8_repack: null pointer");
+  SGLK_CHECK(N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0, "fp8_repack: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(w_nk) && aligned16(packed) && w_stride % 16 == 0 && w_stride >= K,
+             "fp8_repack: rows must be 16-byte aligned");
+  const int64_t pieces = (int64_t)(N / 16) * (K / 128) * 128;
+  hipLaunchKernelGGL(fp8_repack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)w_nk, (uint8_t*)packed, N, K, w_stride);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int64_t sglk_fp8_mm_packed_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  const int splits = fp8_stream_splits(M, N, K);
+  return splits > 1 ? (int64_t)splits * M * N * (int64_t)sizeof(float) : 0;
+}
+
+int sglk_fp8_scaled_mm_packed(const void* a, const void* packed, const float* scales_a, const float* scales_b,
+                              const void* bias, void* out, int M, int N, int K, int64_t a_stride, int64_t out_stride,
+                              void* workspace, int64_t workspace_bytes, int out_dtype, void* stream) {
+  SGLK_CHECK(a && packed && scales_a && scales_b && out, "fp8_scaled_mm_packed: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0,
+             "fp8_scaled_mm_packed: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(a) && aligned16(packed) && a_stride % 16 == 0 && a_stride >= K && out_stride >= N,
+             "fp8_scaled_mm_packed: rows must be 16-byte aligned");
+  int splits = fp8_stream_splits(M, N, K);
+  const int kblocks = K / 128;
+  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * (int64_t)sizeof(float) ||
+                     !aligned16(workspace)))
+    splits = 1;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;
+  const int mblocks = (M + 63) / 64;
+  float* partial = used > 1 ? (float*)workspace : nullptr;
+  static const int env_ns = getenv("SGLK_FP8_STREAM_NS") ? atoi(getenv("SGLK_FP8_STREAM_NS")) : 0;
+  const bool two = env_ns == 2;  // two strips per wave measured slower than one on every decode shape of the 8B model
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_HALF(out_dtype, TO, {
+    if (two)
+      hipLaunchKernelGGL((fp8_stream_kernel<TO, 2, 4>), dim3((N + 127) / 128, used, mblocks), dim3(256), 0, s,
+                         (const uint8_t*)a, (const uint8_t*)packed, scales_a, scales_b, bias, out, partial, M, N, K, per,
+                         a_stride, out_stride);
+    else
+      hipLaunchKernelGGL((fp8_stream_kernel<TO, 1, 4>), dim3((N + 63) / 64, used, mblocks), dim3(256), 0, s,
+                         (const uint8_t*)a, (const uint8_t*)packed, scales_a, scales_b, bias, out, partial, M, N, K, per,
+                         a_stride, out_stride);
+    if (used > 1) {
+      const int64_t vecs = (int64_t)M * (N / 4);
+      hipLaunchKernelGGL((fp8_splitk_reduce_kernel<TO>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
+                         (const float*)workspace, used, scales_a, scales_b, bias, out, M, N, out_stride);
+    }
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_fp8_mm_packed_partial_splits(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 128 != 0 || N % 16 != 0) return 0;
+  const int splits = fp8_stream_splits(M, N, K), kblocks = K / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  return (kblocks + per - 1) / per;
+}
+
+int sglk_fp8_mm_packed_partial(const void* a, const void* packed, float* partial, int M, int N, int K, int64_t a_stride,
+                               void* stream) {
+  SGLK_CHECK(a && packed && partial, "fp8_mm_packed_partial: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0,
+             "fp8_mm_packed_partial: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(a) && aligned16(packed) && aligned16(partial) && a_stride % 16 == 0 && a_stride >= K,
+             "fp8_mm_packed_partial: rows must be 16-byte aligned");
+  const int splits = fp8_stream_splits(M, N, K), kblocks = K / 128;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;
+  hipLaunchKernelGGL((fp8_stream_kernel<bf16_t, 1, 4>), dim3((N + 63) / 64, used, (M + 63) / 64), dim3(256), 0,
+                     (hipStream_t)stream, (const uint8_t*)a, (const uint8_t*)packed, (const float*)nullptr,
+                     (const float*)nullptr, (const void*)nullptr, (void*)nullptr, partial, M, N, K, per, a_stride,
+                     (int64_t)0);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
 }
 
 int sglk_fp8_scaled_mm_ws(const void* a, const void* b_nk, const float* scales_a, const float* scales_b, const void* bias,

@@ -92,6 +92,16 @@ class _Fp8Linear:
         amax = w.abs().amax(dim=1, keepdim=True).clamp(min=1e-12)
         self.scale = (amax / 448.0).float().reshape(N).contiguous()
         self.weight = (w / (amax / 448.0)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+        self.wpacked = None  # the weight in the sequential-streaming layout, once pack() has run
+
+    def pack(self):
+        """A second copy in the streaming layout of fp8_scaled_mm_packed (the decode step reads it; the row-major one
+        stays for callers of the reference's fp8_scaled_mm).  Short inner dimensions stay on the row-major kernel, whose
+        waves split K inside the block (measured on the 70B TP = 8 shard: K = 1024 and 3584 faster there, K >= 4096
+        faster here)."""
+        if self.wpacked is None and self.N % 16 == 0 and self.K % 128 == 0 and self.K >= 4096:
+            self.wpacked = ops.fp8_repack(self.weight)
+        return self
 
     def bytes(self):
         return self.weight.numel() + self.scale.numel() * 4
@@ -182,6 +192,8 @@ class LlamaDecoder:
             for K, N in ((c.hidden, self.q_size + 2 * self.kv_size), (self.q_size, c.hidden), (c.hidden, 2 * c.inter),
                          (c.inter, c.hidden)):
                 ws = max(ws, need(B, N, K))
+                if c.quant == "fp8":
+                    ws = max(ws, ops.fp8_mm_packed_workspace_bytes(B, N, K))
         self.workspace = torch.zeros(max(ws, 256), dtype=torch.uint8, device=device)  # ticket words start at zero
         if c.quant == "fp8":
             kmax = max(c.hidden, self.q_size, c.inter)
@@ -290,6 +302,22 @@ class LlamaDecoder:
         """Decoder-layer fusion (AWQ, 16-bit, head size 128, shapes the partial GEMM covers)."""
         c = self.cfg
         self.fused_dense = False
+        if c.quant == "fp8":
+            # no fusion forms for the fp8 step; `on` selects the streaming weight layout for its products
+            need = 0
+            for L in self.layers:
+                for name in ("qkv", "o", "gate_up", "down"):
+                    w = L[name]
+                    if on:
+                        w.pack()
+                        if w.wpacked is not None and name != "gate_up":
+                            need = max(need, ops.fp8_mm_packed_partial_splits(self.B, w.N, w.K) * self.B * w.N)
+                    else:
+                        w.wpacked = None
+            # raw split sums of qkv / o / down on their way to the consumer kernels
+            self.fp8_partial = torch.empty(need, dtype=torch.float32, device=self.device) if (on and need) else None
+            self.fused = False
+            return False
         if on and c.quant == "bf16":
             self.fused = False
             return self._enable_dense_fusion()
@@ -469,15 +497,22 @@ class LlamaDecoder:
 
     def _fp8_mm(self, name, w, out):
         """The product on activations a producer has already quantised into x_q / x_s."""
-        run = lambda: ops.fp8_scaled_mm(self._xq(w.K), w.weight.t(), self.x_s, w.scale, self.dtype, None, out, self.workspace)
+        if w.wpacked is not None:
+            run = lambda: ops.fp8_scaled_mm_packed(self._xq(w.K), w.wpacked, self.x_s, w.scale, self.dtype, None, out,
+                                                   self.workspace)
+        else:
+            run = lambda: ops.fp8_scaled_mm(self._xq(w.K), w.weight.t(), self.x_s, w.scale, self.dtype, None, out,
+                                            self.workspace)
         if self.gemm_timer is not None:
             self.gemm_timer(name, run)
         else:
             run()
 
     def step_fp8(self):
-        """w8a8 layer with the activation quantisation folded into its producers (norm, gated activation): 11 launches
-        per layer instead of 14; the attention output, whose row maximum spans blocks, is quantised on its own."""
+        """w8a8 layer with the activation quantisation folded into its producers (norm, gated activation), and, where a
+        projection runs on the streaming weight layout, its raw split sums handed to the kernel that consumes them
+        (rotation + pool write after qkv, fused add + norm + quantisation after o and down) instead of a reduction
+        launch: 11 launches per layer at most, 8 with every hand-over."""
         c = self.cfg
         self.prepare_for_decode()
         ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
@@ -488,24 +523,49 @@ class LlamaDecoder:
         o_view = self.attn_out.view(self.B, c.q_heads, c.head_dim)
         tp = getattr(self, "tp_group", None)
         row_out = self.hidden if tp is None else self.tp_buf
+        P = getattr(self, "fp8_partial", None)
+
+        def product(name, w, out, hand_over):
+            """Returns the number of split sums left in P for the consumer, 0 when `out` holds the finished rows."""
+            if hand_over and P is not None and w.wpacked is not None:
+                self._timed(name, lambda: ops.fp8_mm_packed_partial(self._xq(w.K), w.wpacked, P))
+                return ops.fp8_mm_packed_partial_splits(self.B, w.N, w.K)
+            self._fp8_mm(name, w, out)
+            return 0
+
+        pending, pending_w = 0, None   # the previous layer's down projection, when it left split sums
+        last = len(self.layers) - 1
         for li, L in enumerate(self.layers):
             if li == 0:
                 self.residual.copy_(self.hidden)
                 ops.rmsnorm_quant_fp8(self.hidden, None, L["ln1"], self._xq(c.hidden), self.x_s, c.eps)
+            elif pending:
+                ops.rmsnorm_quant_fp8_partial(P, pending, self.x_s, pending_w.scale, self.residual, L["ln1"],
+                                              self._xq(c.hidden), self.x_s, c.eps)
             else:
                 ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln1"], self._xq(c.hidden), self.x_s, c.eps)
-            self._fp8_mm("qkv", L["qkv"], self.qkv)
-            ops.rope_and_store_kv(self.qkv, self.cos_sin, self.positions, self.k_pool[li], self.v_pool[li],
-                                  self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
+            sq = product("qkv", L["qkv"], self.qkv, True)
+            if sq:
+                ops.rope_and_store_kv_partial(self.qkv, P, sq, self.cos_sin, self.positions, self.k_pool[li],
+                                              self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim,
+                                              row_scale=self.x_s, col_scale=L["qkv"].scale)
+            else:
+                ops.rope_and_store_kv(self.qkv, self.cos_sin, self.positions, self.k_pool[li], self.v_pool[li],
+                                      self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim)
             self.attention(li, q_view, o_view, sm_scale)
             ops.per_token_quant_fp8(self.attn_out, self._xq(self.q_size), self.x_s)
-            self._fp8_mm("o", L["o"], row_out)
+            so = product("o", L["o"], row_out, tp is None)
             if tp is not None:
                 self._tp_sum()
-            ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln2"], self._xq(c.hidden), self.x_s, c.eps)
+            if so:
+                ops.rmsnorm_quant_fp8_partial(P, so, self.x_s, L["o"].scale, self.residual, L["ln2"], self._xq(c.hidden),
+                                              self.x_s, c.eps)
+            else:
+                ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln2"], self._xq(c.hidden), self.x_s, c.eps)
             self._fp8_mm("gate_up", L["gate_up"], self.gate_up)
             ops.silu_and_mul_quant_fp8(self.gate_up, self._xq(c.inter), self.x_s)
-            self._fp8_mm("down", L["down"], row_out)
+            pending = product("down", L["down"], row_out, tp is None and li != last)  # the last rows go to the final norm
+            pending_w = L["down"]
             if tp is not None:
                 self._tp_sum()
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)

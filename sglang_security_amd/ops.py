@@ -708,6 +708,72 @@ def fp8_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, bias=None, out=No
     return out
 
 
+def fp8_repack(w_nk):
+    """An e4m3 weight [N, K] (row-major) in the sequential-streaming layout of fp8_scaled_mm_packed (same shape and
+    byte count, not the same meaning)."""
+    _need_gpu(w_nk)
+    if w_nk.dim() != 2 or w_nk.stride(1) != 1 or w_nk.element_size() != 1:
+        raise SglkError("fp8_repack: a row-major [N, K] fp8 tensor")
+    N, K = w_nk.shape
+    out = torch.empty((N, K), dtype=w_nk.dtype, device=w_nk.device)
+    check(lib().sglk_fp8_repack(_ptr(w_nk), _ptr(out), N, K, w_nk.stride(0), _stream(w_nk)), "fp8_repack")
+    return out
+
+
+def fp8_mm_packed_workspace_bytes(M, N, K) -> int:
+    return int(lib().sglk_fp8_mm_packed_workspace_bytes(M, N, K))
+
+
+def fp8_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype, bias=None, out=None, workspace=None):
+    """fp8_scaled_mm on a weight from fp8_repack: mat_a [M, K] e4m3 row-major, packed [N, K]."""
+    _need_gpu(mat_a, packed, scales_a, scales_b)
+    M, K = mat_a.shape
+    N = packed.shape[0]
+    if packed.shape[1] != K or not packed.is_contiguous() or mat_a.stride(1) != 1:
+        raise SglkError("fp8_scaled_mm_packed: mat_a row-major [M, K], packed a contiguous [N, K] tensor from fp8_repack")
+    if scales_a.numel() != M or scales_b.numel() != N:
+        raise SglkError("fp8_scaled_mm_packed: scales_a must have M and scales_b N elements")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    elif tuple(out.shape) != (M, N) or out.dtype != out_dtype or out.stride(1) != 1:
+        raise SglkError(f"fp8_scaled_mm_packed: out must be a row-major [{M}, {N}] tensor of the output dtype")
+    check(lib().sglk_fp8_scaled_mm_packed(_ptr(mat_a), _ptr(packed), _ptr(scales_a.contiguous()), _ptr(scales_b.contiguous()),
+                                          _ptr(bias), _ptr(out), M, N, K, mat_a.stride(0), out.stride(0), _ptr(workspace),
+                                          0 if workspace is None else workspace.numel() * workspace.element_size(),
+                                          dtype_code(out_dtype), _stream(mat_a)), "fp8_scaled_mm_packed")
+    return out
+
+
+def fp8_mm_packed_partial_splits(M, N, K) -> int:
+    return int(lib().sglk_fp8_mm_packed_partial_splits(M, N, K))
+
+
+def fp8_mm_packed_partial(mat_a, packed, partial):
+    """Raw split sums partial[split][M][N] (fp32) of mat_a @ W^T for a weight from fp8_repack; returns the slab count."""
+    _need_gpu(mat_a, packed, partial)
+    M, K = mat_a.shape
+    N = packed.shape[0]
+    splits = fp8_mm_packed_partial_splits(M, N, K)
+    if (packed.shape[1] != K or not packed.is_contiguous() or mat_a.stride(1) != 1 or splits <= 0
+            or partial.dtype != torch.float32 or partial.numel() < splits * M * N):
+        raise SglkError("fp8_mm_packed_partial: shape not covered or partial buffer too small")
+    check(lib().sglk_fp8_mm_packed_partial(_ptr(mat_a), _ptr(packed), _ptr(partial), M, N, K, mat_a.stride(0),
+                                           _stream(mat_a)), "fp8_mm_packed_partial")
+    return splits
+
+
+def rmsnorm_quant_fp8_partial(partials, splits, row_scale, col_scale, residual, weight, out_q, out_s, eps, gemma=False,
+                              bias=None):
+    """rmsnorm_quant_fp8 on rows that arrive as the raw split sums of an fp8 product (partials [splits, rows, hidden],
+    scaled by row_scale[row] * col_scale[col]); residual (updated in place) as there."""
+    _need_gpu(partials, weight, out_q, out_s)
+    rows, hidden = out_q.shape
+    check(lib().sglk_rmsnorm_quant_fp8_partial(_ptr(partials), int(splits), rows * hidden, _ptr(row_scale), _ptr(col_scale),
+                                               _ptr(bias), _ptr(residual), _ptr(weight), _ptr(out_q), _ptr(out_s), rows,
+                                               hidden, float(eps), 1 if gemma else 0, dtype_code(weight.dtype),
+                                               _stream(out_q)), "rmsnorm_quant_fp8_partial")
+
+
 def bmm_fp8(A, B, A_scale, B_scale, dtype, out=None):
     """bmm_fp8 (sgl-kernel/python/sgl_kernel/gemm.py:66-82): A [b, M, K] row-major, B [b, K, N] column-major (a
     transposed view of [b, N, K]), one fp32 scale per operand; e4m3 or e5m2 operands (not both e5m2)."""
@@ -884,10 +950,20 @@ def act_and_mul_xs(out, x, act, xsum_out):
 
 
 def rope_and_store_kv_partial(qkv, partials, splits, cos_sin_cache, positions, k_buffer, v_buffer, loc, q_heads, kv_heads,
-                              head_size, interleave=False, bias=None):
+                              head_size, interleave=False, bias=None, row_scale=None, col_scale=None):
+    """rope_and_store_kv on a qkv row that arrives as split-K partial sums; with row_scale / col_scale the sums are the
+    raw ones of an fp8 product and are scaled as that product's own split sum scales them."""
     _need_gpu(qkv, partials, cos_sin_cache, positions, k_buffer, v_buffer, loc)
     kb = k_buffer.view(k_buffer.shape[0], -1)
     vb = v_buffer.view(v_buffer.shape[0], -1)
+    if row_scale is not None or col_scale is not None:
+        _need_gpu(row_scale, col_scale)
+        check(lib().sglk_rope_and_store_kv_partial_scaled(
+            _ptr(qkv), _ptr(partials), int(splits), qkv.numel(), _ptr(bias), _ptr(row_scale), _ptr(col_scale),
+            _ptr(cos_sin_cache), _ptr(positions), _ptr(kb), _ptr(vb), _ptr(loc), _is64(loc), qkv.shape[0], q_heads, kv_heads,
+            head_size, cos_sin_cache.shape[1], kb.stride(0), vb.stride(0), 1 if interleave else 0, dtype_code(qkv.dtype),
+            _stream(qkv)), "rope_and_store_kv_partial_scaled")
+        return
     check(lib().sglk_rope_and_store_kv_partial(_ptr(qkv), _ptr(partials), int(splits), qkv.numel(), _ptr(bias),
                                                _ptr(cos_sin_cache), _ptr(positions), _ptr(kb), _ptr(vb), _ptr(loc),
                                                _is64(loc), qkv.shape[0], q_heads, kv_heads, head_size,

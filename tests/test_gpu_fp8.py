@@ -161,6 +161,33 @@ def test_fp8_scaled_mm_split_k(M, N, K, with_bias):
     torch.testing.assert_close(out.cpu().float(), one.cpu().float(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1280, 8192), (64, 8192, 1024), (64, 7168, 8192), (64, 8192, 3584), (64, 6144, 4096),
+                                   (5, 128, 4096), (100, 256, 2048), (1, 16, 128), (64, 28672, 4096)])
+@pytest.mark.parametrize("with_bias,with_ws", [(False, True), (True, True), (True, False)])
+def test_fp8_scaled_mm_packed(M, N, K, with_bias, with_ws):
+    """The streaming-layout product (sglk_fp8_repack + sglk_fp8_scaled_mm_packed: split along K through the workspace or
+    unsplit without one) on the decode shapes of the 70B TP = 8 shard and of the 8B model, more than 64 rows, one row:
+    the oracle's product at the reference test's tolerance, and the row-major kernel's result."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b_nk = _fp8_rand((M, K), g), _fp8_rand((N, K), g)
+    sa, sb = torch.rand(M, 1, generator=g) * 0.1, torch.rand(N, 1, generator=g) * 0.1
+    bias = torch.randn(N, generator=g).to(torch.bfloat16) if with_bias else None
+    packed = ops.fp8_repack(b_nk.to(DEV))
+    assert packed.shape == b_nk.shape
+    ws = torch.empty(max(ops.fp8_mm_packed_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=DEV) if with_ws else None
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.fp8_scaled_mm_packed(a.to(DEV), packed, sa.to(DEV), sb.to(DEV), torch.bfloat16, None if bias is None else bias.to(DEV),
+                             out, ws)
+    ref = ops.fp8_scaled_mm(a.to(DEV), b_nk.to(DEV).t(), sa.to(DEV), sb.to(DEV), torch.bfloat16,
+                            None if bias is None else bias.to(DEV))
+    want = oracle.fp8_scaled_mm(a, b_nk.t(), sa, sb, torch.bfloat16, bias)
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(out.cpu().float(), ref.cpu().float(), rtol=1e-2, atol=1e-2)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows,hidden", [(64, 8192), (5, 512), (3, 14336), (1, 4096)])
 @pytest.mark.parametrize("with_residual", [True, False])
@@ -275,3 +302,78 @@ def test_fp8_blockwise_vs_oracle(M, N, K, out_dtype, a_col_major):
         sa_d = sa_d.t().contiguous().t()
     out = ops.fp8_blockwise_scaled_mm(a.to(DEV), b_nk.to(DEV).t(), sa_d, sb_nk.to(DEV).t(), out_dtype)
     torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_fp8_split_sums_handed_to_consumers():
+    """The raw split sums of the streaming product consumed by the rotation kernel and by the fused add + norm +
+    quantisation kernel give the bits of the product's own reduction launch followed by the plain kernels."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(9)
+    M, K, N = 64, 4096, 4096
+    a, b_nk = _fp8_rand((M, K), g).to(DEV), _fp8_rand((N, K), g).to(DEV)
+    sa = (torch.rand(M, generator=g) * 0.1).to(DEV)
+    sb = (torch.rand(N, generator=g) * 0.1).to(DEV)
+    packed = ops.fp8_repack(b_nk)
+    splits = ops.fp8_mm_packed_partial_splits(M, N, K)
+    assert splits > 1
+    ws = torch.empty(ops.fp8_mm_packed_workspace_bytes(M, N, K), dtype=torch.uint8, device=DEV)
+    full = ops.fp8_scaled_mm_packed(a, packed, sa, sb, torch.bfloat16, None, None, ws)
+    part = torch.empty(splits * M * N, dtype=torch.float32, device=DEV)
+    assert ops.fp8_mm_packed_partial(a, packed, part) == splits
+    # fused add + norm + quantisation
+    res0 = torch.randn(M, N, generator=g).to(torch.bfloat16).to(DEV)
+    w = (1 + 0.1 * torch.randn(N, generator=g)).to(torch.bfloat16).to(DEV)
+    q_ref = torch.empty(M, N, dtype=F8, device=DEV)
+    s_ref = torch.empty(M, dtype=torch.float32, device=DEV)
+    r_ref = res0.clone()
+    ops.rmsnorm_quant_fp8(full, r_ref, w, q_ref, s_ref, 1e-5)
+    q = torch.empty_like(q_ref)
+    s = sa.clone()                                 # the product's activation scales, replaced by the kernel's own
+    r = res0.clone()
+    ops.rmsnorm_quant_fp8_partial(part, splits, s, sb, r, w, q, s, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(r, r_ref) and torch.equal(s, s_ref) and torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+    # rotation + pool write: the product read as a qkv row of 24 + 2 x 4 heads of 128
+    Hq, Hkv, D = 24, 4, 128
+    cs = torch.randn(64, D, generator=g).to(DEV)
+    pos = torch.randint(0, 64, (M,), generator=g).to(DEV)
+    loc = (torch.randperm(100, generator=g)[:M] + 1).to(DEV)
+    kb_ref = torch.zeros(128, Hkv, D, dtype=torch.bfloat16, device=DEV)
+    vb_ref = torch.zeros_like(kb_ref)
+    qkv_ref = full.clone()
+    ops.rope_and_store_kv(qkv_ref, cs, pos, kb_ref, vb_ref, loc, Hq, Hkv, D)
+    kb, vb = torch.zeros_like(kb_ref), torch.zeros_like(kb_ref)
+    qkv = torch.empty_like(full)
+    ops.rope_and_store_kv_partial(qkv, part, splits, cs, pos, kb, vb, loc, Hq, Hkv, D, row_scale=sa, col_scale=sb)
+    torch.cuda.synchronize()
+    assert torch.equal(qkv, qkv_ref) and torch.equal(kb, kb_ref) and torch.equal(vb, vb_ref)
+
+
+def test_fp8_decode_step_hand_over_matches_plain():
+    """The fp8 decode step with the streaming layout and the split sums handed to their consumers against the same
+    step on the row-major kernels (tiny model with K >= 4096 would not be tiny: the packing threshold is lowered)."""
+    from sglang_security_amd import decode_runner
+    from sglang_security_amd.decode_runner import LlamaConfig, LlamaDecoder
+
+    cfg = LlamaConfig.tiny("fp8")
+    decs = []
+    for packed in (False, True):
+        dec = LlamaDecoder(cfg, batch=6, pool_slots=1 + 64 + 6 * 24, max_ctx=96, device=DEV, seed=0)
+        dec.setup_shared_prefix_batch(prefix_len=64, suffix_len=5)
+        dec.enable_shared_prefix(True)
+        if packed:
+            for L in dec.layers:                      # every projection on the streaming layout, whatever its K
+                for name in ("qkv", "o", "gate_up", "down"):
+                    L[name].wpacked = _ops().fp8_repack(L[name].weight)
+            need = max(_ops().fp8_mm_packed_partial_splits(6, L[n].N, L[n].K) * 6 * L[n].N for n in ("qkv", "o", "down"))
+            dec.fp8_partial = torch.empty(need, dtype=torch.float32, device=DEV)
+        decs.append(dec)
+    ref, fus = decs
+    for _ in range(3):
+        ref.step()
+        fus.step()
+        torch.cuda.synchronize()
+        l0, l1 = ref.logits.float().cpu(), fus.logits.float().cpu()
+        assert torch.isfinite(l1).all()
+        assert (l0 - l1).abs().max().item() < 0.05 * max(1.0, l0.abs().max().item())
+        fus.input_ids.copy_(ref.input_ids)
