@@ -616,6 +616,7 @@ class LlamaDecoder:
         collectives take over (parallel_state.py:436-461).  Works with the plain op sequence, the fp8 sequence and
         the fused layer path (there the split-K reduction closes inside the GEMM before the collective)."""
         self.tp_group = group
+        self.fused_dense = False  # the 16-bit step's consumer-side split sums have no row-parallel form: plain sequence
         self.tp_rank, self.tp_world = group.rank_in_group, group.world_size
         self.tp_buf = torch.empty_like(self.hidden)
         self.tp_buf_registered = group.register_buffer(self.tp_buf)
