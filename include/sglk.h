@@ -577,6 +577,14 @@ SGLK_API int sglk_fp8_scaled_mm_packed(const void* a, const void* packed, const 
                                        const float* scales_b, const void* bias, void* out, int M, int N,
                                        int K, int64_t a_stride, int64_t out_stride, void* workspace,
                                        int64_t workspace_bytes, int out_dtype, void* stream);
+/* The block-scaled product (sglk_fp8_blockwise_scaled_mm: a contiguous [M, K], out contiguous [M, N]) on a weight from
+ * sglk_fp8_repack; scale arguments and strides as there.  Narrow outputs split along K through the workspace
+ * (sglk_fp8_mm_packed_workspace_bytes()), without one the product runs unsplit. */
+SGLK_API int sglk_fp8_blockwise_scaled_mm_packed(const void* a, const void* packed, const float* scales_a,
+                                                 const float* scales_b, void* out, int M, int N, int K,
+                                                 int64_t sa_stride_m, int64_t sa_stride_k, int64_t sb_stride_n,
+                                                 int64_t sb_stride_k, void* workspace, int64_t workspace_bytes,
+                                                 int out_dtype, void* stream);
 /* The streaming product's raw split sums partial[split][M][N] (sglk_fp8_mm_packed_partial_splits(M, N, K) slabs, 0 =
  * shape not covered; one slab when the shape does not split) left to the kernel that consumes the product:
  * sglk_rmsnorm_quant_fp8_partial and sglk_rope_and_store_kv_partial_scaled form

@@ -560,13 +560,19 @@ __device__ __forceinline__ int fs_off(int r, int c) { return r * 128 + ((c ^ ((r
 __device__ __forceinline__ long lo64(int4v v) { return (long)(uint32_t)v.x | ((long)v.y << 32); }
 __device__ __forceinline__ long hi64(int4v v) { return (long)(uint32_t)v.z | ((long)v.w << 32); }
 
-template <typename TO, int NS, int PF>
+// BW: the block-scaled form (DeepSeek): sa[m, kb] (strides sa_m, sa_k) and sb[n / 128, kb] (strides sb_n, sb_k) scale
+// every 128-k block's product before it is added up; the activation scales of a k-block travel with its tile, the
+// weight scale with the weight pieces.
+template <typename TO, int NS, int PF, bool BW = false>
 __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ wp,
                                                             const float* __restrict__ sa, const float* __restrict__ sb,
                                                             const void* __restrict__ bias, void* __restrict__ out,
                                                             float* __restrict__ partial, int M, int N, int K,
-                                                            int kb_per_split, int64_t x_stride, int64_t out_stride) {
+                                                            int kb_per_split, int64_t x_stride, int64_t out_stride,
+                                                            int64_t sa_m = 0, int64_t sa_k = 0, int64_t sb_n = 0,
+                                                            int64_t sb_k = 0) {
   __shared__ __attribute__((aligned(16))) char xs[2 * 64 * 128];
+  __shared__ __attribute__((aligned(16))) float sas[2][64];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   const int kblocks = K / 128;
@@ -580,14 +586,19 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
   const bool xrow_ok = (m0 + xr) < M;
   const uint8_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
   int4v xreg[2][2];
-  auto x_fetch = [&](int4v(&r2)[2], int kb) {
+  [[maybe_unused]] float sareg[2] = {0.f, 0.f};
+  auto x_fetch = [&](int4v(&r2)[2], int kb, [[maybe_unused]] float& sr) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
       r2[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * (int64_t)kb + 16 * c) : int4v{0, 0, 0, 0};
+    if constexpr (BW)
+      if (xq == 0) sr = xrow_ok ? sa[(int64_t)(m0 + xr) * sa_m + (int64_t)kb * sa_k] : 0.f;
   };
-  auto x_park = [&](const int4v(&r2)[2], int buf) {
+  auto x_park = [&](const int4v(&r2)[2], int buf, [[maybe_unused]] float sr) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) *reinterpret_cast<int4v*>(xs + buf * 8192 + fs_off(xr, 2 * xq + c)) = r2[c];
+    if constexpr (BW)
+      if (xq == 0) sas[buf][xr] = sr;
   };
 
   const uint8_t* wsrc[NS];
@@ -598,13 +609,21 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
   }
   auto wload = [](const uint8_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const int4v*>(p)); };
   int4v wq[PF][NS][2];
+  [[maybe_unused]] float wsc[PF][NS];
+  [[maybe_unused]] const float* sbrow[NS];
+  if constexpr (BW) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sbrow[s] = sb + (int64_t)(min(n0 + 16 * s, N - 1) >> 7) * sb_n + (int64_t)kb0 * sb_k;
+  }
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p < nkb) {
 #pragma unroll
-      for (int s = 0; s < NS; ++s)
+      for (int s = 0; s < NS; ++s) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) wq[p][s][h] = wload(wsrc[s] + 2048 * p + 1024 * h);
+        if constexpr (BW) wsc[p][s] = sbrow[s][(int64_t)p * sb_k];
+      }
     }
 
   f32x4 oacc[NS][4];
@@ -614,9 +633,9 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
     for (int mt = 0; mt < 4; ++mt) oacc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   static_assert(PF % 2 == 0, "the activation registers alternate with the parity of the k-block");
-  x_fetch(xreg[0], kb0);
-  if (nkb > 1) x_fetch(xreg[1], kb0 + 1);
-  x_park(xreg[0], 0);
+  x_fetch(xreg[0], kb0, sareg[0]);
+  if (nkb > 1) x_fetch(xreg[1], kb0 + 1, sareg[1]);
+  x_park(xreg[0], 0, sareg[0]);
   __syncthreads();
 
   for (int base = 0; base < nkb; base += PF) {
@@ -625,25 +644,47 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
       const int j = base + p;
       if (j < nkb) {
         const int buf = j & 1;
-        if (j + 2 < nkb) x_fetch(xreg[p & 1], kb0 + j + 2);  // block j's own registers were parked a step ago
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
+        // block j's own registers were parked a step ago
+        if (j + 2 < nkb) x_fetch(xreg[p & 1], kb0 + j + 2, sareg[p & 1]);
+        if constexpr (BW) {
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
-            const int4v af = *reinterpret_cast<const int4v*>(xs + buf * 8192 + fs_off(16 * mt + i16, 2 * g + h));
+            const int4v af0 = *reinterpret_cast<const int4v*>(xs + buf * 8192 + fs_off(16 * mt + i16, 2 * g));
+            const int4v af1 = *reinterpret_cast<const int4v*>(xs + buf * 8192 + fs_off(16 * mt + i16, 2 * g + 1));
+            const f32x4 as4 = *reinterpret_cast<const f32x4*>(&sas[buf][16 * mt + 4 * g]);  // rows 16 mt + 4 g + r
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-              oacc[s][mt] = mma_f8<0>(lo64(af), lo64(wq[p][s][h]), oacc[s][mt]);
-              oacc[s][mt] = mma_f8<0>(hi64(af), hi64(wq[p][s][h]), oacc[s][mt]);
+              f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+              acc = mma_f8<0>(lo64(af0), lo64(wq[p][s][0]), acc);
+              acc = mma_f8<0>(hi64(af0), hi64(wq[p][s][0]), acc);
+              acc = mma_f8<0>(lo64(af1), lo64(wq[p][s][1]), acc);
+              acc = mma_f8<0>(hi64(af1), hi64(wq[p][s][1]), acc);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) oacc[s][mt][r] += acc[r] * (as4[r] * wsc[p][s]);
             }
           }
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+              const int4v af = *reinterpret_cast<const int4v*>(xs + buf * 8192 + fs_off(16 * mt + i16, 2 * g + h));
+#pragma unroll
+              for (int s = 0; s < NS; ++s) {
+                oacc[s][mt] = mma_f8<0>(lo64(af), lo64(wq[p][s][h]), oacc[s][mt]);
+                oacc[s][mt] = mma_f8<0>(hi64(af), hi64(wq[p][s][h]), oacc[s][mt]);
+              }
+            }
+        }
         if (j + PF < nkb) {
 #pragma unroll
-          for (int s = 0; s < NS; ++s)
+          for (int s = 0; s < NS; ++s) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) wq[p][s][h] = wload(wsrc[s] + 2048 * (int64_t)(j + PF) + 1024 * h);
+            if constexpr (BW) wsc[p][s] = sbrow[s][(int64_t)(j + PF) * sb_k];
+          }
         }
-        if (j + 1 < nkb) x_park(xreg[(p + 1) & 1], buf ^ 1);
+        if (j + 1 < nkb) x_park(xreg[(p + 1) & 1], buf ^ 1, sareg[(p + 1) & 1]);
         __syncthreads();
       }
     }
@@ -654,7 +695,7 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
   for (int s = 0; s < NS; ++s) {
     const int n = n0 + 16 * s;
     if (n >= N) continue;
-    const float sbn = partial ? 1.f : sb[n];
+    const float sbn = (partial || BW) ? 1.f : sb[n];
     const float bn = (!partial && bias) ? ld<TO>(bias, n) : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -665,6 +706,8 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
         if (partial)
           __hip_atomic_store(&partial[((int64_t)blockIdx.y * M + m) * N + n], oacc[s][mt][r], __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
+        else if constexpr (BW)
+          st<TO>(out, (int64_t)m * out_stride + n, oacc[s][mt][r]);
         else
           st<TO>(out, (int64_t)m * out_stride + n, oacc[s][mt][r] * sa[m] * sbn + bn);
       }
@@ -890,6 +933,38 @@ int sglk_fp8_scaled_mm_packed(const void* a, const void* packed, const float* sc
       const int64_t vecs = (int64_t)M * (N / 4);
       hipLaunchKernelGGL((fp8_splitk_reduce_kernel<TO>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
                          (const float*)workspace, used, scales_a, scales_b, bias, out, M, N, out_stride);
+    }
+  });
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_fp8_blockwise_scaled_mm_packed(const void* a, const void* packed, const float* scales_a, const float* scales_b,
+                                        void* out, int M, int N, int K, int64_t sa_stride_m, int64_t sa_stride_k,
+                                        int64_t sb_stride_n, int64_t sb_stride_k, void* workspace, int64_t workspace_bytes,
+                                        int out_dtype, void* stream) {
+  SGLK_CHECK(a && packed && scales_a && scales_b && out, "fp8_blockwise_scaled_mm_packed: null pointer");
+  SGLK_CHECK(M > 0 && N > 0 && K > 0 && N % 16 == 0 && K % 128 == 0,
+             "fp8_blockwise_scaled_mm_packed: N=%d must be a multiple of 16, K=%d of 128", N, K);
+  SGLK_CHECK(aligned16(a) && aligned16(packed), "fp8_blockwise_scaled_mm_packed: operands must be 16-byte aligned");
+  int splits = fp8_stream_splits(M, N, K);
+  const int kblocks = K / 128;
+  if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * N * (int64_t)sizeof(float) ||
+                     !aligned16(workspace)))
+    splits = 1;
+  const int per = (kblocks + splits - 1) / splits;
+  const int used = (kblocks + per - 1) / per;
+  float* partial = used > 1 ? (float*)workspace : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  SGLK_DISPATCH_HALF(out_dtype, TO, {
+    hipLaunchKernelGGL((fp8_stream_kernel<TO, 1, 4, true>), dim3((N + 63) / 64, used, (M + 63) / 64), dim3(256), 0, s,
+                       (const uint8_t*)a, (const uint8_t*)packed, scales_a, scales_b, (const void*)nullptr, out, partial, M,
+                       N, K, per, (int64_t)K, (int64_t)N, sa_stride_m, sa_stride_k, sb_stride_n, sb_stride_k);
+    if (used > 1) {
+      const int64_t vecs = (int64_t)M * (N / 4);
+      hipLaunchKernelGGL((fp8_splitk_reduce_kernel<TO>), dim3((unsigned)((vecs + 255) / 256)), dim3(256), 0, s,
+                         (const float*)workspace, used, (const float*)nullptr, (const float*)nullptr,
+                         (const void*)nullptr, out, M, N, (int64_t)N);
     }
   });
   SGLK_LAUNCH_CHECK();

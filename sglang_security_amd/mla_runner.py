@@ -69,6 +69,14 @@ class BlockFp8Linear:
         self.scale = (amax / 448.0).float().contiguous()                       # [nb, kb]
         s_full = self.scale.repeat_interleave(128, 0)[:N].repeat_interleave(128, 1)
         self.weight = (w / s_full).clamp(-448.0, 448.0).to(F8).contiguous()
+        self.wpacked = None
+
+    def pack(self):
+        """A second copy in the streaming layout of fp8_blockwise_scaled_mm_packed for the decode step (inner
+        dimensions of 4096 and more: shorter ones are faster on the row-major kernel)."""
+        if self.wpacked is None and self.N % 16 == 0 and self.K % 128 == 0 and self.K >= 4096:
+            self.wpacked = ops.fp8_repack(self.weight)
+        return self
 
     def bytes(self):
         return self.weight.numel() + self.scale.numel() * 4
@@ -80,7 +88,7 @@ class BlockFp8Linear:
 
 class DeepseekV3DenseDecoder:
     def __init__(self, cfg: DeepseekV3Config, batch: int, pool_slots: int, max_ctx: int, device="cuda", seed=0,
-                 max_kv_splits=8):
+                 max_kv_splits=8, streaming_weights=True):
         self.cfg, self.B, self.device, self.dtype = cfg, batch, device, torch.bfloat16
         c, B, dt = cfg, batch, torch.bfloat16
         assert c.kv_lora_rank == 512 and c.qk_rope_head_dim == 64, "the latent attention kernel is built for 512 + 64"
@@ -90,7 +98,7 @@ class DeepseekV3DenseDecoder:
         self.sm_scale = 1.0 / math.sqrt(self.qk_head_dim)                        # deepseek_v2.py:586
 
         def lin(K, N):
-            return BlockFp8Linear(K, N, device, gen)
+            return BlockFp8Linear(K, N, device, gen).pack() if streaming_weights else BlockFp8Linear(K, N, device, gen)
 
         def nw(n):
             return (1.0 + 0.1 * torch.randn(n, device=device, generator=gen)).to(dt)
@@ -144,7 +152,7 @@ class DeepseekV3DenseDecoder:
         ws = 256
         for K, N in ((c.hidden, c.q_lora_rank + self.lat), (c.q_lora_rank, c.heads * self.qk_head_dim),
                      (c.heads * c.v_head_dim, c.hidden), (c.hidden, 2 * c.inter), (c.inter, c.hidden)):
-            ws = max(ws, ops.fp8_mm_workspace_bytes(B, N, K))
+            ws = max(ws, ops.fp8_mm_workspace_bytes(B, N, K), ops.fp8_mm_packed_workspace_bytes(B, N, K))
         self.workspace = torch.zeros(ws, dtype=torch.uint8, device=device)
         self.positions = torch.zeros(B, dtype=torch.int64, device=device)
         self.seq_lens = torch.zeros(B, dtype=torch.int64, device=device)
@@ -184,6 +192,8 @@ class DeepseekV3DenseDecoder:
 
     def _mm(self, x2d, w: BlockFp8Linear):
         q, s = self._quant(x2d)
+        if w.wpacked is not None:
+            return ops.fp8_blockwise_scaled_mm_packed(q, w.wpacked, s, w.scale.t(), self.dtype, self.workspace)
         return ops.fp8_blockwise_scaled_mm(q, w.weight.t(), s, w.scale.t(), self.dtype, self.workspace)
 
     def _bmm(self, a_hmk, w_hnk, w_scale):

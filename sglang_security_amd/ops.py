@@ -744,6 +744,26 @@ def fp8_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype, bias=None
     return out
 
 
+def fp8_blockwise_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype, workspace=None):
+    """fp8_blockwise_scaled_mm on a weight from fp8_repack: mat_a [M, K] contiguous, packed [N, K], scales_a [M, K/128]
+    (any strides), scales_b [K/128, N/128] as the reference passes it."""
+    _need_gpu(mat_a, packed, scales_a, scales_b)
+    M, K = mat_a.shape
+    N = packed.shape[0]
+    kb, nb = K // 128, (N + 127) // 128
+    if not mat_a.is_contiguous() or packed.shape[1] != K or not packed.is_contiguous():
+        raise SglkError("fp8_blockwise_scaled_mm_packed: mat_a contiguous [M, K], packed a contiguous [N, K] from fp8_repack")
+    if tuple(scales_a.shape) != (M, kb) or tuple(scales_b.shape) != (kb, nb):
+        raise SglkError(f"fp8_blockwise_scaled_mm_packed: scales_a must be [{M},{kb}] and scales_b [{kb},{nb}]")
+    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    check(lib().sglk_fp8_blockwise_scaled_mm_packed(
+        _ptr(mat_a), _ptr(packed), _ptr(scales_a), _ptr(scales_b), _ptr(out), M, N, K, scales_a.stride(0), scales_a.stride(1),
+        scales_b.stride(1), scales_b.stride(0), _ptr(workspace),
+        0 if workspace is None else workspace.numel() * workspace.element_size(), dtype_code(out_dtype), _stream(mat_a)),
+        "fp8_blockwise_scaled_mm_packed")
+    return out
+
+
 def fp8_mm_packed_partial_splits(M, N, K) -> int:
     return int(lib().sglk_fp8_mm_packed_partial_splits(M, N, K))
 

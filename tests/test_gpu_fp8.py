@@ -377,3 +377,27 @@ def test_fp8_decode_step_hand_over_matches_plain():
         assert torch.isfinite(l1).all()
         assert (l0 - l1).abs().max().item() < 0.05 * max(1.0, l0.abs().max().item())
         fus.input_ids.copy_(ref.input_ids)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 7168, 16384), (64, 36864, 7168), (64, 7168, 18432), (64, 2112, 7168), (5, 576, 4096),
+                                   (100, 256, 2048), (1, 16, 128)])
+@pytest.mark.parametrize("with_ws", [True, False])
+def test_fp8_blockwise_scaled_mm_packed(M, N, K, with_ws):
+    """The block-scaled product on the streaming layout (the dense projections of a DeepSeek-V3 layer, a few odd
+    shapes, with and without the split-K workspace) against the oracle and the row-major kernel."""
+    import oracle
+
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b_nk = _fp8_rand((M, K), g), _fp8_rand((N, K), g)
+    kb, nb = K // 128, (N + 127) // 128
+    sa = torch.rand(M, kb, generator=g) * 0.05 + 0.01
+    sb_nk = torch.rand(nb, kb, generator=g) * 0.05 + 0.01
+    packed = ops.fp8_repack(b_nk.to(DEV))
+    ws = torch.empty(max(ops.fp8_mm_packed_workspace_bytes(M, N, K), 16), dtype=torch.uint8, device=DEV) if with_ws else None
+    out = ops.fp8_blockwise_scaled_mm_packed(a.to(DEV), packed, sa.to(DEV), sb_nk.to(DEV).t(), torch.bfloat16, ws)
+    ref = ops.fp8_blockwise_scaled_mm(a.to(DEV), b_nk.to(DEV).t(), sa.to(DEV), sb_nk.to(DEV).t(), torch.bfloat16)
+    want = oracle.fp8_blockwise_mm(a, b_nk, sa, sb_nk, torch.bfloat16)
+    scale = want.float().abs().max().item()
+    torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2 * max(scale, 1.0))
+    torch.testing.assert_close(out.cpu().float(), ref.cpu().float(), rtol=1e-2, atol=1e-2 * max(scale, 1.0))
