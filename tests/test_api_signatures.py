@@ -101,6 +101,7 @@ def _class_cases():
     from sglang_security_amd.mem_cache.radix_cache import RadixCache
     from sglang_security_amd.private_service.private_client import PrivateJudgeClient
     from sglang_security_amd.quantization.awq import AWQLinearMethod
+    from sglang_security_amd.quantization.w8a8_fp8 import W8A8Fp8LinearMethod
 
     return {
         # reference class: (mirror, methods that must match, methods deliberately absent)
@@ -138,12 +139,14 @@ def _class_cases():
                              {"get_contiguous_buf_infos", "get_flat_data", "transfer", "transfer_per_layer"}),
         "AWQLinearMethod": (AWQLinearMethod, ["__init__", "create_weights", "process_weights_after_loading", "apply"],
                             set()),
+        "W8A8Fp8LinearMethod": (W8A8Fp8LinearMethod,
+                                ["__init__", "create_weights", "process_weights_after_loading", "apply"], set()),
     }
 
 
 @pytest.mark.parametrize("ref_class", ["AttentionBackend", "RadixCache", "CustomAllreduce", "GroupCoordinator",
                                        "PrivateJudgeClient", "ReqToTokenPool", "TokenToKVPoolAllocator",
-                                       "MHATokenToKVPool", "AWQLinearMethod"])
+                                       "MHATokenToKVPool", "AWQLinearMethod", "W8A8Fp8LinearMethod"])
 def test_class_mirror_matches_the_reference(ref_class):
     mirror, must, absent = _class_cases()[ref_class]
     rec = API["classes"][ref_class]

@@ -1,6 +1,8 @@
 """GPU parity for the fp8 (e4m3fn) path through the C ABI: activation quantisation (bit-exact codes and scales
 against the C oracle) and the two scaled matmuls (fp32-accumulated; tolerance rtol 2e-2 as in
 sgl-kernel/tests/test_fp8_gemm.py:45 and test_fp8_blockwise_gemm.py:86 (rtol 0.02 on the relative mean error))."""
+import math
+
 import pytest
 import torch
 
@@ -401,3 +403,40 @@ def test_fp8_blockwise_scaled_mm_packed(M, N, K, with_ws):
     scale = want.float().abs().max().item()
     torch.testing.assert_close(out.cpu().float(), want.float(), rtol=2e-2, atol=2e-2 * max(scale, 1.0))
     torch.testing.assert_close(out.cpu().float(), ref.cpu().float(), rtol=1e-2, atol=1e-2 * max(scale, 1.0))
+
+
+@pytest.mark.parametrize("serialized", [False, True])
+@pytest.mark.parametrize("K,N", [(4096, 1024), (512, 256)])
+def test_w8a8_fp8_linear_method(serialized, K, N):
+    """The W8A8Fp8LinearMethod mirror (w8a8_fp8.py:100-182): weights quantised per output channel at load time (or taken
+    from an fp8-serialised checkpoint), activations per token in apply; decode-size batches on the streaming copy where
+    it exists (K >= 4096), larger ones on the row-major kernel; against the oracle's quantise + scaled product."""
+    import oracle
+    from sglang_security_amd.quantization import W8A8Fp8Config, W8A8Fp8LinearMethod
+
+    g = torch.Generator().manual_seed(K + N)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16)
+    wq_ref, ws_ref = oracle.per_token_quant_fp8(w)                 # one scale per output channel
+    method = W8A8Fp8LinearMethod(W8A8Fp8Config(is_checkpoint_fp8_serialized=serialized))
+    layer = torch.nn.Module()
+    method.create_weights(layer, K, [N], K, N, torch.bfloat16, device=DEV)
+    if serialized:
+        assert layer.weight.dtype == F8 and tuple(layer.weight_scale.shape) == (N, 1)
+        layer.weight.data.copy_(wq_ref.to(DEV))
+        layer.weight_scale.data.copy_(ws_ref.reshape(N, 1).to(DEV))
+    else:
+        assert layer.weight.dtype == torch.bfloat16 and layer.weight_scale is None
+        layer.weight.data.copy_(w.to(DEV))
+    method.process_weights_after_loading(layer)
+    assert tuple(layer.weight.shape) == (K, N) and layer.weight.dtype == F8 and tuple(layer.weight_scale.shape) == (N, 1)
+    assert torch.equal(layer.weight.t().contiguous().view(torch.uint8).cpu(), wq_ref.view(torch.uint8))
+    assert torch.equal(layer.weight_scale.cpu().reshape(-1), ws_ref.reshape(-1))
+    assert (layer.sglk_packed is not None) == (K >= 4096)
+    for m in (5, 300):
+        x = torch.randn(2, m, K, generator=g).to(torch.bfloat16)
+        xq, xs = oracle.per_token_quant_fp8(x.reshape(-1, K))
+        want = oracle.fp8_scaled_mm(xq, wq_ref.t(), xs.reshape(-1, 1), ws_ref.reshape(-1, 1), torch.bfloat16, bias)
+        out = method.apply(layer, x.to(DEV), bias.to(DEV))
+        assert tuple(out.shape) == (2, m, N) and out.dtype == torch.bfloat16
+        torch.testing.assert_close(out.reshape(-1, N).cpu().float(), want.float(), rtol=2e-2, atol=2e-2)

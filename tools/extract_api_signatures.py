@@ -95,6 +95,7 @@ def main():
         "distributed/parallel_state.py": ["GroupCoordinator"],
         "managers/private_service/private_client.py": ["PrivateJudgeClient"],
         "layers/quantization/awq.py": ["AWQConfig", "AWQLinearMethod"],
+        "layers/quantization/w8a8_fp8.py": ["W8A8Fp8Config", "W8A8Fp8LinearMethod"],
     }.items():
         for c in classes:
             doc["classes"][c] = {"file": "python/sglang/srt/" + rel, **class_methods(os.path.join(srt, rel), c)}
