@@ -128,6 +128,14 @@ def _attn_dtype(q, k_buffer, v_buffer=None) -> int:
     return code | (f << _KV_SHIFT)
 
 
+def _same_type_pool(name, rows, k_buffer, v_buffer):
+    """The fused rotation + pool-write kernels store rows in the rows' own type: an fp8 (or otherwise retyped) pool goes
+    through rope + set_kv_buffer, which round to the pool's format."""
+    if k_buffer.dtype != rows.dtype or v_buffer.dtype != rows.dtype:
+        raise SglkError(f"{name}: the pools hold {k_buffer.dtype}, the rows {rows.dtype}; use rope followed by "
+                        f"set_kv_buffer for a pool of another type")
+
+
 def _last_dim_contig(t, name):
     if t.stride(-1) != 1:
         raise SglkError(f"{name}: last dimension must be contiguous")
@@ -382,6 +390,7 @@ def rope_and_store_kv(qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc, q_
     _need_gpu(qkv, cos_sin_cache, positions, k_buffer, v_buffer, loc)
     if not qkv.is_contiguous() or positions.dtype != torch.int64:
         raise SglkError("rope_and_store_kv: qkv must be contiguous and positions int64")
+    _same_type_pool("rope_and_store_kv", qkv, k_buffer, v_buffer)
     kb = k_buffer.view(k_buffer.shape[0], -1)
     vb = v_buffer.view(v_buffer.shape[0], -1)
     check(lib().sglk_rope_and_store_kv(_ptr(qkv), _ptr(cos_sin_cache), _ptr(positions), _ptr(kb), _ptr(vb), _ptr(loc),
@@ -974,6 +983,7 @@ def rope_and_store_kv_partial(qkv, partials, splits, cos_sin_cache, positions, k
     """rope_and_store_kv on a qkv row that arrives as split-K partial sums; with row_scale / col_scale the sums are the
     raw ones of an fp8 product and are scaled as that product's own split sum scales them."""
     _need_gpu(qkv, partials, cos_sin_cache, positions, k_buffer, v_buffer, loc)
+    _same_type_pool("rope_and_store_kv_partial", qkv, k_buffer, v_buffer)
     kb = k_buffer.view(k_buffer.shape[0], -1)
     vb = v_buffer.view(v_buffer.shape[0], -1)
     if row_scale is not None or col_scale is not None:
@@ -1025,6 +1035,7 @@ def decode_attention_shared_prefix_rope(partials, splits, part_stride, bias, cos
     the qkv projection's split-K partial sums [splits][B][(Hq + 2 Hkv) * 128]; o is [B, Hq, 128]."""
     _need_gpu(partials, cos_sin_cache, positions, loc, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr,
               prefix_lens, workspace)
+    _same_type_pool("decode_attention_shared_prefix_rope", o, k_buffer, v_buffer)
     B, Hq, D = o.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
     G = group_indptr.shape[0] - 1

@@ -412,3 +412,22 @@ def test_backend_decode_and_extend_over_fp8_pool():
     od2 = be.forward(qd, kd, vd, layer, fbd, save_kv_cache=False)
     torch.cuda.synchronize()
     assert (od2.float().cpu().view(B, Hq, D) - want_d).abs().max().item() < 2e-2
+
+
+def test_fused_rotation_kernels_refuse_a_retyped_pool():
+    """The kernels that rotate and write the new K / V rows in one launch store 16-bit rows: handed an fp8 pool they must
+    refuse (rope + set_kv_buffer is the path that rounds to the pool's format), not write 16-bit rows over bytes."""
+    from sglang_security_amd._lib import SglkError
+
+    ops = _ops()
+    qkv = torch.zeros(2, (4 + 2 * 2) * 128, dtype=torch.bfloat16, device=DEV)
+    cs = torch.zeros(8, 128, device=DEV)
+    pos = torch.zeros(2, dtype=torch.int64, device=DEV)
+    loc = torch.tensor([1, 2], device=DEV)
+    kb = torch.zeros(4, 2, 128, dtype=torch.uint8, device=DEV).view(torch.float8_e5m2fnuz)
+    with pytest.raises(SglkError):
+        ops.rope_and_store_kv(qkv, cs, pos, kb, kb, loc, 4, 2, 128)
+    part = torch.zeros(2 * qkv.numel(), dtype=torch.float32, device=DEV)
+    with pytest.raises(SglkError):
+        ops.rope_and_store_kv_partial(qkv, part, 2, cs, pos, kb, kb, loc, 4, 2, 128)
+    assert int(kb.view(torch.uint8).sum()) == 0
