@@ -587,7 +587,8 @@ SGLK_API int sglk_fp8_blockwise_scaled_mm_packed(const void* a, const void* pack
                                                  int out_dtype, void* stream);
 /* The streaming product's raw split sums partial[split][M][N] (sglk_fp8_mm_packed_partial_splits(M, N, K) slabs, 0 =
  * shape not covered; one slab when the shape does not split) left to the kernel that consumes the product:
- * sglk_rmsnorm_quant_fp8_partial and sglk_rope_and_store_kv_partial_scaled form
+ * sglk_rmsnorm_quant_fp8_partial, sglk_silu_and_mul_quant_fp8_partial (rows of 2 d columns: gate, then up; dtype = the
+ * 16-bit type the product would have stored) and sglk_rope_and_store_kv_partial_scaled form
  * round(sum * scales_a[m] * scales_b[n] + bias[n]) exactly as the reduction launch of sglk_fp8_scaled_mm_packed does
  * and carry on (fused add + norm + per-token quantisation; rotation + pool write).  row_scale may alias the `scales`
  * output of sglk_rmsnorm_quant_fp8_partial.  No counterpart in the reference, which runs these steps as separate ops. */
@@ -598,6 +599,9 @@ SGLK_API int sglk_rmsnorm_quant_fp8_partial(const float* partials, int splits, i
                                             const float* row_scale, const float* col_scale, const void* bias,
                                             void* residual, const void* weight, void* q, float* scales,
                                             int64_t rows, int hidden, float eps, int gemma, int dtype, void* stream);
+SGLK_API int sglk_silu_and_mul_quant_fp8_partial(const float* partials, int splits, int64_t part_stride,
+                                                 const float* row_scale, const float* col_scale, void* q,
+                                                 float* scales, int64_t rows, int d, int dtype, void* stream);
 SGLK_API int sglk_rope_and_store_kv_partial_scaled(void* qkv, const float* partials, int splits, int64_t part_stride,
                                                    const void* bias, const float* row_scale, const float* col_scale,
                                                    const float* cos_sin_cache, const int64_t* positions,

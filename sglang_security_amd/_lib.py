@@ -105,6 +105,7 @@ _SIGS = {
     "sglk_fp8_blockwise_scaled_mm_packed": (i32, [p, p, p, p, p, i32, i32, i32, i64, i64, i64, i64, p, i64, i32, p]),
     "sglk_fp8_mm_packed_partial_splits": (i32, [i32, i32, i32]),
     "sglk_fp8_mm_packed_partial": (i32, [p, p, p, i32, i32, i32, i64, p]),
+    "sglk_silu_and_mul_quant_fp8_partial": (i32, [p, i32, i64, p, p, p, p, i64, i32, i32, p]),
     "sglk_rmsnorm_quant_fp8_partial": (i32, [p, i32, i64, p, p, p, p, p, p, p, i64, i32, f32, i32, i32, p]),
     "sglk_rope_and_store_kv_partial_scaled": (i32, [p, p, i32, i64, p, p, p, p, p, p, p, p, i32, i64, i32, i32, i32, i32,
                                                i64, i64, i32, i32, p]),

@@ -214,10 +214,17 @@ __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restr
 // silu_and_mul (activation.cu:22-50) followed by sgl_per_token_quant_fp8
 template <typename T>
 __global__ __launch_bounds__(1024) void silu_mul_quant_kernel(const void* __restrict__ xin, uint8_t* __restrict__ q,
-                                                              float* __restrict__ scales, int d) {
+                                                              float* __restrict__ scales, int d,
+                                                              const float* __restrict__ partials, int splits,
+                                                              int64_t part_stride, const float* __restrict__ row_scale,
+                                                              const float* __restrict__ col_scale) {
+  // partials: x arrives as the raw split sums of the gate_up fp8 product, partials[s][row][2 d], and is formed as that
+  // product's own split sum forms it (round_T(sum * row_scale[row] * col_scale[n])).  row_scale may be the array
+  // `scales`: read before the block's barrier, written after it.
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
   const uint16_t* x = reinterpret_cast<const uint16_t*>(xin) + row * 2 * d;
+  const float rsc = (partials && row_scale) ? row_scale[row] : 1.f;
   const int nvec = d >> 3;
   constexpr int MAXV = 4;
   float keep[MAXV][8];
@@ -226,13 +233,30 @@ __global__ __launch_bounds__(1024) void silu_mul_quant_kernel(const void* __rest
   for (int it = 0; it < MAXV; ++it) {
     const int v = threadIdx.x + it * 1024;
     if (v < nvec) {
-      const short8 a = reinterpret_cast<const short8*>(x)[v];
-      const short8 g = reinterpret_cast<const short8*>(x + d)[v];
+      float ga[8], ua[8];
+      if (partials) {
+        sum_partials(partials, splits, part_stride, row * 2 * d + 8 * v, ga);
+        sum_partials(partials, splits, part_stride, row * 2 * d + d + 8 * v, ua);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float cg = col_scale ? col_scale[8 * v + j] : 1.f, cu = col_scale ? col_scale[d + 8 * v + j] : 1.f;
+          ga[j] = Conv<T>::to_f32(Conv<T>::from_f32(scaled_sum(ga[j], rsc, cg, 0.f)));  // what the product would store
+          ua[j] = Conv<T>::to_f32(Conv<T>::from_f32(scaled_sum(ua[j], rsc, cu, 0.f)));
+        }
+      } else {
+        const short8 a = reinterpret_cast<const short8*>(x)[v];
+        const short8 g = reinterpret_cast<const short8*>(x + d)[v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          ga[j] = Conv<T>::to_f32((uint16_t)a[j]);
+          ua[j] = Conv<T>::to_f32((uint16_t)g[j]);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float av = Conv<T>::to_f32((uint16_t)a[j]);
+        const float av = ga[j];
         const float sv = Conv<T>::to_f32(Conv<T>::from_f32(av / (1.0f + __expf(-av))));
-        keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32(sv * Conv<T>::to_f32((uint16_t)g[j])));
+        keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32(sv * ua[j]));
         amax = fmaxf(amax, fabsf(keep[it][j]));
       }
     }
@@ -838,7 +862,27 @@ int sglk_silu_and_mul_quant_fp8(const void* x, void* q, float* scales, int64_t r
   if (rows == 0) return SGLK_OK;
   SGLK_DISPATCH_HALF(dtype, T,
                      hipLaunchKernelGGL((silu_mul_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
-                                        x, (uint8_t*)q, scales, d));
+                                        x, (uint8_t*)q, scales, d, (const float*)nullptr, 0, (int64_t)0,
+                                        (const float*)nullptr, (const float*)nullptr));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_silu_and_mul_quant_fp8_partial(const float* partials, int splits, int64_t part_stride, const float* row_scale,
+                                        const float* col_scale, void* q, float* scales, int64_t rows, int d, int dtype,
+                                        void* stream) {
+  SGLK_CHECK(partials && q && scales, "silu_and_mul_quant_fp8_partial: null pointer");
+  SGLK_CHECK((row_scale == nullptr) == (col_scale == nullptr), "silu_and_mul_quant_fp8_partial: both scale vectors or neither");
+  SGLK_CHECK(rows >= 0 && d > 0 && d % 8 == 0 && d <= 4 * 1024 * 8,
+             "silu_and_mul_quant_fp8_partial: d=%d must be a multiple of 8, at most 32768", d);
+  SGLK_CHECK(splits >= 1 && part_stride >= rows * 2 * d && part_stride % 4 == 0 && aligned16(partials) &&
+                 ((uintptr_t)q & 7) == 0,
+             "silu_and_mul_quant_fp8_partial: bad partial layout");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((silu_mul_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
+                                        (const void*)nullptr, (uint8_t*)q, scales, d, partials, splits, part_stride,
+                                        row_scale, col_scale));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

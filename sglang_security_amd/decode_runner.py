@@ -310,7 +310,7 @@ class LlamaDecoder:
                     w = L[name]
                     if on:
                         w.pack()
-                        if w.wpacked is not None and name != "gate_up":
+                        if w.wpacked is not None:
                             need = max(need, ops.fp8_mm_packed_partial_splits(self.B, w.N, w.K) * self.B * w.N)
                     else:
                         w.wpacked = None
@@ -562,8 +562,14 @@ class LlamaDecoder:
                                               self.x_s, c.eps)
             else:
                 ops.rmsnorm_quant_fp8(self.hidden, self.residual, L["ln2"], self._xq(c.hidden), self.x_s, c.eps)
-            self._fp8_mm("gate_up", L["gate_up"], self.gate_up)
-            ops.silu_and_mul_quant_fp8(self.gate_up, self._xq(c.inter), self.x_s)
+            w = L["gate_up"]
+            sg = ops.fp8_mm_packed_partial_splits(self.B, w.N, w.K) if (P is not None and w.wpacked is not None) else 0
+            if sg > 1:  # an unsplit product gains nothing from the hand-over: it stores finished rows itself
+                product("gate_up", w, self.gate_up, True)
+                ops.silu_and_mul_quant_fp8_partial(P, sg, self.x_s, w.scale, self._xq(c.inter), self.x_s, self.dtype)
+            else:
+                self._fp8_mm("gate_up", w, self.gate_up)
+                ops.silu_and_mul_quant_fp8(self.gate_up, self._xq(c.inter), self.x_s)
             pending = product("down", L["down"], row_out, tp is None and li != last)  # the last rows go to the final norm
             pending_w = L["down"]
             if tp is not None:

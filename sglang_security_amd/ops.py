@@ -803,6 +803,16 @@ def rmsnorm_quant_fp8_partial(partials, splits, row_scale, col_scale, residual, 
                                                _stream(out_q)), "rmsnorm_quant_fp8_partial")
 
 
+def silu_and_mul_quant_fp8_partial(partials, splits, row_scale, col_scale, out_q, out_s, dtype):
+    """silu_and_mul_quant_fp8 on gate_up rows that arrive as the raw split sums of an fp8 product (partials
+    [splits, rows, 2 d]); dtype: the 16-bit type that product would have stored its rows in."""
+    _need_gpu(partials, out_q, out_s)
+    rows, d = out_q.shape
+    check(lib().sglk_silu_and_mul_quant_fp8_partial(_ptr(partials), int(splits), rows * 2 * d, _ptr(row_scale),
+                                                    _ptr(col_scale), _ptr(out_q), _ptr(out_s), rows, d, dtype_code(dtype),
+                                                    _stream(out_q)), "silu_and_mul_quant_fp8_partial")
+
+
 def bmm_fp8(A, B, A_scale, B_scale, dtype, out=None):
     """bmm_fp8 (sgl-kernel/python/sgl_kernel/gemm.py:66-82): A [b, M, K] row-major, B [b, K, N] column-major (a
     transposed view of [b, N, K]), one fp32 scale per operand; e4m3 or e5m2 operands (not both e5m2)."""

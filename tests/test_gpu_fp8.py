@@ -335,6 +335,15 @@ def test_fp8_split_sums_handed_to_consumers():
     ops.rmsnorm_quant_fp8_partial(part, splits, s, sb, r, w, q, s, 1e-5)
     torch.cuda.synchronize()
     assert torch.equal(r, r_ref) and torch.equal(s, s_ref) and torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+    # gated activation + quantisation: the product read as [gate | up] rows of 2 x 2048
+    qa_ref = torch.empty(M, N // 2, dtype=F8, device=DEV)
+    sa_ref = torch.empty(M, dtype=torch.float32, device=DEV)
+    ops.silu_and_mul_quant_fp8(full, qa_ref, sa_ref)
+    qa = torch.empty_like(qa_ref)
+    s2 = sa.clone()
+    ops.silu_and_mul_quant_fp8_partial(part, splits, s2, sb, qa, s2, torch.bfloat16)
+    torch.cuda.synchronize()
+    assert torch.equal(s2, sa_ref) and torch.equal(qa.view(torch.uint8), qa_ref.view(torch.uint8))
     # rotation + pool write: the product read as a qkv row of 24 + 2 x 4 heads of 128
     Hq, Hkv, D = 24, 4, 128
     cs = torch.randn(64, D, generator=g).to(DEV)
