@@ -264,9 +264,12 @@ def deepseek_dense_workload(args, dev, world):
                 torch.cuda._sleep(int(5e-3 * 2.0e9))
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(stream)
-                for L in dec.layers:
+                for L in dec.layers:  # the product the step runs (streaming layout where the layer holds one)
                     w = L[name]
-                    ops.fp8_blockwise_scaled_mm(xq, w.weight.t(), xs, w.scale.t(), torch.bfloat16, dec.workspace)
+                    if w.wpacked is not None:
+                        ops.fp8_blockwise_scaled_mm_packed(xq, w.wpacked, xs, w.scale.t(), torch.bfloat16, dec.workspace)
+                    else:
+                        ops.fp8_blockwise_scaled_mm(xq, w.weight.t(), xs, w.scale.t(), torch.bfloat16, dec.workspace)
                 b.record(stream)
                 stream.synchronize()
                 ts.append(a.elapsed_time(b) * 1e3 / cfg.layers)

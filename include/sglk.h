@@ -148,6 +148,21 @@ SGLK_API int sglk_prepare_for_decode(const int32_t* req_to_token, int64_t row_st
  * rotated IN PLACE in kv_buffer and copied to k_pe_out [B, rope_dim] -- the reference leaves the pool row as it is
  * and the caller then stores k_pe_out over it (models/deepseek_v2.py:1189-1193), after which the two agree.
  * Follow with sglk_decode_attention on q_out.  cos_sin_cache fp32 [max_pos, rotary_dim] (cos half, sin half). */
+/* Rotary step + cache write of the absorbed-MLA decode in one launch (forward_absorb,
+ * python/sglang/srt/models/deepseek_v2.py:1127-1193: rotary_emb on q_pe / k_pe, q_input[..., lora:] = q_pe,
+ * k_input = [k_nope | k_pe], set_kv_buffer of the latent row): for request b the rope part of every head,
+ * q_pe[b, h, 0..rope_dim) (strides qpe_stride_b / _h), is rotated at positions[b] into
+ * q_out[b, h, kv_lora_rank .. + rope_dim); the latent row latent[b] = [k_nope (kv_lora_rank, already normalised) |
+ * k_pe (rope_dim, unrotated)] is written to kv_buffer row loc[b] with its rope part rotated.  The first rotary_dim
+ * rope elements are rotated (neox halves or interleaved pairs), the rest copied.  cos_sin_cache fp32
+ * [max_pos, rotary_dim] (cos half, sin half). */
+SGLK_API int sglk_mla_rope_and_store(const void* q_pe, void* q_out, const void* latent, void* kv_buffer,
+                                     const void* loc, int loc_is64, const float* cos_sin_cache,
+                                     const int64_t* positions, int B, int H, int kv_lora_rank, int rope_dim,
+                                     int rotary_dim, int64_t qpe_stride_b, int64_t qpe_stride_h,
+                                     int64_t qo_stride_b, int64_t qo_stride_h, int64_t latent_stride_b,
+                                     int64_t kv_stride_n, int64_t cos_sin_stride, int is_neox, int dtype,
+                                     void* stream);
 SGLK_API int sglk_mla_rope_prepare(const void* q, void* q_out, void* kv_buffer, void* k_pe_out,
                                    const int32_t* kv_indptr, const int32_t* kv_indices,
                                    const float* cos_sin_cache, const int64_t* positions, int B, int H,
@@ -537,6 +552,13 @@ SGLK_API int sglk_per_token_group_quant_fp8(const void* x, void* q, float* scale
 /* Replaces sgl_per_tensor_quant_fp8, sgl-kernel/csrc/gemm/per_tensor_quant_fp8.cu. */
 SGLK_API int sglk_per_tensor_quant_fp8(const void* x, void* q, float* scale, int64_t numel,
                                        int is_static, int dtype, void* stream);
+/* The same quantisation of a [rows, cols] view whose rows lie x_row_stride elements apart (q: q_row_stride bytes
+ * apart), one scale for the whole view: what the reference reaches with per_tensor_quant_mla_fp8 on the sliced,
+ * transposed q_nope (python/sglang/srt/models/deepseek_v2.py:965-972) without the copy in between.  The dynamic
+ * form takes a running maximum into `scale`, which must hold 0 on entry. */
+SGLK_API int sglk_per_tensor_quant_fp8_rows(const void* x, void* q, float* scale, int64_t rows, int64_t cols,
+                                            int64_t x_row_stride, int64_t q_row_stride, int is_static,
+                                            int dtype, void* stream);
 /* out = (A @ B) * scales_a[M] * scales_b[N] (+bias); A [M,K] e4m3 row-major, B given as [N,K]
  * row-major (the reference's column-major [K,N]).  Replaces fp8_scaled_mm,
  * sgl-kernel/csrc/gemm/fp8_gemm_kernel.cu:1071-1146. */

@@ -95,6 +95,8 @@ _SIGS = {
     "sglk_per_token_quant_fp8": (i32, [p, p, p, i64, i32, i32, p]),
     "sglk_per_token_group_quant_fp8": (i32, [p, p, p, i64, i32, i32, f32, f32, f32, i32, i32, p]),
     "sglk_per_tensor_quant_fp8": (i32, [p, p, p, i64, i32, i32, p]),
+    "sglk_per_tensor_quant_fp8_rows": (i32, [p, p, p, i64, i64, i64, i64, i32, i32, p]),
+    "sglk_mla_rope_and_store": (i32, [p, p, p, p, p, i32, p, p] + [i32] * 5 + [i64] * 7 + [i32, i32, p]),
     "sglk_fp8_scaled_mm": (i32, [p, p, p, p, p, p, i32, i32, i32, i64, i64, i64, i32, p]),
     "sglk_fp8_blockwise_scaled_mm": (i32, [p, p, p, p, p, i32, i32, i32, i64, i64, i64, i64, i32, p]),
     "sglk_rmsnorm_quant_fp8": (i32, [p, p, p, p, p, i64, i32, f32, i32, i32, p]),

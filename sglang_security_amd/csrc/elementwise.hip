@@ -661,6 +661,56 @@ __global__ void __launch_bounds__(256) mla_rope_prepare_kernel(const void* __res
       st<T>(k_pe_out, (int64_t)b * kpe_stride_b + e, ld<T>(kv_buffer, loc * kv_stride_n + lora + e));
 }
 
+// Rotary step + cache write of the absorbed-MLA decode (models/deepseek_v2.py:1127-1193) in one launch.  Block
+// (request b, part y): parts 0 .. gridDim.y - 2 deal the H heads' rope parts among themselves (q_pe -> rotated into
+// q_out[..., lora ..]); the last part writes the latent row [k_nope | rotated k_pe] to pool row loc[b].
+template <typename T>
+__global__ void __launch_bounds__(256) mla_rope_store_kernel(const void* __restrict__ q_pe, void* __restrict__ q_out,
+                                                             const void* __restrict__ latent, void* __restrict__ kv_buffer,
+                                                             const void* __restrict__ loc, int loc_is64,
+                                                             const float* __restrict__ cos_sin,
+                                                             const int64_t* __restrict__ positions, int H, int lora,
+                                                             int rope_dim, int rot_dim, int64_t qp_b, int64_t qp_h,
+                                                             int64_t qo_b, int64_t qo_h, int64_t lat_b, int64_t kv_n,
+                                                             int64_t cs_stride, int neox) {
+  const int b = blockIdx.x;
+  const float* cs = cos_sin + positions[b] * cs_stride;
+  const int half = rot_dim / 2;
+  if ((int)blockIdx.y + 1 < (int)gridDim.y) {
+    const int parts = gridDim.y - 1;
+    const int per = (H + parts - 1) / parts;
+    const int h0 = blockIdx.y * per, h1 = min(h0 + per, H);
+    for (int i = threadIdx.x; i < (h1 - h0) * half; i += blockDim.x) {
+      const int h = h0 + i / half, p = i % half;
+      const int e0 = neox ? p : 2 * p, e1 = neox ? p + half : 2 * p + 1;
+      const float c = cs[p], sn = cs[half + p];
+      const int64_t src = (int64_t)b * qp_b + (int64_t)h * qp_h, dst = (int64_t)b * qo_b + (int64_t)h * qo_h + lora;
+      float y0, y1;
+      rope_pair(ld<T>(q_pe, src + e0), ld<T>(q_pe, src + e1), c, sn, y0, y1);
+      st<T>(q_out, dst + e0, y0);
+      st<T>(q_out, dst + e1, y1);
+    }
+    for (int i = threadIdx.x; i < (h1 - h0) * (rope_dim - rot_dim); i += blockDim.x) {
+      const int h = h0 + i / (rope_dim - rot_dim), e = rot_dim + i % (rope_dim - rot_dim);
+      st<T>(q_out, (int64_t)b * qo_b + (int64_t)h * qo_h + lora + e, ld<T>(q_pe, (int64_t)b * qp_b + (int64_t)h * qp_h + e));
+    }
+  } else {
+    const int64_t row = loc_is64 ? reinterpret_cast<const int64_t*>(loc)[b] : (int64_t) reinterpret_cast<const int32_t*>(loc)[b];
+    const int64_t src = (int64_t)b * lat_b, dst = row * kv_n;
+    for (int e = threadIdx.x; e < lora; e += blockDim.x) st<T>(kv_buffer, dst + e, ld<T>(latent, src + e));
+    for (int p = threadIdx.x; p < half; p += blockDim.x) {
+      const int e0 = neox ? p : 2 * p, e1 = neox ? p + half : 2 * p + 1;
+      const float c = cs[p], sn = cs[half + p];
+      float y0, y1;
+      rope_pair(ld<T>(latent, src + lora + e0), ld<T>(latent, src + lora + e1), c, sn, y0, y1);
+      st<T>(kv_buffer, dst + lora + e0, y0);
+      st<T>(kv_buffer, dst + lora + e1, y1);
+    }
+    for (int e = rot_dim + threadIdx.x; e < rope_dim; e += blockDim.x)
+      st<T>(kv_buffer, dst + lora + e, ld<T>(latent, src + lora + e));
+  }
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -912,6 +962,28 @@ int sglk_argmax(const void* x, int64_t* out, int64_t rows, int cols, int64_t row
   SGLK_DISPATCH_FLOAT(dtype, T,
                       hipLaunchKernelGGL((argmax_rows_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
                                          x, out, cols, row_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_mla_rope_and_store(const void* q_pe, void* q_out, const void* latent, void* kv_buffer, const void* loc,
+                            int loc_is64, const float* cos_sin_cache, const int64_t* positions, int B, int H,
+                            int kv_lora_rank, int rope_dim, int rotary_dim, int64_t qpe_stride_b, int64_t qpe_stride_h,
+                            int64_t qo_stride_b, int64_t qo_stride_h, int64_t latent_stride_b, int64_t kv_stride_n,
+                            int64_t cos_sin_stride, int is_neox, int dtype, void* stream) {
+  SGLK_CHECK(B >= 0 && H > 0 && kv_lora_rank >= 0 && rope_dim > 0, "mla_rope_and_store: bad shape");
+  SGLK_CHECK(rotary_dim > 0 && rotary_dim % 2 == 0 && rotary_dim <= rope_dim, "mla_rope_and_store: bad rotary dim");
+  SGLK_CHECK(qpe_stride_h >= rope_dim && qo_stride_h >= kv_lora_rank + rope_dim && latent_stride_b >= kv_lora_rank + rope_dim &&
+                 kv_stride_n >= kv_lora_rank + rope_dim && cos_sin_stride >= rotary_dim,
+             "mla_rope_and_store: bad strides");
+  if (B == 0) return SGLK_OK;
+  SGLK_CHECK(q_pe && q_out && latent && kv_buffer && loc && cos_sin_cache && positions, "mla_rope_and_store: null pointer");
+  const int parts = std::max(1, std::min(H, H * (rotary_dim / 2) / 1024));  // about four pairs a thread
+  SGLK_DISPATCH_FLOAT(dtype, T,
+                      hipLaunchKernelGGL((mla_rope_store_kernel<T>), dim3(B, parts + 1), dim3(256), 0, (hipStream_t)stream,
+                                         q_pe, q_out, latent, kv_buffer, loc, loc_is64, cos_sin_cache, positions, H,
+                                         kv_lora_rank, rope_dim, rotary_dim, qpe_stride_b, qpe_stride_h, qo_stride_b,
+                                         qo_stride_h, latent_stride_b, kv_stride_n, cos_sin_stride, is_neox));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -323,24 +323,48 @@ __global__ __launch_bounds__(256) void per_group_quant_kernel(const void* __rest
 }
 
 // ---- per tensor ----------------------------------------------------------------------------------------
-template <typename T>
+// x is a [rows, cols] view (row pitch xs, the columns consecutive), q likewise (row pitch qs); VEC: eight columns a
+// thread and step (cols, both pitches and both base addresses multiples of eight elements).
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void per_tensor_absmax_kernel(const void* __restrict__ x, float* __restrict__ scale,
-                                                                int64_t n) {
+                                                                int64_t rows, int64_t cols, int64_t xs) {
   __shared__ float red[4];
   float amax = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    amax = fmaxf(amax, fabsf(ld<T>(x, i)));
+  const int64_t per = VEC ? cols / 8 : cols, n = rows * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per, c = i - r * per;
+    if constexpr (VEC) {
+      float v[8];
+      load8<T>(x, r * xs + 8 * c, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+    } else {
+      amax = fmaxf(amax, fabsf(ld<T>(x, r * xs + c)));
+    }
+  }
   amax = block_max_256(amax, red);
   // non-negative floats order like their bit patterns
   if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(scale), __float_as_int(amax / kFp8Max));
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void per_tensor_quant_kernel(const void* __restrict__ x, uint8_t* __restrict__ q,
-                                                               const float* __restrict__ scale, int64_t n) {
+                                                               const float* __restrict__ scale, int64_t rows,
+                                                               int64_t cols, int64_t xs, int64_t qs) {
   const float inv = 1.0f / scale[0];
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    q[i] = cvt1(clamp_sym(ld<T>(x, i) * inv, -kFp8Max, kFp8Max));
+  const int64_t per = VEC ? cols / 8 : cols, n = rows * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per, c = i - r * per;
+    if constexpr (VEC) {
+      float v[8];
+      load8<T>(x, r * xs + 8 * c, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = clamp_sym(v[j] * inv, -kFp8Max, kFp8Max);
+      *reinterpret_cast<uint2*>(q + r * qs + 8 * c) = cvt8(v);
+    } else {
+      q[r * qs + c] = cvt1(clamp_sym(ld<T>(x, r * xs + c) * inv, -kFp8Max, kFp8Max));
+    }
+  }
 }
 
 // ---- scaled matmul -------------------------------------------------------------------------------------
@@ -887,19 +911,43 @@ int sglk_silu_and_mul_quant_fp8_partial(const float* partials, int splits, int64
   return SGLK_OK;
 }
 
-int sglk_per_tensor_quant_fp8(const void* x, void* q, float* scale, int64_t numel, int is_static, int dtype,
-                              void* stream) {
+int sglk_per_tensor_quant_fp8_rows(const void* x, void* q, float* scale, int64_t rows, int64_t cols, int64_t x_row_stride,
+                                   int64_t q_row_stride, int is_static, int dtype, void* stream) {
   SGLK_CHECK(x && q && scale, "per_tensor_quant_fp8: null pointer");
-  SGLK_CHECK(numel >= 0, "per_tensor_quant_fp8: negative size");
-  if (numel == 0) return SGLK_OK;
+  SGLK_CHECK(rows >= 0 && cols >= 0, "per_tensor_quant_fp8: negative size");
+  SGLK_CHECK(rows <= 1 || (x_row_stride >= cols && q_row_stride >= cols), "per_tensor_quant_fp8: row pitch below the row");
+  if (rows == 0 || cols == 0) return SGLK_OK;
   hipStream_t s = (hipStream_t)stream;
-  const unsigned blocks = (unsigned)std::min<int64_t>((numel + 255) / 256, 1024);
+  const int esz = dtype == SGLK_F32 ? 4 : 2;
+  const bool vec = cols % 8 == 0 && x_row_stride % 8 == 0 && q_row_stride % 8 == 0 && aligned16(x) &&
+                   (reinterpret_cast<uintptr_t>(q) & 7) == 0 && (esz == 2 || (reinterpret_cast<uintptr_t>(x) & 31) == 0);
+  const int64_t work = vec ? rows * (cols / 8) : rows * cols;
+  const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 2048);
+  // every block of the maximum pass ends in one atomic on the same word: few blocks, more elements a thread
+  const unsigned mblocks = std::min(blocks, 256u);
   SGLK_DISPATCH_FLOAT(dtype, T, {
-    if (!is_static) hipLaunchKernelGGL((per_tensor_absmax_kernel<T>), dim3(blocks), dim3(256), 0, s, x, scale, numel);
-    hipLaunchKernelGGL((per_tensor_quant_kernel<T>), dim3(blocks), dim3(256), 0, s, x, (uint8_t*)q, scale, numel);
+    if (vec) {
+      if (!is_static)
+        hipLaunchKernelGGL((per_tensor_absmax_kernel<T, true>), dim3(mblocks), dim3(256), 0, s, x, scale, rows, cols,
+                           x_row_stride);
+      hipLaunchKernelGGL((per_tensor_quant_kernel<T, true>), dim3(blocks), dim3(256), 0, s, x, (uint8_t*)q, scale, rows,
+                         cols, x_row_stride, q_row_stride);
+    } else {
+      if (!is_static)
+        hipLaunchKernelGGL((per_tensor_absmax_kernel<T, false>), dim3(mblocks), dim3(256), 0, s, x, scale, rows, cols,
+                           x_row_stride);
+      hipLaunchKernelGGL((per_tensor_quant_kernel<T, false>), dim3(blocks), dim3(256), 0, s, x, (uint8_t*)q, scale, rows,
+                         cols, x_row_stride, q_row_stride);
+    }
   });
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_per_tensor_quant_fp8(const void* x, void* q, float* scale, int64_t numel, int is_static, int dtype,
+                              void* stream) {
+  SGLK_CHECK(numel >= 0, "per_tensor_quant_fp8: negative size");
+  return sglk_per_tensor_quant_fp8_rows(x, q, scale, 1, numel, numel, numel, is_static, dtype, stream);
 }
 
 int sglk_fp8_scaled_mm(const void* a, const void* b_nk, const float* scales_a, const float* scales_b, const void* bias,

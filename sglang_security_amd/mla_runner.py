@@ -73,8 +73,9 @@ class BlockFp8Linear:
 
     def pack(self):
         """A second copy in the streaming layout of fp8_blockwise_scaled_mm_packed for the decode step (inner
-        dimensions of 4096 and more: shorter ones are faster on the row-major kernel)."""
-        if self.wpacked is None and self.N % 16 == 0 and self.K % 128 == 0 and self.K >= 4096:
+        dimensions of 4096 and more, or 1536 and more under a wide output (q_b): the rest is faster on the row-major
+        kernel)."""
+        if self.wpacked is None and self.N % 16 == 0 and self.K % 128 == 0 and (self.K >= 4096 or (self.K >= 1536 and self.N >= 16384)):
             self.wpacked = ops.fp8_repack(self.weight)
         return self
 
@@ -139,16 +140,18 @@ class DeepseekV3DenseDecoder:
         self.hidden = torch.zeros(B, c.hidden, dtype=dt, device=device)
         self.residual = torch.zeros(B, c.hidden, dtype=dt, device=device)
         self.q_input = torch.zeros(B, c.heads, self.lat, dtype=dt, device=device)
-        self.q_pe = torch.zeros(B, c.heads * c.qk_rope_head_dim, dtype=dt, device=device)
-        self.k_pe = torch.zeros(B, c.qk_rope_head_dim, dtype=dt, device=device)
-        self.k_input = torch.zeros(B, 1, self.lat, dtype=dt, device=device)
+        self.qkv_a = torch.zeros(B, c.q_lora_rank + self.lat, dtype=dt, device=device)
+        self.q_a = torch.zeros(B, c.q_lora_rank, dtype=dt, device=device)
+        self.q_b = torch.zeros(B, c.heads * self.qk_head_dim, dtype=dt, device=device)
+        self.attn_flat = torch.zeros(B, c.heads * c.v_head_dim, dtype=dt, device=device)
+        self.gate_up = torch.zeros(B, 2 * c.inter, dtype=dt, device=device)
         self.attn_out = torch.zeros(B, c.heads, c.kv_lora_rank, dtype=dt, device=device)
         self.act = torch.zeros(B, c.inter, dtype=dt, device=device)
         kmax = max(c.hidden, c.q_lora_rank, c.heads * c.v_head_dim, c.inter)
         self.x_q = torch.empty(B * kmax, dtype=F8, device=device)
         self.x_s = torch.empty(B * (kmax // 128), dtype=torch.float32, device=device)
         self.bq = torch.empty(c.heads * B * max(c.qk_nope_head_dim, c.kv_lora_rank), dtype=F8, device=device)
-        self.bs = torch.zeros(1, dtype=torch.float32, device=device)
+        self.bs = torch.zeros(2 * c.layers, dtype=torch.float32, device=device)   # one scale slot per bmm of the step
         ws = 256
         for K, N in ((c.hidden, c.q_lora_rank + self.lat), (c.q_lora_rank, c.heads * self.qk_head_dim),
                      (c.heads * c.v_head_dim, c.hidden), (c.hidden, 2 * c.inter), (c.inter, c.hidden)):
@@ -190,63 +193,59 @@ class DeepseekV3DenseDecoder:
         ops.per_token_group_quant_fp8(x2d, q, s, 128, 1e-10, -448.0, 448.0)
         return q, s
 
-    def _mm(self, x2d, w: BlockFp8Linear):
+    def _mm(self, x2d, w: BlockFp8Linear, out=None):
         q, s = self._quant(x2d)
         if w.wpacked is not None:
-            return ops.fp8_blockwise_scaled_mm_packed(q, w.wpacked, s, w.scale.t(), self.dtype, self.workspace)
-        return ops.fp8_blockwise_scaled_mm(q, w.weight.t(), s, w.scale.t(), self.dtype, self.workspace)
+            return ops.fp8_blockwise_scaled_mm_packed(q, w.wpacked, s, w.scale.t(), self.dtype, self.workspace, out)
+        return ops.fp8_blockwise_scaled_mm(q, w.weight.t(), s, w.scale.t(), self.dtype, self.workspace, out)
 
-    def _bmm(self, a_hmk, w_hnk, w_scale):
-        """[H, M, K] bf16 x [H, N, K] e4m3 -> [H, M, N]: per-tensor dynamic quantisation of a (per_tensor_quant_mla_fp8,
-        deepseek_v2.py:965-972), then bmm_fp8."""
-        H, M, K = a_hmk.shape
-        a = a_hmk.contiguous()
-        q = self.bq[: H * M * K].view(H, M, K)
-        self.bs.zero_()
-        ops.per_tensor_quant_fp8(a, q, self.bs, False)
-        return ops.bmm_fp8(q, w_hnk.transpose(1, 2), self.bs, w_scale, self.dtype)
+    def _bmm(self, a_bhk, w_hnk, w_scale, scale, out_hbn):
+        """a [B, H, K] bf16 (rows one pitch apart) x w [H, N, K] e4m3 -> out [H, B, N] (a view with any row pitch):
+        per-tensor dynamic quantisation of a (per_tensor_quant_mla_fp8, deepseek_v2.py:965-972) in the layout it
+        comes in, then bmm_fp8 over the transposed view; `scale` is this product's own zeroed scale slot."""
+        B, H, K = a_bhk.shape
+        q = self.bq[: B * H * K].view(B, H, K)
+        ops.per_tensor_quant_fp8_rows(a_bhk, q, scale, False)
+        return ops.bmm_fp8(q.transpose(0, 1), w_hnk.transpose(1, 2), scale, w_scale, self.dtype, out=out_hbn)
 
     def step(self, input_hidden=None):
         """One decode step of the layer stack: `hidden` holds the layers' input (the embedding rows of the new tokens)
-        on entry and the normalised output of the last layer on exit."""
+        on entry and the normalised output of the last layer on exit.  Every product writes where its consumer
+        reads: no copies between the launches."""
         c, B = self.cfg, self.B
         ops.prepare_for_decode(self.req_to_token, self.req_pool_indices, self.seq_lens, self.positions, self.out_cache_loc)
         ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
                             self.num_kv_splits, c.heads, 1, self.max_kv_splits, self.cu_count)
         if input_hidden is not None:
             self.hidden.copy_(input_hidden)
-        nope, rope_d, lat = c.qk_nope_head_dim, c.qk_rope_head_dim, c.kv_lora_rank
+        self.bs.zero_()                                                              # the running maxima of every bmm
+        nope, lat = c.qk_nope_head_dim, c.kv_lora_rank
+        attn_hbn = self.attn_flat.view(B, c.heads, c.v_head_dim).transpose(0, 1)    # [H, B, 128] over [B, H * 128]
         for li, L in enumerate(self.layers):
             if li == 0:
                 self.residual.copy_(self.hidden)
                 ops.rmsnorm(self.hidden, self.hidden, L["ln1"], c.eps)
             else:
                 ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln1"], c.eps)
-            qkv_a = self._mm(self.hidden, L["qkv_a"])                                   # [B, 1536 + 576]
-            q_a = qkv_a[:, : c.q_lora_rank]
-            ops.rmsnorm(q_a, q_a, L["q_a_ln"], c.eps)
+            qkv_a = self._mm(self.hidden, L["qkv_a"], self.qkv_a)                       # [B, 1536 + 576]
+            ops.rmsnorm(self.q_a, qkv_a[:, : c.q_lora_rank], L["q_a_ln"], c.eps)
             k_nope = qkv_a[:, c.q_lora_rank: c.q_lora_rank + lat]
             ops.rmsnorm(k_nope, k_nope, L["kv_a_ln"], c.eps)
-            q = self._mm(q_a.contiguous(), L["q_b"]).view(B, c.heads, self.qk_head_dim)
-            # absorbed key projection: q_nope [B, H, 128] . w_kc^T -> [B, H, 512]
-            q_nope_out = self._bmm(q[..., :nope].transpose(0, 1), L["w_kc"], L["w_scale"])  # [H, B, 512]
-            self.q_input[..., :lat].copy_(q_nope_out.transpose(0, 1))
-            self.q_pe.view(B, c.heads, rope_d).copy_(q[..., nope:])
-            self.k_pe.copy_(qkv_a[:, c.q_lora_rank + lat:])
-            ops.rope(self.q_pe, self.k_pe, self.cos_sin, self.positions, rope_d, interleave=True)
-            self.q_input[..., lat:].copy_(self.q_pe.view(B, c.heads, rope_d))
-            self.k_input[:, 0, :lat].copy_(k_nope)
-            self.k_input[:, 0, lat:].copy_(self.k_pe)
-            self.kv_pool[li].index_copy_(0, self.out_cache_loc, self.k_input)                # set_kv_buffer of the latent row
+            q = self._mm(self.q_a, L["q_b"], self.q_b).view(B, c.heads, self.qk_head_dim)
+            # absorbed key projection: q_nope [B, H, 128] . w_kc^T -> q_input[..., :512]
+            self._bmm(q[..., :nope], L["w_kc"], L["w_scale"], self.bs[2 * li: 2 * li + 1],
+                      self.q_input[..., :lat].transpose(0, 1))
+            # rope on q_pe / k_pe, q_input[..., 512:] = q_pe, the latent row [k_nope | k_pe] into the pool
             pool = self.kv_pool[li]
+            ops.mla_rope_and_store(q[..., nope:], self.q_input, qkv_a[:, c.q_lora_rank:], pool, self.out_cache_loc,
+                                   self.cos_sin, self.positions, lat, is_neox=False)
             ops.decode_attention_fwd(self.q_input, pool, pool[..., :lat], self.attn_out, self.kv_indptr, self.kv_indices,
                                      self.attn_logits, self.attn_lse, self.num_kv_splits, self.max_kv_splits, self.sm_scale)
-            # absorbed value projection: attn [B, H, 512] . w_vc^T -> [B, H, 128]
-            o_heads = self._bmm(self.attn_out.transpose(0, 1), L["w_vc"], L["w_scale"])    # [H, B, 128]
-            attn = o_heads.transpose(0, 1).reshape(B, c.heads * c.v_head_dim)
-            self.hidden.copy_(self._mm(attn, L["o"]))
+            # absorbed value projection: attn [B, H, 512] . w_vc^T -> [B, H * 128]
+            self._bmm(self.attn_out, L["w_vc"], L["w_scale"], self.bs[2 * li + 1: 2 * li + 2], attn_hbn)
+            self._mm(self.attn_flat, L["o"], self.hidden)
             ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln2"], c.eps)
-            gu = self._mm(self.hidden, L["gate_up"])
+            gu = self._mm(self.hidden, L["gate_up"], self.gate_up)
             ops.act_and_mul(self.act, gu, 0)
-            self.hidden.copy_(self._mm(self.act, L["down"]))
+            self._mm(self.act, L["down"], self.hidden)
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)

@@ -5,6 +5,7 @@ Function names and argument order follow the reference callers they replace (cit
 """
 from __future__ import annotations
 
+import math
 from typing import Optional
 
 import torch
@@ -648,6 +649,54 @@ def per_tensor_quant_fp8(x, out_q, out_s, is_static):
                                           dtype_code(x.dtype), _stream(x)), "per_tensor_quant_fp8")
 
 
+def per_tensor_quant_fp8_rows(x, out_q, out_s, is_static=False):
+    """per_tensor_quant_fp8 of a strided view: x [..., cols] whose leading dimensions collapse to rows one pitch apart
+    (e.g. q[..., :nope] of [B, H, nope + rope]), out_q the same shape with its own pitch; one scale for the view."""
+    _need_gpu(x, out_q, out_s)
+    cols = x.shape[-1]
+    rows = x.numel() // max(cols, 1)
+
+    def pitch(t):
+        if t.stride(-1) != 1 and cols > 1:
+            raise SglkError("per_tensor_quant_fp8_rows: the last dimension must be contiguous")
+        if t.dim() == 1:
+            return cols
+        st = t.stride(-2)
+        for d in range(t.dim() - 2):  # the leading dimensions must walk the rows at one pitch
+            if t.shape[d] > 1 and t.stride(d) != st * math.prod(t.shape[d + 1:-1]):
+                raise SglkError("per_tensor_quant_fp8_rows: rows must lie one pitch apart")
+        return st
+
+    if tuple(out_q.shape) != tuple(x.shape) or out_q.dtype != torch.float8_e4m3fn or out_s.dtype != torch.float32:
+        raise SglkError("per_tensor_quant_fp8_rows: out_q must be float8_e4m3fn of x's shape and out_s float32")
+    check(lib().sglk_per_tensor_quant_fp8_rows(_ptr(x), _ptr(out_q), _ptr(out_s), rows, cols, pitch(x), pitch(out_q),
+                                               1 if is_static else 0, dtype_code(x.dtype), _stream(x)),
+          "per_tensor_quant_fp8_rows")
+
+
+def mla_rope_and_store(q_pe, q_out, latent, kv_buffer, loc, cos_sin_cache, positions, kv_lora_rank, rotary_dim=None,
+                       is_neox=False):
+    """Rotary step + cache write of the absorbed-MLA decode (models/deepseek_v2.py:1127-1193) in one launch: q_pe
+    [B, H, rope] (any strides with a contiguous last dimension) rotated into q_out[..., kv_lora_rank:]; latent [B,
+    kv_lora_rank + rope] = [k_nope | unrotated k_pe] written to kv_buffer rows loc with the rope part rotated."""
+    _need_gpu(q_pe, q_out, latent, kv_buffer, loc, cos_sin_cache, positions)
+    B, H, rope_dim = q_pe.shape
+    kb = kv_buffer.view(kv_buffer.shape[0], -1)
+    if q_pe.stride(2) != 1 or q_out.stride(2) != 1 or latent.stride(1) != 1 or positions.dtype != torch.int64:
+        raise SglkError("mla_rope_and_store: last dimensions must be contiguous and positions int64")
+    if (q_out.shape[0] != B or q_out.shape[1] != H or q_out.shape[2] < kv_lora_rank + rope_dim or latent.shape[0] != B
+            or latent.shape[1] != kv_lora_rank + rope_dim or kb.shape[1] < kv_lora_rank + rope_dim or loc.numel() != B):
+        raise SglkError("mla_rope_and_store: shapes do not fit")
+    if not (q_pe.dtype == q_out.dtype == latent.dtype == kv_buffer.dtype) or cos_sin_cache.dtype != torch.float32:
+        raise SglkError("mla_rope_and_store: one element type for q, the latent row and the pool; fp32 cos / sin")
+    rd = rope_dim if rotary_dim is None else rotary_dim
+    check(lib().sglk_mla_rope_and_store(_ptr(q_pe), _ptr(q_out), _ptr(latent), _ptr(kb), _ptr(loc), _is64(loc),
+                                        _ptr(cos_sin_cache), _ptr(positions), B, H, kv_lora_rank, rope_dim, rd,
+                                        q_pe.stride(0), q_pe.stride(1), q_out.stride(0), q_out.stride(1), latent.stride(0),
+                                        kb.stride(0), cos_sin_cache.stride(0), 1 if is_neox else 0,
+                                        dtype_code(q_pe.dtype), _stream(q_pe)), "mla_rope_and_store")
+
+
 def _b_as_nk(mat_b, name):
     """The reference passes B as a column-major [K, N] view (mat_b.stride(0) == 1): the same memory as a
     row-major [N, K] matrix."""
@@ -753,7 +802,7 @@ def fp8_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype, bias=None
     return out
 
 
-def fp8_blockwise_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype, workspace=None):
+def fp8_blockwise_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype, workspace=None, out=None):
     """fp8_blockwise_scaled_mm on a weight from fp8_repack: mat_a [M, K] contiguous, packed [N, K], scales_a [M, K/128]
     (any strides), scales_b [K/128, N/128] as the reference passes it."""
     _need_gpu(mat_a, packed, scales_a, scales_b)
@@ -764,7 +813,7 @@ def fp8_blockwise_scaled_mm_packed(mat_a, packed, scales_a, scales_b, out_dtype,
         raise SglkError("fp8_blockwise_scaled_mm_packed: mat_a contiguous [M, K], packed a contiguous [N, K] from fp8_repack")
     if tuple(scales_a.shape) != (M, kb) or tuple(scales_b.shape) != (kb, nb):
         raise SglkError(f"fp8_blockwise_scaled_mm_packed: scales_a must be [{M},{kb}] and scales_b [{kb},{nb}]")
-    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    out = _mm_out(out, M, N, out_dtype, mat_a.device, "fp8_blockwise_scaled_mm_packed")
     check(lib().sglk_fp8_blockwise_scaled_mm_packed(
         _ptr(mat_a), _ptr(packed), _ptr(scales_a), _ptr(scales_b), _ptr(out), M, N, K, scales_a.stride(0), scales_a.stride(1),
         scales_b.stride(1), scales_b.stride(0), _ptr(workspace),
@@ -876,7 +925,16 @@ def topk_softmax(topk_weights, topk_ids, token_expert_indices, gating_output):
                                   _stream(gating_output)), "topk_softmax")
 
 
-def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, workspace=None):
+def _mm_out(out, M, N, out_dtype, device, name):
+    """The [M, N] result tensor of a product: a fresh one, or the caller's (an addition: contiguous, of the type)."""
+    if out is None:
+        return torch.empty((M, N), dtype=out_dtype, device=device)
+    if tuple(out.shape) != (M, N) or out.dtype != out_dtype or not out.is_contiguous() or out.device != device:
+        raise SglkError(f"{name}: out must be a contiguous [{M},{N}] {out_dtype} tensor on the operands' device")
+    return out
+
+
+def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, workspace=None, out=None):
     """fp8_blockwise_scaled_mm (sgl-kernel/python/sgl_kernel/gemm.py:36-45): scales_a [M, K/128] (any strides),
     scales_b [K/128, N/128] as the reference passes it (the transpose of the [N/128, K/128] checkpoint tensor)."""
     _need_gpu(mat_a, mat_b, scales_a, scales_b)
@@ -891,7 +949,7 @@ def fp8_blockwise_scaled_mm(mat_a, mat_b, scales_a, scales_b, out_dtype, workspa
     nb = (N + 127) // 128
     if tuple(scales_a.shape) != (M, kb) or tuple(scales_b.shape) != (kb, nb):
         raise SglkError(f"fp8_blockwise_scaled_mm: scales_a must be [{M},{kb}] and scales_b [{kb},{nb}]")
-    out = torch.empty((M, N), dtype=out_dtype, device=mat_a.device)
+    out = _mm_out(out, M, N, out_dtype, mat_a.device, "fp8_blockwise_scaled_mm")
     if workspace is not None:  # an addition: narrow outputs are split along K (fp8_mm_workspace_bytes)
         _need_gpu(workspace)
         check(lib().sglk_fp8_blockwise_scaled_mm_ws(_ptr(mat_a), _ptr(b), _ptr(scales_a), _ptr(scales_b), _ptr(out), M, N,

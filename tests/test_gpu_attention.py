@@ -438,3 +438,44 @@ def test_decode_attention_mla_fused_rope(dtype, neox, rotary_dim):
     want2 = oracle.decode_attention(q, kv, kv[..., :lora].contiguous(), ptr, ind, ns.cpu(), sm, 0.0)
     assert (o2.float().cpu() - want2).abs().max().item() < tol
     assert torch.equal(kv_d2.cpu(), kv)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("neox", [False, True])
+@pytest.mark.parametrize("B,H", [(5, 16), (64, 128), (1, 3)])
+def test_mla_rope_and_store(dtype, neox, B, H):
+    """The one-launch rotary step + cache write of the absorbed-MLA decode (models/deepseek_v2.py:1127-1193) writes
+    the bytes of the sequence it replaces: rope on copies of q_pe / k_pe (the rope kernel the golden rotary vectors
+    pin), q_input[..., lora:] = q_pe, the latent row [k_nope | k_pe] stored at the requests' slots."""
+    ops = _ops()
+    lora, nope, rope = 512, 128, 64
+    gen = torch.Generator().manual_seed(B * 7 + H)
+    q = (torch.randn(B, H, nope + rope, generator=gen) * 0.5).to(dtype).to(DEV)       # q_b's output: [nope | rope]
+    qkv_a = torch.randn(B, 96 + lora + rope, generator=gen).to(dtype).to(DEV)        # ... | k_nope | k_pe
+    slots = 3 * B + 2
+    pool = torch.randn(slots, 1, lora + rope, generator=gen).to(dtype).to(DEV)
+    loc = (torch.randperm(slots - 1, generator=gen)[:B] + 1).to(DEV)
+    positions = torch.randint(0, 200, (B,), generator=gen).to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, rope, 2).float() / rope))
+    fr = torch.einsum("i,j->ij", torch.arange(256).float(), inv)
+    cos_sin = torch.cat([fr.cos(), fr.sin()], dim=-1).to(DEV)
+    q_input = torch.randn(B, H, lora + rope, generator=gen).to(dtype).to(DEV)
+
+    q_pe = q[..., nope:].clone().reshape(B, H * rope)
+    k_pe = qkv_a[:, 96 + lora:].clone()
+    ops.rope(q_pe, k_pe, cos_sin, positions, rope, interleave=not neox)
+    want_q = q_input.clone()
+    want_q[..., lora:] = q_pe.view(B, H, rope)
+    want_pool = pool.clone()
+    want_pool[loc, 0, :lora] = qkv_a[:, 96: 96 + lora]
+    want_pool[loc, 0, lora:] = k_pe
+
+    for loc_t in (loc, loc.to(torch.int32)):
+        got_q, got_pool = q_input.clone(), pool.clone()
+        ops.mla_rope_and_store(q[..., nope:], got_q, qkv_a[:, 96:], got_pool, loc_t, cos_sin, positions, lora, is_neox=neox)
+        assert torch.equal(got_q, want_q)
+        assert torch.equal(got_pool, want_pool)
+    from sglang_security_amd import SglkError
+
+    with pytest.raises(SglkError):
+        ops.mla_rope_and_store(q[..., nope:], q_input[:, :, : lora + 8], qkv_a[:, 96:], pool, loc, cos_sin, positions, lora)

@@ -87,8 +87,8 @@ def test_per_token_group_quant_bitexact(rows, hidden, group, dtype, col_major):
     assert torch.equal(_u8(q), wq.view(torch.uint8))
 
 
-@pytest.mark.parametrize("n", [1, 1000, 256 * 1024 + 3])
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n", [1, 1000, 4096, 256 * 1024 + 3, 1024 * 1024])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 def test_per_tensor_quant(n, dtype):
     """sgl-kernel/tests/test_per_tensor_quant_fp8.py: dynamic scale = absmax / 448; static uses the given scale."""
     import oracle
@@ -107,6 +107,31 @@ def test_per_tensor_quant(n, dtype):
     s2 = torch.tensor([0.0625], device=DEV)
     ops.per_tensor_quant_fp8(x.to(DEV), q2, s2, True)
     assert torch.equal(_u8(q2), oracle.e4m3_encode((x.float() * 16.0).clamp(-448, 448)).view(torch.uint8))
+
+
+@pytest.mark.parametrize("shape,cols,off", [((64, 128, 192), 128, 0), ((5, 3, 40), 24, 8), ((7, 2, 33), 20, 13),
+                                            ((4, 16, 512), 512, 0)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_per_tensor_quant_rows(shape, cols, off, dtype):
+    """The strided form (a slice of the last dimension, rows one pitch apart; vector and scalar paths) gives the bytes
+    and the scale of per_tensor_quant_fp8 on a contiguous copy of the same view."""
+    ops = _ops()
+    torch.manual_seed(shape[0] + cols)
+    x = (torch.randn(shape) * 3).to(dtype).to(DEV)
+    view = x[..., off: off + cols]
+    want_q = torch.empty(view.shape, dtype=F8, device=DEV)
+    want_s = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.per_tensor_quant_fp8(view.contiguous(), want_q, want_s, False)
+    q = torch.empty(view.shape, dtype=F8, device=DEV)
+    s = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.per_tensor_quant_fp8_rows(view, q, s, False)
+    assert s.item() == want_s.item() and torch.equal(_u8(q), _u8(want_q))
+    # a padded output pitch, and the static form
+    wide = torch.zeros(shape[0], shape[1], cols + 16, dtype=torch.uint8, device=DEV).view(F8)
+    ops.per_tensor_quant_fp8_rows(view, wide[..., :cols], s, True)
+    assert torch.equal(_u8(wide[..., :cols]), _u8(want_q)) and int(_u8(wide[..., cols:]).max()) == 0
+    with pytest.raises(Exception):
+        ops.per_tensor_quant_fp8_rows(x.transpose(0, 1)[..., :cols], q.transpose(0, 1), s, False)
 
 
 def _fp8_rand(shape, g):
