@@ -611,7 +611,7 @@ __device__ __forceinline__ long hi64(int4v v) { return (long)(uint32_t)v.z | ((l
 // BW: the block-scaled form (DeepSeek): sa[m, kb] (strides sa_m, sa_k) and sb[n / 128, kb] (strides sb_n, sb_k) scale
 // every 128-k block's product before it is added up; the activation scales of a k-block travel with its tile, the
 // weight scale with the weight pieces.
-template <typename TO, int NS, int PF, bool BW = false>
+template <typename TO, int NS, int PF, bool BW = false, int XPF = PF>
 __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __restrict__ x, const uint8_t* __restrict__ wp,
                                                             const float* __restrict__ sa, const float* __restrict__ sb,
                                                             const void* __restrict__ bias, void* __restrict__ out,
@@ -629,12 +629,14 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
   const int nkb = min(kb_per_split, kblocks - kb0);
   const int n0 = (blockIdx.x * 4 + wid) * 16 * NS + i16;
 
-  // activations: thread (row xr, quarter xq) moves bytes [32 xq, 32 xq + 32) of its row, two k-blocks ahead
+  // activations: thread (row xr, quarter xq) moves bytes [32 xq, 32 xq + 32) of its row; a k-block's bytes are
+  // requested XPF blocks ahead and parked in LDS one block ahead (a step of the loop is shorter than the way to the
+  // L2 and back: a request made only a step before its use would set the pace)
   const int xr = threadIdx.x >> 2, xq = threadIdx.x & 3;
   const bool xrow_ok = (m0 + xr) < M;
   const uint8_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
-  int4v xreg[2][2];
-  [[maybe_unused]] float sareg[2] = {0.f, 0.f};
+  int4v xreg[XPF][2];
+  [[maybe_unused]] float sareg[XPF] = {};
   auto x_fetch = [&](int4v(&r2)[2], int kb, [[maybe_unused]] float& sr) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -669,8 +671,8 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) wq[p][s][h] = wload(wsrc[s] + 2048 * p + 1024 * h);
-        if constexpr (BW) wsc[p][s] = sbrow[s][(int64_t)p * sb_k];
+        for (int h = 0; h < 2; ++h) wq[p % PF][s][h] = wload(wsrc[s] + 2048 * p + 1024 * h);
+        if constexpr (BW) wsc[p % PF][s] = sbrow[s][(int64_t)p * sb_k];
       }
     }
 
@@ -680,20 +682,23 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) oacc[s][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  static_assert(PF % 2 == 0, "the activation registers alternate with the parity of the k-block");
-  x_fetch(xreg[0], kb0, sareg[0]);
-  if (nkb > 1) x_fetch(xreg[1], kb0 + 1, sareg[1]);
+  constexpr int U = PF > XPF ? PF : XPF;  // the loop is unrolled so that register slots are compile-time
+  static_assert(PF % 2 == 0 && XPF % 2 == 0 && U % PF == 0 && U % XPF == 0,
+                "the LDS tiles alternate with the parity of the k-block");
+#pragma unroll
+  for (int p = 0; p < XPF; ++p)
+    if (p < nkb) x_fetch(xreg[p], kb0 + p, sareg[p]);
   x_park(xreg[0], 0, sareg[0]);
   __syncthreads();
 
-  for (int base = 0; base < nkb; base += PF) {
+  for (int base = 0; base < nkb; base += U) {
 #pragma unroll
-    for (int p = 0; p < PF; ++p) {
+    for (int p = 0; p < U; ++p) {  // block j: weight slot j % PF = p % PF, activation slot p % XPF
       const int j = base + p;
       if (j < nkb) {
         const int buf = j & 1;
         // block j's own registers were parked a step ago
-        if (j + 2 < nkb) x_fetch(xreg[p & 1], kb0 + j + 2, sareg[p & 1]);
+        if (j + XPF < nkb) x_fetch(xreg[p % XPF], kb0 + j + XPF, sareg[p % XPF]);
         if constexpr (BW) {
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
@@ -703,12 +708,12 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
               f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-              acc = mma_f8<0>(lo64(af0), lo64(wq[p][s][0]), acc);
-              acc = mma_f8<0>(hi64(af0), hi64(wq[p][s][0]), acc);
-              acc = mma_f8<0>(lo64(af1), lo64(wq[p][s][1]), acc);
-              acc = mma_f8<0>(hi64(af1), hi64(wq[p][s][1]), acc);
+              acc = mma_f8<0>(lo64(af0), lo64(wq[p % PF][s][0]), acc);
+              acc = mma_f8<0>(hi64(af0), hi64(wq[p % PF][s][0]), acc);
+              acc = mma_f8<0>(lo64(af1), lo64(wq[p % PF][s][1]), acc);
+              acc = mma_f8<0>(hi64(af1), hi64(wq[p % PF][s][1]), acc);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) oacc[s][mt][r] += acc[r] * (as4[r] * wsc[p][s]);
+              for (int r = 0; r < 4; ++r) oacc[s][mt][r] += acc[r] * (as4[r] * wsc[p % PF][s]);
             }
           }
         } else {
@@ -719,8 +724,8 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
               const int4v af = *reinterpret_cast<const int4v*>(xs + buf * 8192 + fs_off(16 * mt + i16, 2 * g + h));
 #pragma unroll
               for (int s = 0; s < NS; ++s) {
-                oacc[s][mt] = mma_f8<0>(lo64(af), lo64(wq[p][s][h]), oacc[s][mt]);
-                oacc[s][mt] = mma_f8<0>(hi64(af), hi64(wq[p][s][h]), oacc[s][mt]);
+                oacc[s][mt] = mma_f8<0>(lo64(af), lo64(wq[p % PF][s][h]), oacc[s][mt]);
+                oacc[s][mt] = mma_f8<0>(hi64(af), hi64(wq[p % PF][s][h]), oacc[s][mt]);
               }
             }
         }
@@ -728,11 +733,11 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
 #pragma unroll
           for (int s = 0; s < NS; ++s) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) wq[p][s][h] = wload(wsrc[s] + 2048 * (int64_t)(j + PF) + 1024 * h);
-            if constexpr (BW) wsc[p][s] = sbrow[s][(int64_t)(j + PF) * sb_k];
+            for (int h = 0; h < 2; ++h) wq[p % PF][s][h] = wload(wsrc[s] + 2048 * (int64_t)(j + PF) + 1024 * h);
+            if constexpr (BW) wsc[p % PF][s] = sbrow[s][(int64_t)(j + PF) * sb_k];
           }
         }
-        if (j + 1 < nkb) x_park(xreg[(p + 1) & 1], buf ^ 1, sareg[(p + 1) & 1]);
+        if (j + 1 < nkb) x_park(xreg[(p + 1) % XPF], buf ^ 1, sareg[(p + 1) % XPF]);
         __syncthreads();
       }
     }
@@ -1049,7 +1054,8 @@ int sglk_fp8_blockwise_scaled_mm_packed(const void* a, const void* packed, const
   float* partial = used > 1 ? (float*)workspace : nullptr;
   hipStream_t s = (hipStream_t)stream;
   SGLK_DISPATCH_HALF(out_dtype, TO, {
-    hipLaunchKernelGGL((fp8_stream_kernel<TO, 1, 4, true>), dim3((N + 63) / 64, used, (M + 63) / 64), dim3(256), 0, s,
+    // block-scaled: the scaling holds more registers; the deeper activation request does not pay here (measured)
+    hipLaunchKernelGGL((fp8_stream_kernel<TO, 1, 4, true, 2>), dim3((N + 63) / 64, used, (M + 63) / 64), dim3(256), 0, s,
                        (const uint8_t*)a, (const uint8_t*)packed, scales_a, scales_b, (const void*)nullptr, out, partial, M,
                        N, K, per, (int64_t)K, (int64_t)N, sa_stride_m, sa_stride_k, sb_stride_n, sb_stride_k);
     if (used > 1) {
