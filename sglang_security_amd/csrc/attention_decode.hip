@@ -453,18 +453,19 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
 static constexpr int kMlaD = 576, kMlaDv = 512;
 static constexpr int kMlaPitch = kMlaD * 2 + 16;
 static constexpr int kMlaTileBytes = kTile * kMlaPitch;  // 37376
-static constexpr int kMlaScoreBytes = 4 * 2 * 64 * 16;   // four waves' partial score tiles
-static constexpr int kMlaLds = kMlaTileBytes + kMlaScoreBytes;
+static constexpr int kMlaScoreBytes = 4 * 2 * 64 * 16;   // four waves' partial score tiles, per tile of 16 heads
 
-template <typename T>
-__global__ void __launch_bounds__(256, 3) decode_stage1_mla(
+// HT: tiles of 16 query heads per block (2 where the group has 32 heads or more: a latent tile in LDS and every
+// operand read out of it then serve twice the heads).
+template <typename T, int HT>
+__global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
     const void* __restrict__ q, const void* __restrict__ kv_buffer, const int32_t* __restrict__ kv_indptr,
     const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits, float* __restrict__ attn_lse,
     const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, float sm_scale, float logit_cap) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* tile = lds;
-  float4v* sbuf = reinterpret_cast<float4v*>(lds + kMlaTileBytes);
+  float4v* sbuf = reinterpret_cast<float4v*>(lds + kMlaTileBytes);  // [HT][4 waves][2 halves][64 lanes]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int hl = lane & 15, g = lane >> 4;
   const int b = blockIdx.x;
@@ -477,104 +478,122 @@ __global__ void __launch_bounds__(256, 3) decode_stage1_mla(
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
   const int s0 = per_split * split, s1 = min(s0 + per_split, len);
   if (s1 <= s0) return;  // block-uniform
-  const int head_in_group = ht * 16 + hl;
-  const bool head_ok = head_in_group < group;
-  const int head = kvh * group + head_in_group;
+  bool head_ok[HT];
+  int head[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const int head_in_group = (ht * HT + t) * 16 + hl;
+    head_ok[t] = head_in_group < group;
+    head[t] = kvh * group + head_in_group;
+  }
 
   // Q^T operand of this wave's k-steps wid, wid + 4, ...: lane (hl, g) holds q[head][32*ks + 8*g .. +8)
   constexpr int kSteps = kMlaD / 32;  // 18
-  short8 qf[5];
-  {
-    const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h;
+  short8 qf[HT][5];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head[t] * q_stride_h;
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       const int ks = wid + 4 * i;
-      if (head_ok && ks < kSteps)
-        qf[i] = *reinterpret_cast<const short8*>(qp + 32 * ks + 8 * g);
+      if (head_ok[t] && ks < kSteps)
+        qf[t][i] = *reinterpret_cast<const short8*>(qp + 32 * ks + 8 * g);
       else
-        qf[i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+        qf[t][i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
     }
   }
   const float LOG2E = 1.4426950408889634f;
   const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
-  float m = -INFINITY, lsum = 0.f;
-  float4v oacc[8];
+  float m[HT], lsum[HT];
+  float4v oacc[HT][8];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) oacc[n] = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < HT; ++t) {
+    m[t] = -INFINITY, lsum[t] = 0.f;
+#pragma unroll
+    for (int n = 0; n < 8; ++n) oacc[t][n] = float4v{0.f, 0.f, 0.f, 0.f};
+  }
 
   // tile fetch: eight threads per row, thread (row, sub) takes 16-byte pieces sub, sub + 8, ..., sub + 64
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(kv_buffer) + (int64_t)kvh * k_stride_h;
   const int32_t* idx = kv_indices + start;
   const int frow = threadIdx.x >> 3, fsub = threadIdx.x & 7;
-  int4v kreg[9];
-  auto fetch = [&](int t0) {
+  // FD tiles are in flight (registers) while one is multiplied (two measured no faster than one: the step is
+  // not bound by the way to the rows and back)
+  constexpr int FD = 1;
+  int4v kreg[FD][9];
+  auto fetch = [&](int4v(&kr)[9], int t0) {
     int tok = t0 + frow;
     tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
     const uint16_t* row = kbase + (int64_t)idx[tok] * k_stride_n + fsub * 8;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) kreg[j] = *reinterpret_cast<const int4v*>(row + 64 * j);
+    for (int j = 0; j < 9; ++j) kr[j] = *reinterpret_cast<const int4v*>(row + 64 * j);
   };
-  auto park = [&]() {
+  auto park = [&](const int4v(&kr)[9]) {
 #pragma unroll
-    for (int j = 0; j < 9; ++j) *reinterpret_cast<int4v*>(tile + frow * kMlaPitch + (fsub + 8 * j) * 16) = kreg[j];
+    for (int j = 0; j < 9; ++j) *reinterpret_cast<int4v*>(tile + frow * kMlaPitch + (fsub + 8 * j) * 16) = kr[j];
   };
 
-  fetch(s0);
-  for (int t0 = s0; t0 < s1; t0 += kTile) {
+  auto step = [&](int4v(&kr)[9], int t0) {
     __syncthreads();  // every wave is done with the previous tile
-    park();
+    park(kr);
     __syncthreads();
-    if (t0 + kTile < s1) fetch(t0 + kTile);  // next tile's rows fly while this one is multiplied
-    // ---- this wave's share of S^T = K . Q^T
-    float4v sacc[2];
+    if (t0 + FD * kTile < s1) fetch(kr, t0 + FD * kTile);  // later tiles' rows fly while this one is multiplied
+    // ---- this wave's share of S^T = K . Q^T: a K operand read serves every head tile
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      sacc[hh] = float4v{0.f, 0.f, 0.f, 0.f};
+      float4v sacc[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) sacc[t] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
         const int ks = wid + 4 * i;
         if (ks < kSteps) {  // wave-uniform
           const short8 kf = *reinterpret_cast<const short8*>(tile + (16 * hh + hl) * kMlaPitch + (4 * ks + g) * 16);
-          sacc[hh] = Mfma16<T>::mma(kf, qf[i], sacc[hh]);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) sacc[t] = Mfma16<T>::mma(kf, qf[t][i], sacc[t]);
         }
       }
-      sbuf[(wid * 2 + hh) * 64 + lane] = sacc[hh];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) sbuf[((t * 4 + wid) * 2 + hh) * 64 + lane] = sacc[t];
     }
     __syncthreads();
     // ---- full scores (same sum order in every wave), scale / cap / mask, online softmax (exp2 domain)
-    float sv[8];
-    float tmax = -INFINITY;
+    short8 pf[HT];  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float4v tot = sbuf[hh * 64 + lane];
+    for (int t = 0; t < HT; ++t) {
+      float sv[8];
+      float tmax = -INFINITY;
 #pragma unroll
-      for (int w = 1; w < 4; ++w) tot += sbuf[(w * 2 + hh) * 64 + lane];
+      for (int hh = 0; hh < 2; ++hh) {
+        float4v tot = sbuf[((t * 4) * 2 + hh) * 64 + lane];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float sc = tot[r] * qk_scale;
-        if (logit_cap > 0.f) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
-        const int tok = t0 + 16 * hh + 4 * g + r;
-        sc = tok < s1 ? sc : -INFINITY;
-        sv[hh * 4 + r] = sc;
-        tmax = fmaxf(tmax, sc);
+        for (int w = 1; w < 4; ++w) tot += sbuf[((t * 4 + w) * 2 + hh) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = tot[r] * qk_scale;
+          if (logit_cap > 0.f) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
+          const int tok = t0 + 16 * hh + 4 * g + r;
+          sc = tok < s1 ? sc : -INFINITY;
+          sv[hh * 4 + r] = sc;
+          tmax = fmaxf(tmax, sc);
+        }
       }
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m, tmax);  // finite: token t0 of this tile is always valid
-    const float alpha = exp2f(m - m_new);
-    m = m_new;
-    float psum = 0.f;
-    short8 pf;  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m[t], tmax);  // finite: token t0 of this tile is always valid
+      const float alpha = exp2f(m[t] - m_new);
+      m[t] = m_new;
+      float psum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float p = exp2f(sv[j] - m_new);
-      psum += p;
-      pf[j] = (short)Conv<T>::from_f32(p);
-    }
-    lsum = lsum * alpha + psum;
+      for (int j = 0; j < 8; ++j) {
+        const float p = exp2f(sv[j] - m_new);
+        psum += p;
+        pf[t][j] = (short)Conv<T>::from_f32(p);
+      }
+      lsum[t] = lsum[t] * alpha + psum;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) oacc[n] *= alpha;
+      for (int n = 0; n < 8; ++n) oacc[t][n] *= alpha;
+    }
     // ---- O^T += V^T . P^T over this wave's 128 output elements, V read transposed out of the K rows
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
@@ -582,19 +601,33 @@ __global__ void __launch_bounds__(256, 3) decode_stage1_mla(
       const short4v lo = lds_read_tr16(tile + (4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
       const short4v hi = lds_read_tr16(tile + (16 + 4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
       const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      oacc[n] = Mfma16<T>::mma(vf, pf, oacc[n]);
+#pragma unroll
+      for (int t = 0; t < HT; ++t) oacc[t][n] = Mfma16<T>::mma(vf, pf[t], oacc[t][n]);
     }
+  };
+
+#pragma unroll
+  for (int f = 0; f < FD; ++f)
+    if (s0 + f * kTile < s1) fetch(kreg[f], s0 + f * kTile);
+  for (int t0 = s0; t0 < s1; t0 += FD * kTile) {
+#pragma unroll
+    for (int f = 0; f < FD; ++f)
+      if (t0 + f * kTile < s1) step(kreg[f], t0 + f * kTile);  // block-uniform
   }
 
-  lsum += __shfl_xor(lsum, 16, 64);
-  lsum += __shfl_xor(lsum, 32, 64);
-  if (head_ok) {
-    const float inv = 1.0f / lsum;
-    const int64_t ob = ((int64_t)b * Hq + head) * max_kv_splits + split;
-    float* dst = attn_logits + ob * kMlaDv + 128 * wid;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[n] * inv;
-    if (wid == 0 && g == 0) attn_lse[ob] = (m + log2f(lsum)) * 0.6931471805599453f;
+  for (int t = 0; t < HT; ++t) {
+    float ls = lsum[t];
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    if (head_ok[t]) {
+      const float inv = 1.0f / ls;
+      const int64_t ob = ((int64_t)b * Hq + head[t]) * max_kv_splits + split;
+      float* dst = attn_logits + ob * kMlaDv + 128 * wid;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[t][n] * inv;
+      if (wid == 0 && g == 0) attn_lse[ob] = (m[t] + log2f(ls)) * 0.6931471805599453f;
+    }
   }
 }
 
@@ -1030,12 +1063,23 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
       });
     });
   } else if (mla) {
-    const int head_tiles = (group + 15) / 16;
-    dim3 grid(B, Hkv * head_tiles, max_kv_splits);
-    SGLK_DISPATCH_HALF(dtype, T,
-                       hipLaunchKernelGGL((decode_stage1_mla<T>), grid, dim3(256), kMlaLds, s, q, k_buffer, kv_indptr,
-                                          kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv,
-                                          head_tiles, q_stride_b, q_stride_h, k_stride_n, k_stride_h, sm_scale, logit_cap));
+    if (group >= 32) {  // two tiles of 16 heads per block
+      const int head_tiles = (group + 31) / 32;
+      dim3 grid(B, Hkv * head_tiles, max_kv_splits);
+      SGLK_DISPATCH_HALF(dtype, T,
+                         hipLaunchKernelGGL((decode_stage1_mla<T, 2>), grid, dim3(256), kMlaTileBytes + 2 * kMlaScoreBytes,
+                                            s, q, k_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                                            max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
+                                            k_stride_h, sm_scale, logit_cap));
+    } else {
+      const int head_tiles = (group + 15) / 16;
+      dim3 grid(B, Hkv * head_tiles, max_kv_splits);
+      SGLK_DISPATCH_HALF(dtype, T,
+                         hipLaunchKernelGGL((decode_stage1_mla<T, 1>), grid, dim3(256), kMlaTileBytes + kMlaScoreBytes, s,
+                                            q, k_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                                            max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
+                                            k_stride_h, sm_scale, logit_cap));
+    }
   } else if (fast) {
     const int head_tiles = (group + 15) / 16;
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);

@@ -254,7 +254,7 @@ def test_decode_attention_head64_pairs_vs_oracle(dtype, B, Hq, Hkv, prefix, max_
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Hq,max_len,max_splits,cap", [(3, 16, 70, 4, 0.0), (4, 128, 500, 8, 0.0), (2, 24, 1300, 16, 30.0),
-                                                        (5, 16, 31, 2, 0.0)])
+                                                        (5, 16, 31, 2, 0.0), (2, 40, 200, 4, 0.0), (3, 48, 333, 8, 20.0)])
 def test_decode_attention_mla(dtype, B, Hq, max_len, max_splits, cap):
     """Absorbed-MLA decode (memory_pool.py:492-521: one latent row of 576 per token, values = a view of its first
     512 elements) on the matrix-core kernel, against the C oracle and against the generic kernel (which a separate
