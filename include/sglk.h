@@ -576,6 +576,15 @@ SGLK_API int sglk_rmsnorm_quant_fp8(const void* x, void* residual, const void* w
                                     int dtype, void* stream);
 SGLK_API int sglk_silu_and_mul_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int d,
                                          int dtype, void* stream);
+/* The same two fusions with per (token, 128-element group) scales (sgl_per_token_group_quant_fp8,
+ * sgl-kernel/csrc/gemm/per_token_group_quant_8bit.cu:96-197, group 128, eps 1e-10, +-448): what the block-fp8 linear
+ * method quantises its input with (python/sglang/srt/layers/quantization/fp8_utils.py:190-197) folded into the norm /
+ * activation in front of it.  scales [rows, hidden / 128] row-major; x rows x_row_stride elements apart. */
+SGLK_API int sglk_rmsnorm_group_quant_fp8(const void* x, void* residual, const void* weight, void* q, float* scales,
+                                          int64_t rows, int hidden, int64_t x_row_stride, float eps, int gemma,
+                                          int dtype, void* stream);
+SGLK_API int sglk_silu_and_mul_group_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int d,
+                                               int dtype, void* stream);
 /* The same product with a scratch buffer (sglk_fp8_mm_workspace_bytes(), contents don't matter): narrow outputs
  * (N = 1280 of a TP = 8 qkv shard gives 40 blocks) are split along K, fp32 partials summed in split order and scaled
  * by a second launch.  Falls back to the form above when the workspace is missing or too small. */

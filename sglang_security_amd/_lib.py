@@ -101,6 +101,8 @@ _SIGS = {
     "sglk_fp8_blockwise_scaled_mm": (i32, [p, p, p, p, p, i32, i32, i32, i64, i64, i64, i64, i32, p]),
     "sglk_rmsnorm_quant_fp8": (i32, [p, p, p, p, p, i64, i32, f32, i32, i32, p]),
     "sglk_silu_and_mul_quant_fp8": (i32, [p, p, p, i64, i32, i32, p]),
+    "sglk_rmsnorm_group_quant_fp8": (i32, [p, p, p, p, p, i64, i32, i64, f32, i32, i32, p]),
+    "sglk_silu_and_mul_group_quant_fp8": (i32, [p, p, p, i64, i32, i32, p]),
     "sglk_fp8_mm_workspace_bytes": (i64, [i32, i32, i32]),
     "sglk_fp8_scaled_mm_ws": (i32, [p, p, p, p, p, p, i32, i32, i32, i64, i64, i64, p, i64, i32, p]),
     "sglk_fp8_repack": (i32, [p, p, i32, i32, i64, p]),

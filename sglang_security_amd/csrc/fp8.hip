@@ -121,16 +121,37 @@ __device__ __forceinline__ float block_max_1024(float v, float* red) {
   return t;
 }
 
+// per (token, 128-element group) scales, as sgl_per_token_group_quant_fp8 forms them (scale = max(eps, amax) / 448,
+// q = clamp(y / scale)): a group is sixteen consecutive 8-element vectors, i.e. sixteen consecutive lanes of a wave
+// (vector v of thread t: v = t + 1024 it, and 1024 is a multiple of 16), all of them live when the row length is a
+// multiple of 128
+constexpr float kGroupEps = 1e-10f;
+__device__ __forceinline__ void group_quant_store(const float (&y)[8], uint8_t* q, float* scales, int64_t row, int len,
+                                                  int v) {
+  float amax = kGroupEps;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(y[j]));
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 16));
+  const float ys = amax / kFp8Max;
+  if ((v & 15) == 0) scales[row * (len >> 7) + (v >> 4)] = ys;
+  float o8[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o8[j] = clamp_sym(y[j] / ys, -kFp8Max, kFp8Max);
+  *reinterpret_cast<uint2*>(q + row * len + 8 * v) = cvt8(o8);
+}
+
 // residual += x (when given), y = round(rmsnorm(residual) * w), then per-token quantisation of y:
 // fused_add_rmsnorm (norm.cu) followed by sgl_per_token_quant_fp8 (per_token_quant_fp8.cu) with the same roundings
-template <typename T>
+// GROUP: per (token, 128-group) scales instead (sgl_per_token_group_quant_fp8), scales [rows, hidden / 128]
+template <typename T, bool GROUP = false>
 __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restrict__ xin, void* __restrict__ residual,
                                                              const void* __restrict__ w, uint8_t* __restrict__ q,
                                                              float* __restrict__ scales, int hidden, float eps, int gemma,
                                                              const float* __restrict__ partials, int splits,
                                                              int64_t part_stride, const float* __restrict__ row_scale,
                                                              const float* __restrict__ col_scale,
-                                                             const void* __restrict__ bias) {
+                                                             const void* __restrict__ bias, int64_t x_stride) {
   // partials: the input row arrives as the raw split sums of the preceding fp8 product, partials[s][row][:], and is
   // formed here as that product's own split sum forms it: round_T(sum * row_scale[row] * col_scale[n] + bias[n]).
   // row_scale may be the very array `scales` (the product's activation scales, replaced by this kernel's own): it is
@@ -139,7 +160,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restr
   const int64_t row = blockIdx.x;
   const float rsc = (partials && row_scale) ? row_scale[row] : 1.f;
   const uint16_t* bsrc = reinterpret_cast<const uint16_t*>(bias);
-  const uint16_t* x = reinterpret_cast<const uint16_t*>(xin) + row * hidden;
+  const uint16_t* x = reinterpret_cast<const uint16_t*>(xin) + row * x_stride;
   uint16_t* res = residual ? reinterpret_cast<uint16_t*>(residual) + row * hidden : nullptr;
   const uint16_t* wr = reinterpret_cast<const uint16_t*>(w);
   const int nvec = hidden >> 3;
@@ -192,8 +213,10 @@ __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restr
         keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32((keep[it][j] * inv) * wf));  // the value rmsnorm stores
         amax = fmaxf(amax, fabsf(keep[it][j]));
       }
+      if constexpr (GROUP) group_quant_store(keep[it], q, scales, row, hidden, v);
     }
   }
+  if constexpr (GROUP) return;
   amax = block_max_1024(amax, red);
   const float scale = amax / kFp8Max;
   if (threadIdx.x == 0) scales[row] = scale;
@@ -212,7 +235,7 @@ __global__ __launch_bounds__(1024) void rmsnorm_quant_kernel(const void* __restr
 
 // y = round(round(silu(gate)) * up) per element of x = [gate | up], then per-token quantisation of y:
 // silu_and_mul (activation.cu:22-50) followed by sgl_per_token_quant_fp8
-template <typename T>
+template <typename T, bool GROUP = false>
 __global__ __launch_bounds__(1024) void silu_mul_quant_kernel(const void* __restrict__ xin, uint8_t* __restrict__ q,
                                                               float* __restrict__ scales, int d,
                                                               const float* __restrict__ partials, int splits,
@@ -259,8 +282,10 @@ __global__ __launch_bounds__(1024) void silu_mul_quant_kernel(const void* __rest
         keep[it][j] = Conv<T>::to_f32(Conv<T>::from_f32(sv * ua[j]));
         amax = fmaxf(amax, fabsf(keep[it][j]));
       }
+      if constexpr (GROUP) group_quant_store(keep[it], q, scales, row, d, v);
     }
   }
+  if constexpr (GROUP) return;
   amax = block_max_1024(amax, red);
   const float scale = amax / kFp8Max;
   if (threadIdx.x == 0) scales[row] = scale;
@@ -857,7 +882,40 @@ int sglk_rmsnorm_quant_fp8(const void* x, void* residual, const void* weight, vo
                      hipLaunchKernelGGL((rmsnorm_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
                                         x, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma,
                                         (const float*)nullptr, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
-                                        (const void*)nullptr));
+                                        (const void*)nullptr, (int64_t)hidden));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_rmsnorm_group_quant_fp8(const void* x, void* residual, const void* weight, void* q, float* scales, int64_t rows,
+                                 int hidden, int64_t x_row_stride, float eps, int gemma, int dtype, void* stream) {
+  SGLK_CHECK(x && weight && q && scales, "rmsnorm_group_quant_fp8: null pointer");
+  SGLK_CHECK(rows >= 0 && hidden > 0, "rmsnorm_group_quant_fp8: bad shape");
+  SGLK_CHECK(hidden % 128 == 0 && hidden <= 4 * 1024 * 8,
+             "rmsnorm_group_quant_fp8: hidden=%d must be a multiple of 128, at most 32768", hidden);
+  SGLK_CHECK(x_row_stride >= hidden && x_row_stride % 8 == 0, "rmsnorm_group_quant_fp8: bad row pitch");
+  SGLK_CHECK(aligned16(x) && aligned16(weight) && (!residual || aligned16(residual)) && ((uintptr_t)q & 7) == 0,
+             "rmsnorm_group_quant_fp8: tensors must be 16-byte aligned");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((rmsnorm_quant_kernel<T, true>), dim3((unsigned)rows), dim3(1024), 0,
+                                        (hipStream_t)stream, x, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma,
+                                        (const float*)nullptr, 0, (int64_t)0, (const float*)nullptr, (const float*)nullptr,
+                                        (const void*)nullptr, x_row_stride));
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_silu_and_mul_group_quant_fp8(const void* x, void* q, float* scales, int64_t rows, int d, int dtype, void* stream) {
+  SGLK_CHECK(x && q && scales, "silu_and_mul_group_quant_fp8: null pointer");
+  SGLK_CHECK(rows >= 0 && d > 0 && d % 128 == 0 && d <= 4 * 1024 * 8,
+             "silu_and_mul_group_quant_fp8: d=%d must be a multiple of 128, at most 32768", d);
+  SGLK_CHECK(aligned16(x) && ((uintptr_t)q & 7) == 0, "silu_and_mul_group_quant_fp8: tensors must be 16-byte aligned");
+  if (rows == 0) return SGLK_OK;
+  SGLK_DISPATCH_HALF(dtype, T,
+                     hipLaunchKernelGGL((silu_mul_quant_kernel<T, true>), dim3((unsigned)rows), dim3(1024), 0,
+                                        (hipStream_t)stream, x, (uint8_t*)q, scales, d, (const float*)nullptr, 0, (int64_t)0,
+                                        (const float*)nullptr, (const float*)nullptr));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
@@ -878,7 +936,7 @@ int sglk_rmsnorm_quant_fp8_partial(const float* partials, int splits, int64_t pa
   SGLK_DISPATCH_HALF(dtype, T,
                      hipLaunchKernelGGL((rmsnorm_quant_kernel<T>), dim3((unsigned)rows), dim3(1024), 0, (hipStream_t)stream,
                                         (const void*)nullptr, residual, weight, (uint8_t*)q, scales, hidden, eps, gemma,
-                                        partials, splits, part_stride, row_scale, col_scale, bias));
+                                        partials, splits, part_stride, row_scale, col_scale, bias, (int64_t)hidden));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -193,8 +193,12 @@ class DeepseekV3DenseDecoder:
         ops.per_token_group_quant_fp8(x2d, q, s, 128, 1e-10, -448.0, 448.0)
         return q, s
 
-    def _mm(self, x2d, w: BlockFp8Linear, out=None):
-        q, s = self._quant(x2d)
+    def _qbuf(self, M, K):
+        return self.x_q[: M * K].view(M, K), self.x_s[: M * (K // 128)].view(M, K // 128)
+
+    def _mm(self, x2d, w: BlockFp8Linear, out=None, quantised=None):
+        """quantised: (q, s) when the producer of x2d already left its group-quantised form behind."""
+        q, s = self._quant(x2d) if quantised is None else quantised
         if w.wpacked is not None:
             return ops.fp8_blockwise_scaled_mm_packed(q, w.wpacked, s, w.scale.t(), self.dtype, self.workspace, out)
         return ops.fp8_blockwise_scaled_mm(q, w.weight.t(), s, w.scale.t(), self.dtype, self.workspace, out)
@@ -222,16 +226,20 @@ class DeepseekV3DenseDecoder:
         nope, lat = c.qk_nope_head_dim, c.kv_lora_rank
         attn_hbn = self.attn_flat.view(B, c.heads, c.v_head_dim).transpose(0, 1)    # [H, B, 128] over [B, H * 128]
         for li, L in enumerate(self.layers):
+            # the norms and the activation leave the group-quantised input of the product behind them (the 16-bit
+            # rows in between are formed and rounded in registers only)
+            xq = self._qbuf(B, c.hidden)
             if li == 0:
                 self.residual.copy_(self.hidden)
-                ops.rmsnorm(self.hidden, self.hidden, L["ln1"], c.eps)
+                ops.rmsnorm_group_quant_fp8(self.hidden, None, L["ln1"], xq[0], xq[1], c.eps)
             else:
-                ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln1"], c.eps)
-            qkv_a = self._mm(self.hidden, L["qkv_a"], self.qkv_a)                       # [B, 1536 + 576]
-            ops.rmsnorm(self.q_a, qkv_a[:, : c.q_lora_rank], L["q_a_ln"], c.eps)
+                ops.rmsnorm_group_quant_fp8(self.hidden, self.residual, L["ln1"], xq[0], xq[1], c.eps)
+            qkv_a = self._mm(None, L["qkv_a"], self.qkv_a, quantised=xq)               # [B, 1536 + 576]
+            xq = self._qbuf(B, c.q_lora_rank)
+            ops.rmsnorm_group_quant_fp8(qkv_a[:, : c.q_lora_rank], None, L["q_a_ln"], xq[0], xq[1], c.eps)
             k_nope = qkv_a[:, c.q_lora_rank: c.q_lora_rank + lat]
             ops.rmsnorm(k_nope, k_nope, L["kv_a_ln"], c.eps)
-            q = self._mm(self.q_a, L["q_b"], self.q_b).view(B, c.heads, self.qk_head_dim)
+            q = self._mm(None, L["q_b"], self.q_b, quantised=xq).view(B, c.heads, self.qk_head_dim)
             # absorbed key projection: q_nope [B, H, 128] . w_kc^T -> q_input[..., :512]
             self._bmm(q[..., :nope], L["w_kc"], L["w_scale"], self.bs[2 * li: 2 * li + 1],
                       self.q_input[..., :lat].transpose(0, 1))
@@ -244,8 +252,10 @@ class DeepseekV3DenseDecoder:
             # absorbed value projection: attn [B, H, 512] . w_vc^T -> [B, H * 128]
             self._bmm(self.attn_out, L["w_vc"], L["w_scale"], self.bs[2 * li + 1: 2 * li + 2], attn_hbn)
             self._mm(self.attn_flat, L["o"], self.hidden)
-            ops.fused_add_rmsnorm(self.hidden, self.residual, L["ln2"], c.eps)
-            gu = self._mm(self.hidden, L["gate_up"], self.gate_up)
-            ops.act_and_mul(self.act, gu, 0)
-            self._mm(self.act, L["down"], self.hidden)
+            xq = self._qbuf(B, c.hidden)
+            ops.rmsnorm_group_quant_fp8(self.hidden, self.residual, L["ln2"], xq[0], xq[1], c.eps)
+            gu = self._mm(None, L["gate_up"], self.gate_up, quantised=xq)
+            xq = self._qbuf(B, c.inter)
+            ops.silu_and_mul_group_quant_fp8(gu, xq[0], xq[1])
+            self._mm(None, L["down"], self.hidden, quantised=xq)
         ops.fused_add_rmsnorm(self.hidden, self.residual, self.final_norm, c.eps)

@@ -729,6 +729,39 @@ def silu_and_mul_quant_fp8(x, out_q, out_s):
                                             _stream(x)), "silu_and_mul_quant_fp8")
 
 
+def _group_quant_outputs(name, rows, cols, out_q, out_s):
+    if cols % 128 != 0 or tuple(out_q.shape) != (rows, cols) or not out_q.is_contiguous() or \
+            out_q.dtype != torch.float8_e4m3fn:
+        raise SglkError(f"{name}: out_q must be a contiguous float8_e4m3fn [{rows},{cols}] with {cols} a multiple of 128")
+    if tuple(out_s.shape) != (rows, cols // 128) or not out_s.is_contiguous() or out_s.dtype != torch.float32:
+        raise SglkError(f"{name}: out_s must be a contiguous float32 [{rows},{cols // 128}]")
+
+
+def rmsnorm_group_quant_fp8(x, residual, weight, out_q, out_s, eps, gemma=False):
+    """fused_add_rmsnorm (residual += x when given; rmsnorm otherwise) + sgl_per_token_group_quant_fp8 (group 128,
+    eps 1e-10, +-448) of the normalised rows, which are not written: out_q / out_s hold what the two reference calls
+    would have produced.  x rows may lie a pitch apart (a column slice)."""
+    _need_gpu(x, weight, out_q, out_s)
+    rows, hidden = x.shape
+    if x.stride(1) != 1 or (residual is not None and not residual.is_contiguous()) or not weight.is_contiguous():
+        raise SglkError("rmsnorm_group_quant_fp8: rows must be contiguous")
+    _group_quant_outputs("rmsnorm_group_quant_fp8", rows, hidden, out_q, out_s)
+    check(lib().sglk_rmsnorm_group_quant_fp8(_ptr(x), _ptr(residual), _ptr(weight), _ptr(out_q), _ptr(out_s), rows, hidden,
+                                             x.stride(0) if rows > 1 else hidden, float(eps), 1 if gemma else 0,
+                                             dtype_code(x.dtype), _stream(x)), "rmsnorm_group_quant_fp8")
+
+
+def silu_and_mul_group_quant_fp8(x, out_q, out_s):
+    """silu_and_mul over x = [gate | up] + sgl_per_token_group_quant_fp8 (group 128) of the product rows."""
+    _need_gpu(x, out_q, out_s)
+    rows, two_d = x.shape
+    if not x.is_contiguous():
+        raise SglkError("silu_and_mul_group_quant_fp8: x must be contiguous")
+    _group_quant_outputs("silu_and_mul_group_quant_fp8", rows, two_d // 2, out_q, out_s)
+    check(lib().sglk_silu_and_mul_group_quant_fp8(_ptr(x), _ptr(out_q), _ptr(out_s), rows, two_d // 2, dtype_code(x.dtype),
+                                                  _stream(x)), "silu_and_mul_group_quant_fp8")
+
+
 def fp8_mm_workspace_bytes(M, N, K) -> int:
     return int(lib().sglk_fp8_mm_workspace_bytes(M, N, K))
 

@@ -474,3 +474,62 @@ def test_w8a8_fp8_linear_method(serialized, K, N):
         out = method.apply(layer, x.to(DEV), bias.to(DEV))
         assert tuple(out.shape) == (2, m, N) and out.dtype == torch.bfloat16
         torch.testing.assert_close(out.reshape(-1, N).cpu().float(), want.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 128), (5, 1536), (64, 7168), (3, 18432)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_rmsnorm_group_quant_matches_the_two_calls(rows, hidden, dtype, with_residual):
+    """The norm with the 128-group quantisation folded in against fused_add_rmsnorm / rmsnorm followed by
+    sgl_per_token_group_quant_fp8 (to the bar of test_rmsnorm_quant_fp8); rows may be a column slice."""
+    ops = _ops()
+    torch.manual_seed(rows + hidden)
+    wide = (torch.randn(rows, hidden + 64) * 2).to(dtype).to(DEV)
+    x = wide[:, :hidden]                                           # rows a pitch apart
+    x[0, :128] = 0                                                 # an all-zero group exercises eps
+    w = (1 + 0.1 * torch.randn(hidden)).to(dtype).to(DEV)
+    res = (torch.randn(rows, hidden)).to(dtype).to(DEV) if with_residual else None
+    xc = x.clone().contiguous()
+    if with_residual:
+        res_want = res.clone()
+        ops.fused_add_rmsnorm(xc, res_want, w, 1e-6)
+    else:
+        ops.rmsnorm(xc, xc, w, 1e-6)
+    want_q = torch.empty(rows, hidden, dtype=F8, device=DEV)
+    want_s = torch.empty(rows, hidden // 128, dtype=torch.float32, device=DEV)
+    ops.per_token_group_quant_fp8(xc, want_q, want_s, 128, 1e-10, -448.0, 448.0)
+    q = torch.empty(rows, hidden, dtype=F8, device=DEV)
+    s = torch.empty(rows, hidden // 128, dtype=torch.float32, device=DEV)
+    res_got = res.clone() if with_residual else None
+    ops.rmsnorm_group_quant_fp8(x, res_got, w, q, s, 1e-6)
+    # the residual is bit-exact; a normalised value may sit one 16-bit ulp away (another summation order of the
+    # squares), which can move a group's scale or an fp8 code by one step
+    if with_residual:
+        assert torch.equal(res_got, res_want)
+    torch.testing.assert_close(s, want_s, rtol=1e-2, atol=1e-12)
+    deq = q.float().view(rows, -1, 128) * s[..., None]
+    ref = want_q.float().view(rows, -1, 128) * want_s[..., None]
+    assert (deq - ref).abs().max().item() <= 0.08 * ref.abs().max().item()
+    assert (_u8(q) != _u8(want_q)).float().mean().item() < 0.02
+    with pytest.raises(Exception):
+        ops.rmsnorm_group_quant_fp8(x[:, :64], None, w[:64], q[:, :64].contiguous(), s[:, :1].contiguous(), 1e-6)
+
+
+@pytest.mark.parametrize("rows,d", [(1, 128), (7, 2048), (64, 18432)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_silu_and_mul_group_quant_matches_the_two_calls(rows, d, dtype):
+    ops = _ops()
+    torch.manual_seed(rows + d)
+    x = (torch.randn(rows, 2 * d) * 2).to(dtype).to(DEV)
+    x[0, :128] = 0
+    act = torch.empty(rows, d, dtype=dtype, device=DEV)
+    ops.act_and_mul(act, x, 0)
+    want_q = torch.empty(rows, d, dtype=F8, device=DEV)
+    want_s = torch.empty(rows, d // 128, dtype=torch.float32, device=DEV)
+    ops.per_token_group_quant_fp8(act, want_q, want_s, 128, 1e-10, -448.0, 448.0)
+    q = torch.empty(rows, d, dtype=F8, device=DEV)
+    s = torch.empty(rows, d // 128, dtype=torch.float32, device=DEV)
+    ops.silu_and_mul_group_quant_fp8(x, q, s)
+    # bit for bit the two-step result, except that an exact zero may carry the other sign (codes 0x00 / 0x80)
+    unsigned_zero = lambda t: torch.where(_u8(t) == 0x80, torch.zeros_like(_u8(t)), _u8(t))
+    assert torch.equal(s, want_s) and torch.equal(unsigned_zero(q), unsigned_zero(want_q))
