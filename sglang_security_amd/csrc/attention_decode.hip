@@ -306,6 +306,30 @@ __global__ void __launch_bounds__(128) decode_stage2(const float* __restrict__ a
   const int splits = max(num_kv_splits[b], 1);
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
   const int64_t base = ((int64_t)b * Hq + h) * max_kv_splits;
+  if (Dv % 512 == 0 && !xsum_out && (reinterpret_cast<uintptr_t>(attn_logits) & 15) == 0) {
+    // wide values (absorbed MLA): four consecutive elements a thread, a split's weights formed once per thread; the
+    // same operations per element, in the same order, as the loop below
+    for (int d = 4 * threadIdx.x; d < Dv; d += 512) {
+      float e_sum = 0.f, e_max = -INFINITY;
+      float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < max_kv_splits; ++s) {
+        const int s0 = per_split * s, s1 = min(s0 + per_split, len);
+        if (s1 > s0) {
+          const float4v tv = *reinterpret_cast<const float4v*>(attn_logits + (base + s) * Dv + d);
+          const float tl = attn_lse[base + s];
+          const float n_max = fmaxf(tl, e_max);
+          const float old = expf(e_max - n_max), w = expf(tl - n_max);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = acc[r] * old + w * tv[r];
+          e_sum = e_sum * old + w;
+          e_max = n_max;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d + r, acc[r] / e_sum);
+    }
+    return;
+  }
   for (int d = threadIdx.x; d < Dv; d += 128) {
     float e_sum = 0.f, e_max = -INFINITY, acc = 0.f;
     for (int s = 0; s < max_kv_splits; ++s) {
