@@ -481,7 +481,9 @@ static constexpr int kMlaScoreBytes = 4 * 2 * 64 * 16;   // four waves' partial 
 
 // HT: tiles of 16 query heads per block (2 where the group has 32 heads or more: a latent tile in LDS and every
 // operand read out of it then serve twice the heads).
-template <typename T, int HT>
+// CAP: the logit cap (tanh) compiled in; a run-time test per score splits the tile loop into blocks the scheduler
+// cannot interleave.
+template <typename T, int HT, bool CAP>
 __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
     const void* __restrict__ q, const void* __restrict__ kv_buffer, const int32_t* __restrict__ kv_indptr,
     const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits, float* __restrict__ attn_lse,
@@ -527,7 +529,7 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
     }
   }
   const float LOG2E = 1.4426950408889634f;
-  const float qk_scale = (logit_cap > 0.f) ? sm_scale : sm_scale * LOG2E;
+  const float qk_scale = CAP ? sm_scale : sm_scale * LOG2E;
   float m[HT], lsum[HT];
   float4v oacc[HT][8];
 #pragma unroll
@@ -595,7 +597,7 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float sc = tot[r] * qk_scale;
-          if (logit_cap > 0.f) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
+          if constexpr (CAP) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
           const int tok = t0 + 16 * hh + 4 * g + r;
           sc = tok < s1 ? sc : -INFINITY;
           sv[hh * 4 + r] = sc;
@@ -1090,19 +1092,26 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
     if (group >= 32) {  // two tiles of 16 heads per block
       const int head_tiles = (group + 31) / 32;
       dim3 grid(B, Hkv * head_tiles, max_kv_splits);
-      SGLK_DISPATCH_HALF(dtype, T,
-                         hipLaunchKernelGGL((decode_stage1_mla<T, 2>), grid, dim3(256), kMlaTileBytes + 2 * kMlaScoreBytes,
-                                            s, q, k_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
-                                            max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
-                                            k_stride_h, sm_scale, logit_cap));
+#define SGLK_MLA_LAUNCH(HT, CAP)                                                                                         \
+  hipLaunchKernelGGL((decode_stage1_mla<T, HT, CAP>), grid, dim3(256), kMlaTileBytes + HT * kMlaScoreBytes, s, q, k_buffer, \
+                     kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles,      \
+                     q_stride_b, q_stride_h, k_stride_n, k_stride_h, sm_scale, logit_cap)
+      SGLK_DISPATCH_HALF(dtype, T, {
+        if (logit_cap > 0.f)
+          SGLK_MLA_LAUNCH(2, true);
+        else
+          SGLK_MLA_LAUNCH(2, false);
+      });
     } else {
       const int head_tiles = (group + 15) / 16;
       dim3 grid(B, Hkv * head_tiles, max_kv_splits);
-      SGLK_DISPATCH_HALF(dtype, T,
-                         hipLaunchKernelGGL((decode_stage1_mla<T, 1>), grid, dim3(256), kMlaTileBytes + kMlaScoreBytes, s,
-                                            q, k_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
-                                            max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
-                                            k_stride_h, sm_scale, logit_cap));
+      SGLK_DISPATCH_HALF(dtype, T, {
+        if (logit_cap > 0.f)
+          SGLK_MLA_LAUNCH(1, true);
+        else
+          SGLK_MLA_LAUNCH(1, false);
+      });
+#undef SGLK_MLA_LAUNCH
     }
   } else if (fast) {
     const int head_tiles = (group + 15) / 16;
