@@ -572,12 +572,12 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
       for (int t = 0; t < HT; ++t) sacc[t] = float4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 5; ++i) {
-        const int ks = wid + 4 * i;
-        if (ks < kSteps) {  // wave-uniform
-          const short8 kf = *reinterpret_cast<const short8*>(tile + (16 * hh + hl) * kMlaPitch + (4 * ks + g) * 16);
+        // k-steps past the row (waves 2 and 3 in their fifth round) multiply the row's last step by the zeros their
+        // q registers hold there: no branch in the tile loop
+        const int ks = min(wid + 4 * i, kSteps - 1);
+        const short8 kf = *reinterpret_cast<const short8*>(tile + (16 * hh + hl) * kMlaPitch + (4 * ks + g) * 16);
 #pragma unroll
-          for (int t = 0; t < HT; ++t) sacc[t] = Mfma16<T>::mma(kf, qf[t][i], sacc[t]);
-        }
+        for (int t = 0; t < HT; ++t) sacc[t] = Mfma16<T>::mma(kf, qf[t][i], sacc[t]);
       }
 #pragma unroll
       for (int t = 0; t < HT; ++t) sbuf[((t * 4 + wid) * 2 + hh) * 64 + lane] = sacc[t];
