@@ -543,17 +543,22 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
   const uint16_t* kbase = reinterpret_cast<const uint16_t*>(kv_buffer) + (int64_t)kvh * k_stride_h;
   const int32_t* idx = kv_indices + start;
   const int frow = threadIdx.x >> 3, fsub = threadIdx.x & 7;
-  // FD tiles are in flight (registers) while one is multiplied (two measured no faster than one: the step is
-  // not bound by the way to the rows and back)
+  // FD tiles are in flight (registers) while one is multiplied (two measured no faster than one, with or without
+  // the slots read ahead: the step is not bound by the way to the rows and back)
   constexpr int FD = 1;
   int4v kreg[FD][9];
-  auto fetch = [&](int4v(&kr)[9], int t0) {
+  // a row's slot is read one tile before its bytes are requested (slot and bytes are two dependent trips to memory)
+  auto slot_of = [&](int t0) {
     int tok = t0 + frow;
     tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
-    const uint16_t* row = kbase + (int64_t)idx[tok] * k_stride_n + fsub * 8;
+    return idx[tok];
+  };
+  auto fetch = [&](int4v(&kr)[9], int slot) {
+    const uint16_t* row = kbase + (int64_t)slot * k_stride_n + fsub * 8;
 #pragma unroll
     for (int j = 0; j < 9; ++j) kr[j] = *reinterpret_cast<const int4v*>(row + 64 * j);
   };
+  int slot_next = 0;
   auto park = [&](const int4v(&kr)[9]) {
 #pragma unroll
     for (int j = 0; j < 9; ++j) *reinterpret_cast<int4v*>(tile + frow * kMlaPitch + (fsub + 8 * j) * 16) = kr[j];
@@ -563,7 +568,10 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
     __syncthreads();  // every wave is done with the previous tile
     park(kr);
     __syncthreads();
-    if (t0 + FD * kTile < s1) fetch(kr, t0 + FD * kTile);  // later tiles' rows fly while this one is multiplied
+    if (t0 + FD * kTile < s1) {  // later tiles' rows fly while this one is multiplied
+      fetch(kr, slot_next);
+      slot_next = slot_of(t0 + (FD + 1) * kTile);
+    }
     // ---- this wave's share of S^T = K . Q^T: a K operand read serves every head tile
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -634,7 +642,8 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
 
 #pragma unroll
   for (int f = 0; f < FD; ++f)
-    if (s0 + f * kTile < s1) fetch(kreg[f], s0 + f * kTile);
+    if (s0 + f * kTile < s1) fetch(kreg[f], slot_of(s0 + f * kTile));
+  slot_next = slot_of(s0 + FD * kTile);
   for (int t0 = s0; t0 < s1; t0 += FD * kTile) {
 #pragma unroll
     for (int f = 0; f < FD; ++f)
