@@ -658,16 +658,16 @@ __global__ void __launch_bounds__(256, 2) fp8_stream_kernel(const uint8_t* __res
   // requested XPF blocks ahead and parked in LDS one block ahead (a step of the loop is shorter than the way to the
   // L2 and back: a request made only a step before its use would set the pace)
   const int xr = threadIdx.x >> 2, xq = threadIdx.x & 3;
-  const bool xrow_ok = (m0 + xr) < M;
-  const uint8_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
+  // rows past M re-read row M - 1 (their products are never stored): no exec-masked branch in the loop
+  const int64_t xrow = min(m0 + xr, M - 1);
+  const uint8_t* xsrc = x + xrow * x_stride + 32 * xq;
   int4v xreg[XPF][2];
   [[maybe_unused]] float sareg[XPF] = {};
   auto x_fetch = [&](int4v(&r2)[2], int kb, [[maybe_unused]] float& sr) {
 #pragma unroll
     for (int c = 0; c < 2; ++c)
-      r2[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * (int64_t)kb + 16 * c) : int4v{0, 0, 0, 0};
-    if constexpr (BW)
-      if (xq == 0) sr = xrow_ok ? sa[(int64_t)(m0 + xr) * sa_m + (int64_t)kb * sa_k] : 0.f;
+      r2[c] = *reinterpret_cast<const int4v*>(xsrc + 128 * (int64_t)kb + 16 * c);
+    if constexpr (BW) sr = sa[xrow * sa_m + (int64_t)kb * sa_k];  // every thread of a row: no branch
   };
   auto x_park = [&](const int4v(&r2)[2], int buf, [[maybe_unused]] float sr) {
 #pragma unroll
