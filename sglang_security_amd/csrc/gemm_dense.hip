@@ -54,8 +54,8 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
   const int n0 = (blockIdx.x * 4 + wid) * 16 * NS + i16;  // weight row (output column) of this lane, strip 0
 
   const int xr = threadIdx.x >> 2, xq = threadIdx.x & 3;
-  const bool xrow_ok = (m0 + xr) < M;
-  const uint16_t* xsrc = x + (int64_t)(m0 + xr) * x_stride + 32 * xq;
+  // rows past M re-read row M - 1 (their products land in rows nobody reads): no exec-masked branch in the loop
+  const uint16_t* xsrc = x + (int64_t)min(m0 + xr, M - 1) * x_stride + 32 * xq;
   // Activations are requested two k-blocks ahead: loads return in order, so the wait before a tile is
   // parked leaves only the weight loads issued after its request in flight, and that has to be the
   // whole weight prefetch depth.
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256, 2) dense_gemm_nt_kernel(const uint16_t* _
   auto x_fetch = [&](int4v(&xr4)[4], int kb) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      xr4[c] = xrow_ok ? *reinterpret_cast<const int4v*>(xsrc + 128 * kb + 8 * c) : int4v{0, 0, 0, 0};
+      xr4[c] = *reinterpret_cast<const int4v*>(xsrc + 128 * kb + 8 * c);
   };
   auto x_park = [&](const int4v(&xr4)[4], int buf) {
 #pragma unroll
