@@ -779,10 +779,37 @@ SGLK_API int64_t sglk_ar_meta_size(void);
  * (init_custom_ar, sgl-kernel/csrc/allreduce/custom_all_reduce.hip:13-49) */
 SGLK_API int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi,
                               int64_t staging_bytes);
+/* The same with the peers' signal blocks named by IPC handles, as the reference's ROCm binding takes them
+ * (init_custom_ar(meta, rank_data, handles, offsets, rank, full_nvlink), custom_all_reduce.hip:13-35;
+ * constructor custom_all_reduce_hip.cuh:376-399): handles[w] points at the sglk_ipc_handle_bytes() bytes of rank
+ * w's handle, offsets[w] is that rank's block offset inside the allocation; the own entries are not opened.
+ * meta is this rank's block (sglk_ar_meta_size() + staging_bytes bytes of zeroed uncached memory).  rank_data /
+ * rank_data_bytes: caller-owned device memory for the records of peer pointers (64 bytes per registered or
+ * captured input; the reference hands in 8 MiB, custom_all_reduce.py:289-291); NULL makes the communicator
+ * allocate room for 4096 records itself.  Mappings opened here are closed by sglk_ar_dispose. */
+SGLK_API int64_t sglk_ar_init_handles(void* meta, void* rank_data, int64_t rank_data_bytes,
+                                      const void* const* handles, const int64_t* offsets, int rank, int world,
+                                      int full_xgmi, int64_t staging_bytes);
 SGLK_API int sglk_ar_dispose(int64_t fa);
 /* data_ptrs[w]: every rank's registered input buffer for `local` (peer mappings);
  * data_ptrs[rank] == local.  (register_buffer, custom_all_reduce.hip:119-144) */
 SGLK_API int sglk_ar_register_buffer(int64_t fa, void* local, void* const* data_ptrs);
+/* The same with the peers' buffers named by IPC handle + offset
+ * (register_buffer(fa, t, handles, offsets), custom_all_reduce.hip:119-124, custom_all_reduce_hip.cuh:442-458). */
+SGLK_API int sglk_ar_register_buffer_handles(int64_t fa, void* local, const void* const* handles,
+                                             const int64_t* offsets);
+/* Graph capture (custom_all_reduce_hip.cuh:413-434,460-476; caller custom_all_reduce.py:335-348,388-393): while
+ * the stream is capturing, sglk_ar_all_reduce accepts an input that is not registered, reserves a record for it and
+ * remembers the pointer.  After the capture: sglk_ar_graph_buffer_count() inputs are pending;
+ * sglk_ar_get_graph_buffer_ipc_meta writes their IPC handles (count * sglk_ipc_handle_bytes() bytes, in launch
+ * order) and offsets (get_graph_buffer_ipc_meta, custom_all_reduce.hip:126-137); the caller exchanges them between
+ * the ranks; sglk_ar_register_graph_buffers takes every rank's lists (handles[w]: count handles back to back,
+ * offsets[w]: count offsets; the own entries are ignored), maps them and fills the records in
+ * (register_graph_buffers, custom_all_reduce.hip:139-144).  The graph must not be replayed before that. */
+SGLK_API int64_t sglk_ar_graph_buffer_count(int64_t fa);
+SGLK_API int sglk_ar_get_graph_buffer_ipc_meta(int64_t fa, void* handles_out, int64_t* offsets_out, int64_t cap);
+SGLK_API int sglk_ar_register_graph_buffers(int64_t fa, const void* const* handles,
+                                            const int64_t* const* offsets, int64_t count);
 /* out = sum over ranks of their registered `inp` (fp32 accumulation in rank order, one rounding:
  * every rank gets bit-identical results).  numel * element size must be a multiple of 16.
  * algo: 0 = choose as the reference does (custom_all_reduce_hip.cuh:543-553), 1 = one-stage,

@@ -121,7 +121,12 @@ _SIGS = {
     "sglk_topk_softmax": (i32, [p, p, p, p, i32, i32, i32, i64, i32, p]),
     "sglk_ar_meta_size": (i64, []),
     "sglk_ar_init": (i64, [p, i32, i32, i32, i64]),
+    "sglk_ar_init_handles": (i64, [p, p, i64, p, p, i32, i32, i32, i64]),
     "sglk_ar_dispose": (i32, [i64]),
+    "sglk_ar_register_buffer_handles": (i32, [i64, p, p, p]),
+    "sglk_ar_graph_buffer_count": (i64, [i64]),
+    "sglk_ar_get_graph_buffer_ipc_meta": (i32, [i64, p, p, i64]),
+    "sglk_ar_register_graph_buffers": (i32, [i64, p, p, i64]),
     "sglk_ar_register_buffer": (i32, [i64, p, p]),
     "sglk_ar_all_reduce": (i32, [i64, p, p, i64, i32, i32, p]),
     "sglk_ar_all_reduce_unreg": (i32, [i64, p, p, p, i64, i32, i32, p]),

@@ -18,6 +18,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(PKG, "libsglk.so")
+TORCH_SRC = os.path.join(CSRC, "torch", "allreduce_ops.cc")
+TORCH_LIB = os.path.join(PKG, "sgl_kernel", "common_ops.so")
 ARCH = "gfx950"
 
 
@@ -62,7 +64,31 @@ def build(force: bool = False, jobs: int = 6) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
+    build_torch_ops(force)
     return LIB
+
+
+def build_torch_ops(force: bool = False) -> str:
+    """sgl_kernel/common_ops.so: the torch.ops.sgl_kernel.* registrations that have to come from C++ (the all-reduce
+    op set, whose `str[]` arguments carry raw handle bytes).  Host code only: g++ against the installed torch's
+    headers, linked to libsglk.so beside it."""
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    deps = [TORCH_SRC, os.path.join(ROOT, "include", "sglk.h"), LIB]
+    if not force and os.path.exists(TORCH_LIB) and os.path.getmtime(TORCH_LIB) >= max(os.path.getmtime(d) for d in deps):
+        return TORCH_LIB
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(rocm, "include")] + ["-I" + d for d in ce.include_paths()] + [
+        TORCH_SRC, "-o", TORCH_LIB, "-L" + PKG, "-l:libsglk.so", "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch",
+        "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + tlib]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch op library failed to build:\n" + r.stderr[-4000:])
+    return TORCH_LIB
 
 
 if __name__ == "__main__":

@@ -23,10 +23,12 @@
 // that communicator poisons its output at once without waiting, and the host entry points return SGLK_ESTUCK as
 // soon as they see the host word.  Peers waiting for the failed rank time out the same way, so the failure reaches
 // every rank.  Recovery is a new communicator.
+#include <array>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -140,9 +142,13 @@ __device__ __forceinline__ uint4 reduce_vec(const Inputs& in, int world, int64_t
   return pack_vec<T>(acc);
 }
 
+// The peer pointers of an input live in device memory (`slot`, one Inputs record per registered buffer) and not in
+// the kernel arguments: a launch captured into a graph names a record that register_graph_buffers fills in only
+// after the capture has ended (custom_all_reduce_hip.cuh:453-476), so the record is read when the kernel runs.
 template <typename T>
-__global__ void __launch_bounds__(kThreads) allreduce_one_stage(Inputs in, Peers peers, Signal* self, void* out, int rank,
-                                                                int world, int64_t nvec, Watch watch) {
+__global__ void __launch_bounds__(kThreads) allreduce_one_stage(const Inputs* __restrict__ slot, Peers peers, Signal* self,
+                                                                void* out, int rank, int world, int64_t nvec, Watch watch) {
+  const Inputs in = *slot;
   if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
     reinterpret_cast<uint4*>(out)[i] = reduce_vec<T>(in, world, i);
@@ -150,8 +156,9 @@ __global__ void __launch_bounds__(kThreads) allreduce_one_stage(Inputs in, Peers
 }
 
 template <typename T>
-__global__ void __launch_bounds__(kThreads) allreduce_two_stage(Inputs in, Peers peers, Signal* self, void* out, int rank,
-                                                                int world, int64_t nvec, Watch watch) {
+__global__ void __launch_bounds__(kThreads) allreduce_two_stage(const Inputs* __restrict__ slot, Peers peers, Signal* self,
+                                                                void* out, int rank, int world, int64_t nvec, Watch watch) {
+  const Inputs in = *slot;
   const int64_t part = nvec / world;  // the last rank also takes the remainder
   const int64_t lo = part * rank, hi = rank == world - 1 ? nvec : lo + part;
   uint4* stage = reinterpret_cast<uint4*>(self + 1);
@@ -170,8 +177,9 @@ __global__ void __launch_bounds__(kThreads) allreduce_two_stage(Inputs in, Peers
 }
 
 // out[r * nvec + i] = rank r's input vector i: every rank's registered input, concatenated in rank order.
-__global__ void __launch_bounds__(kThreads) allgather_kernel(Inputs in, Peers peers, Signal* self, void* out, int rank,
-                                                             int world, int64_t nvec, Watch watch) {
+__global__ void __launch_bounds__(kThreads) allgather_kernel(const Inputs* __restrict__ slot, Peers peers, Signal* self,
+                                                             void* out, int rank, int world, int64_t nvec, Watch watch) {
+  const Inputs in = *slot;
   if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec * world);
   for (int r = 0; r < world; ++r) {
     const int src = (rank + r) % world;
@@ -183,19 +191,51 @@ __global__ void __launch_bounds__(kThreads) allgather_kernel(Inputs in, Peers pe
   if (!barrier_all<false>(peers, self, rank, world, watch)) poison(out, nvec * world);
 }
 
+using IpcKey = std::array<uint8_t, sizeof(hipIpcMemHandle_t)>;
+
 struct Comm {
   int rank = 0, world = 1, full_xgmi = 1;
   int64_t staging_bytes = 0;
   Peers peers{};
   Signal* self = nullptr;
-  std::map<const void*, Inputs> buffers;
+  // Records of peer pointers in device memory: the caller's rank_data buffer (init_custom_ar's second argument,
+  // custom_all_reduce.py:289-294) or, for the pointer form of init, an allocation of this communicator.
+  Inputs* slot_next = nullptr;
+  Inputs* slot_end = nullptr;
+  void* own_slots = nullptr;
+  std::map<const void*, Inputs*> buffers;   // registered input -> its record
+  std::vector<void*> graph_unreg;           // inputs seen under capture, in launch order; records reserved
+  std::vector<Inputs*> graph_slots;
+  std::map<IpcKey, char*> ipc;              // handles this communicator opened (closed in dispose)
   std::mutex mu;
   uint32_t* host_flag = nullptr;  // pinned; the kernels write it through watch.host_flag
   Watch watch{};
   ~Comm() {
     if (host_flag) (void)hipHostFree(host_flag);
+    for (auto& kv : ipc)
+      if (kv.second) (void)hipIpcCloseMemHandle(kv.second);
+    if (own_slots) (void)hipFree(own_slots);
+  }
+  // open_ipc_handle (custom_all_reduce_hip.cuh:402-411): one mapping per distinct handle
+  char* open(const void* handle) {
+    IpcKey key;
+    std::memcpy(key.data(), handle, sizeof(hipIpcMemHandle_t));
+    auto it = ipc.find(key);
+    if (it != ipc.end()) return it->second;
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handle, sizeof(h));
+    void* p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return nullptr;
+    ipc[key] = static_cast<char*>(p);
+    return static_cast<char*>(p);
+  }
+  Inputs* take_slot() {
+    if (!slot_next || slot_next >= slot_end) return nullptr;
+    return slot_next++;
   }
 };
+
+constexpr int64_t kOwnSlots = 4096;  // records the pointer form of init allocates for itself
 
 int check_alive(Comm* c, const char* what) {
   if (__atomic_load_n(c->host_flag, __ATOMIC_RELAXED) != 0)
@@ -250,7 +290,50 @@ int64_t sglk_ar_init(void* const* meta_ptrs, int rank, int world, int full_xgmi,
     if (v > 0) ms = v;
   }
   c->watch.ticks = (uint64_t)ms * kTicksPerMs;
+  if (hipMalloc(&c->own_slots, sizeof(Inputs) * kOwnSlots) != hipSuccess) {
+    fail(SGLK_EHIP, "ar_init: record area: %s", hipGetErrorString(hipGetLastError()));
+    c->own_slots = nullptr;
+    delete c;
+    return 0;
+  }
+  c->slot_next = static_cast<Inputs*>(c->own_slots);
+  c->slot_end = c->slot_next + kOwnSlots;
   return (int64_t) reinterpret_cast<intptr_t>(c);
+}
+
+int64_t sglk_ar_init_handles(void* meta, void* rank_data, int64_t rank_data_bytes, const void* const* handles,
+                             const int64_t* offsets, int rank, int world, int full_xgmi, int64_t staging_bytes) {
+  if (!meta || !handles || !offsets || world < 1 || world > kMaxRanks || rank < 0 || rank >= world) {
+    fail(SGLK_EINVAL, "ar_init_handles: bad arguments (world=%d rank=%d; at most %d ranks)", world, rank, kMaxRanks);
+    return 0;
+  }
+  if (rank_data && rank_data_bytes < (int64_t)sizeof(Inputs)) {
+    fail(SGLK_EINVAL, "ar_init_handles: rank_data holds no record (%lld bytes)", (long long)rank_data_bytes);
+    return 0;
+  }
+  // the own block first, so that a Comm exists to keep the mappings opened for the peers
+  void* metas[kMaxRanks];
+  for (int r = 0; r < world; ++r) metas[r] = meta;
+  const int64_t fa = sglk_ar_init(metas, rank, world, full_xgmi, staging_bytes);
+  if (!fa) return 0;
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  for (int r = 0; r < world; ++r) {
+    if (r == rank) continue;
+    char* base = handles[r] ? c->open(handles[r]) : nullptr;
+    if (!base) {
+      fail(SGLK_EHIP, "ar_init_handles: cannot map the signal block of rank %d", r);
+      delete c;
+      return 0;
+    }
+    c->peers.sig[r] = reinterpret_cast<Signal*>(base + offsets[r]);
+  }
+  if (rank_data) {  // the caller's buffer takes the place of the own record area
+    (void)hipFree(c->own_slots);
+    c->own_slots = nullptr;
+    c->slot_next = static_cast<Inputs*>(rank_data);
+    c->slot_end = c->slot_next + rank_data_bytes / (int64_t)sizeof(Inputs);
+  }
+  return fa;
 }
 
 int sglk_ar_set_timeout_ms(int64_t fa, int64_t ms) {
@@ -275,7 +358,85 @@ int sglk_ar_register_buffer(int64_t fa, void* local, void* const* data_ptrs) {
   }
   SGLK_CHECK(data_ptrs[c->rank] == local, "ar_register_buffer: data_ptrs[rank] must be the local buffer");
   std::lock_guard<std::mutex> g(c->mu);
-  c->buffers[local] = in;
+  auto it = c->buffers.find(local);
+  Inputs* slot = it != c->buffers.end() ? it->second : c->take_slot();
+  SGLK_CHECK(slot, "ar_register_buffer: the record area is full (custom_all_reduce_hip.cuh:436-440)");
+  SGLK_HIP(hipMemcpy(slot, &in, sizeof(Inputs), hipMemcpyHostToDevice));
+  c->buffers[local] = slot;
+  return SGLK_OK;
+}
+
+int sglk_ar_register_buffer_handles(int64_t fa, void* local, const void* const* handles, const int64_t* offsets) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c && local && handles && offsets, "ar_register_buffer_handles: null argument");
+  void* ptrs[kMaxRanks];
+  {
+    std::lock_guard<std::mutex> g(c->mu);
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) {
+        ptrs[r] = local;
+        continue;
+      }
+      char* base = handles[r] ? c->open(handles[r]) : nullptr;
+      SGLK_CHECK(base, "ar_register_buffer_handles: cannot map the buffer of rank %d", r);
+      ptrs[r] = base + offsets[r];
+    }
+  }
+  return sglk_ar_register_buffer(fa, local, ptrs);
+}
+
+int64_t sglk_ar_graph_buffer_count(int64_t fa) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  if (!c) return fail(SGLK_EINVAL, "ar_graph_buffer_count: null handle");
+  std::lock_guard<std::mutex> g(c->mu);
+  return (int64_t)c->graph_unreg.size();
+}
+
+int sglk_ar_get_graph_buffer_ipc_meta(int64_t fa, void* handles_out, int64_t* offsets_out, int64_t cap) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c, "ar_get_graph_buffer_ipc_meta: null handle");
+  std::lock_guard<std::mutex> g(c->mu);
+  const int64_t n = (int64_t)c->graph_unreg.size();
+  SGLK_CHECK(n <= cap && (n == 0 || (handles_out && offsets_out)), "ar_get_graph_buffer_ipc_meta: room for %lld records needed",
+             (long long)n);
+  for (int64_t i = 0; i < n; ++i) {
+    // the handle names the whole allocation: share its base and the pointer's offset in it
+    // (custom_all_reduce_hip.cuh:413-434)
+    void* base = nullptr;
+    size_t size = 0;
+    SGLK_HIP(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)c->graph_unreg[(size_t)i]));
+    hipIpcMemHandle_t h;
+    SGLK_HIP(hipIpcGetMemHandle(&h, base));
+    std::memcpy(static_cast<char*>(handles_out) + i * (int64_t)sizeof(h), &h, sizeof(h));
+    offsets_out[i] = (int64_t)((char*)c->graph_unreg[(size_t)i] - (char*)base);
+  }
+  return SGLK_OK;
+}
+
+int sglk_ar_register_graph_buffers(int64_t fa, const void* const* handles, const int64_t* const* offsets, int64_t count) {
+  Comm* c = reinterpret_cast<Comm*>((intptr_t)fa);
+  SGLK_CHECK(c && (count == 0 || (handles && offsets)), "ar_register_graph_buffers: null argument");
+  std::lock_guard<std::mutex> g(c->mu);
+  SGLK_CHECK(count == (int64_t)c->graph_unreg.size(),
+             "ar_register_graph_buffers: %lld records given, %lld inputs were captured", (long long)count,
+             (long long)c->graph_unreg.size());
+  // addresses are not deduplicated, as in the reference (:453-476): every captured launch owns its record
+  for (int64_t i = 0; i < count; ++i) {
+    Inputs in{};
+    for (int r = 0; r < c->world; ++r) {
+      if (r == c->rank) {
+        in.ptr[r] = c->graph_unreg[(size_t)i];
+        continue;
+      }
+      SGLK_CHECK(handles[r] && offsets[r], "ar_register_graph_buffers: null list for rank %d", r);
+      char* base = c->open(static_cast<const char*>(handles[r]) + i * (int64_t)sizeof(hipIpcMemHandle_t));
+      SGLK_CHECK(base, "ar_register_graph_buffers: cannot map input %lld of rank %d", (long long)i, r);
+      in.ptr[r] = base + offsets[r][i];
+    }
+    SGLK_HIP(hipMemcpy(c->graph_slots[(size_t)i], &in, sizeof(Inputs), hipMemcpyHostToDevice));
+  }
+  c->graph_unreg.clear();
+  c->graph_slots.clear();
   return SGLK_OK;
 }
 
@@ -290,12 +451,25 @@ int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, in
   // custom_all_reduce_hip.cuh:480-484: the payload must be a whole number of 16-byte packs
   SGLK_CHECK(bytes % 16 == 0, "ar_all_reduce: byte size %lld is not a multiple of 16", (long long)bytes);
   SGLK_CHECK(aligned16(inp) && aligned16(out), "ar_all_reduce: buffers must be 16-byte aligned");
-  Inputs in;
+  const Inputs* in = nullptr;
   {
     std::lock_guard<std::mutex> g(c->mu);
     auto it = c->buffers.find(inp);
-    SGLK_CHECK(it != c->buffers.end(), "ar_all_reduce: input %p is not a registered buffer", inp);
-    in = it->second;
+    if (it != c->buffers.end()) {
+      in = it->second;
+    } else {
+      // custom_all_reduce_hip.cuh:517-533: under capture an unknown input gets a record that
+      // register_graph_buffers fills in before the graph is replayed; outside capture it is an error
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      SGLK_HIP(hipStreamIsCapturing((hipStream_t)stream, &st));
+      SGLK_CHECK(st == hipStreamCaptureStatusActive,
+                 "ar_all_reduce: input %p is not a registered buffer (and the stream is not capturing)", inp);
+      Inputs* slot = c->take_slot();
+      SGLK_CHECK(slot, "ar_all_reduce: the record area is full (custom_all_reduce_hip.cuh:436-440)");
+      c->graph_unreg.push_back(const_cast<void*>(inp));
+      c->graph_slots.push_back(slot);
+      in = slot;
+    }
   }
   const int64_t nvec = bytes / 16;
   if (algo == 0) {
@@ -336,7 +510,7 @@ int sglk_ar_all_gather(int64_t fa, const void* inp, void* out, int64_t bytes_per
   if (int rc = check_alive(c, "ar_all_gather")) return rc;
   SGLK_CHECK(bytes_per_rank % 16 == 0, "ar_all_gather: byte size %lld is not a multiple of 16", (long long)bytes_per_rank);
   SGLK_CHECK(aligned16(inp) && aligned16(out), "ar_all_gather: buffers must be 16-byte aligned");
-  Inputs in;
+  const Inputs* in = nullptr;
   {
     std::lock_guard<std::mutex> g(c->mu);
     auto it = c->buffers.find(inp);

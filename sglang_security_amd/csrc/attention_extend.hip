@@ -154,8 +154,9 @@ __global__ void __launch_bounds__(256) extend_attention_mfma128(
 template <typename T>
 __global__ void __launch_bounds__(128) extend_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_lse,
                                                          void* __restrict__ o, int Hq, int kv_splits, int64_t o_stride_t,
-                                                         int64_t o_stride_h) {
+                                                         int64_t o_stride_h, const int32_t* __restrict__ qo_indptr, int B) {
   const int64_t t = blockIdx.x;
+  if (t >= qo_indptr[B]) return;  // rows of an over-allocated q_extend hold no partials: leave their output alone
   const int h = blockIdx.y, d = threadIdx.x;
   const int64_t row0 = (t * Hq + h) * kv_splits;
   float e_max = -INFINITY, e_sum = 0.f, acc = 0.f;
@@ -332,7 +333,7 @@ static int extend_attention_impl(const void* q_extend, const void* k_extend, con
     SGLK_LAUNCH_CHECK();
     SGLK_DISPATCH_HALF(dtype, T,
                        hipLaunchKernelGGL((extend_merge_kernel<T>), dim3((unsigned)total_rows, Hq), dim3(128), 0, s, part_o,
-                                          part_lse, o_extend, Hq, kv_splits, o_stride_t, o_stride_h));
+                                          part_lse, o_extend, Hq, kv_splits, o_stride_t, o_stride_h, qo_indptr, B));
   } else if (fast && !(env_nc && atoi(env_nc) == 2)) {
     dim3 grid((max_extend_len + 63) / 64, Hq, B);
     SGLK_EXT_TILE(1, grid, 1, (float*)nullptr, (float*)nullptr);

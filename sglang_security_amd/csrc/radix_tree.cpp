@@ -31,6 +31,7 @@
 #include <mutex>
 #include <set>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "sglk.h"
@@ -82,6 +83,8 @@ struct Node {
   int64_t epoch = 0;
   bool orphan = false;          // cut off from the root, kept only because a request still locks it
   bool slots_returned = false;  // its slots went back to the pool when it left the tree
+  bool value_filtered = false;  // `owned` (not `value`) lists the slots this node may still give back
+  std::vector<int64_t> owned;   // value minus the slots the overwriting node took over (compat 2 only)
 };
 
 struct Slot {
@@ -165,20 +168,31 @@ struct Tree {
 
   // A subtree that an overwrite cut off from the root (the fork's private-root quirk).  Unlocked nodes go now,
   // locked ones when their last lock goes; with compat == 2 their slots return to the pool and their sizes leave
-  // the counters (compat == 1 keeps both, as the fork does).
+  // the counters (compat == 1 keeps both, as the fork does).  A request that matched the old child and then
+  // finishes inserts its WHOLE slot row (cache_finished_req, radix_cache.py:160-197: insert() returns 0 at the
+  // private root, nothing is freed), so the overwriting node's value names the old child's slots again: those
+  // now belong to the new node and must not go back to the pool with the old one.
   void drop_orphan_node(Node* x) {
     if (compat == 2 && !x->slots_returned) {
-      free_slots(x->value);
+      free_slots(x->value_filtered ? x->owned : x->value);
       evictable -= (int64_t)x->value.size();
     }
     release(x);
   }
-  void orphan_subtree(Node* top) {
+  void orphan_subtree(Node* top, const int64_t* new_val, int64_t new_len) {
+    std::unordered_set<int64_t> taken;
+    if (compat == 2) taken.insert(new_val, new_val + new_len);
     std::vector<Node*> st{top};
     while (!st.empty()) {
       Node* x = st.back();
       st.pop_back();
       for (auto& it : x->children.items) st.push_back(it.second);
+      if (compat == 2 && !x->slots_returned) {
+        x->owned.clear();
+        for (int64_t s : x->value)
+          if (!taken.count(s)) x->owned.push_back(s);
+        x->value_filtered = true;
+      }
       if (x->lock_ref > 0) {
         x->orphan = true;  // a running request still walks up from here (never down: forget the children)
         x->children.items.clear();
@@ -262,6 +276,8 @@ struct Tree {
       x->slots_returned = true;
       delete_leaf(x);
       release(x);
+      for (Node* g : grace)  // a node kept for an earlier caller must not walk up into a destroyed parent
+        if (g->parent == x) g->parent = nullptr;
     }
   }
 
@@ -352,7 +368,7 @@ struct Tree {
         nn->key.assign(key, key + n);
         nn->value.assign(val, val + n);
         nn->owner = user;
-        if (Node* old = node->children.find(child_key)) orphan_subtree(old);  // the root quirk: overwritten child
+        if (Node* old = node->children.find(child_key)) orphan_subtree(old, val, len);  // the root quirk: overwritten child
         node->children.set(child_key, nn);
         evictable += n;
         created.push_back(nn->id);
@@ -508,7 +524,9 @@ int64_t sglk_radix_match_prefix(int64_t tree, const int32_t* key, int64_t key_le
   std::lock_guard<std::mutex> g(t->mu);
   std::vector<int64_t> out;
   Node* last = t->root;
-  t->settle_grace();
+  // Grace nodes are NOT settled here: the scheduler matches many requests before it locks one, and the node a
+  // release cut off must still resolve when inc_lock_ref finally arrives (the reference walks the dead node's
+  // parent chain and locks the live ancestors, radix_cache.py:285-299).  Insert, evict and reset settle them.
   const int64_t n = t->match(key, key_len, user_id, out, &last);
   if (last_node) *last_node = last->id;
   t->flush_dead();

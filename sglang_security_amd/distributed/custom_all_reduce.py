@@ -1,9 +1,10 @@
 """Peer-to-peer all-reduce communicator over the sglk_ar_* entry points.
 
 Mirror of CustomAllreduce (python/sglang/srt/distributed/device_communicators/custom_all_reduce.py:146-510):
-same constructor arguments and the same methods (should_custom_ar, all_reduce_reg, all_reduce_unreg,
-custom_all_reduce, register_buffer, close).  Handles are exchanged through the given CPU (gloo) process
-group; every rank then maps the peers' signal blocks and input buffers with hipIpcOpenMemHandle.
+same constructor arguments and the same methods (capture, should_custom_ar, all_reduce_reg, all_reduce_unreg,
+custom_all_reduce, register_buffer, register_graph_buffers, close), built like the reference's HIP branch on the
+`sgl_kernel.allreduce` functions.  Handles are exchanged through the given CPU (gloo) process group; the library
+then maps the peers' signal blocks and input buffers with hipIpcOpenMemHandle.
 """
 from __future__ import annotations
 
@@ -12,6 +13,8 @@ from typing import List, Optional
 
 import torch
 import torch.distributed as dist
+
+from contextlib import contextmanager
 
 from .._lib import SglkError, check, dtype_code, lib
 
@@ -28,11 +31,14 @@ class CustomAllreduce:
 
     def __init__(self, group, device, max_size: int = _MAX_CAR_SIZE, full_xgmi: bool = True,
                  timeout_ms: Optional[int] = None) -> None:
+        """The HIP branch of the reference constructor (custom_all_reduce.py:282-298), op for op: allocate_meta_buffer
+        -> get_meta_buffer_ipc_handle -> handle exchange over the CPU group -> init_custom_ar -> register_buffer of
+        the staging buffer.  full_xgmi is the reference's full_nvlink (every pair of GPUs one xGMI hop apart)."""
         self._ptr = 0
+        self._IS_CAPTURING = False
         self.disabled = True
         self.failed = False
-        self._opened: List[int] = []
-        self._meta = 0
+        self.meta = None
         if dist.get_backend(group) == "nccl":
             raise SglkError("CustomAllreduce needs a CPU (gloo) group for the handle exchange")
         self.group = group
@@ -48,53 +54,70 @@ class CustomAllreduce:
             device = torch.device(device)
         self.device = device
         self.max_size = max_size
-        self.full_xgmi = full_xgmi
-        L = lib()
+        self.full_xgmi = self.full_nvlink = full_xgmi
+        from ..sgl_kernel import allreduce as ops
+
+        self._ops = ops
         torch.cuda.set_device(device)
-        total = int(L.sglk_ar_meta_size()) + max_size
-        self._meta = L.sglk_alloc_uncached(total)
-        if not self._meta:
-            check(-1, "alloc_uncached")
-        metas = self._exchange(self._meta)
-        arr = (C.c_void_p * self.world_size)(*metas)
-        self._ptr = L.sglk_ar_init(arr, self.rank, self.world_size, 1 if full_xgmi else 0, max_size)
-        if not self._ptr:
-            check(-1, "ar_init")
-        if timeout_ms is not None:
-            check(L.sglk_ar_set_timeout_ms(self._ptr, int(timeout_ms)), "ar_set_timeout_ms")
-        # the staging input buffer for tensors that are not registered themselves
+        # signal block + staging area of the two-stage algorithm: uncached, zero-filled (:283-284)
+        self.meta = ops.allocate_meta_buffer(ops.meta_size() + max_size)
+        # eager inputs are copied into this pre-registered buffer (:285)
         self.buffer = torch.empty(max_size, dtype=torch.uint8, device=device)
+        handle = ops.get_meta_buffer_ipc_handle(self.meta)
+        handles, offsets = self._gather_ipc_meta((bytes(handle.numpy().tobytes()), 0))
+        # one 64-byte record of peer pointers per registered or captured input (:289-291)
+        self.rank_data = torch.empty(8 * 1024 * 1024, dtype=torch.uint8, device=device)
+        self._ptr = ops.init_custom_ar(self.meta, self.rank_data, handles, offsets, self.rank, self.full_nvlink)
+        if timeout_ms is not None:
+            check(lib().sglk_ar_set_timeout_ms(self._ptr, int(timeout_ms)), "ar_set_timeout_ms")
         self.register_buffer(self.buffer)
         self.disabled = False
 
-    # ---- handle exchange ------------------------------------------------------------------------
-    def _exchange(self, local_ptr: int) -> List[int]:
-        """All-gather the IPC handle of local_ptr and open the peers' handles; returns one address per rank."""
+    # ---- handle exchange (custom_all_reduce.py:335-411) ---------------------------------------------------
+    @contextmanager
+    def capture(self):
+        """Wrap a graph capture: all-reduce launches recorded inside it name inputs that no peer has mapped yet;
+        leaving the context exchanges their handles and fills the records in (register_graph_buffers)."""
+        try:
+            self._IS_CAPTURING = True
+            yield
+        finally:
+            self._IS_CAPTURING = False
+            if not self.disabled:
+                self.register_graph_buffers()
+
+    def _get_ipc_meta(self, inp: torch.Tensor):
+        """(handle of the allocation that holds inp, inp's offset in it), gathered over the ranks.  The reference asks
+        for the handle of inp's own address and sends offset 0 (:350-358), which holds for a tensor that starts its
+        allocation; a tensor the caching allocator carved out of a larger segment needs the segment's base."""
         L = lib()
-        n = L.sglk_ipc_handle_bytes()
-        buf = (C.c_char * n)()
+        buf = (C.c_char * L.sglk_ipc_handle_bytes())()
         off = C.c_int64(0)
-        check(L.sglk_ipc_get_handle(local_ptr, buf, C.byref(off)), "ipc_get_handle")
-        mine = (bytes(buf), int(off.value))
-        gathered = [None] * self.world_size
-        dist.all_gather_object(gathered, mine, group=self.group)
-        ptrs = []
-        for r, (h, o) in enumerate(gathered):
-            if r == self.rank:
-                ptrs.append(local_ptr)
-                continue
-            base = L.sglk_ipc_open_handle(h)
-            if not base:
-                check(-1, "ipc_open_handle")
-            self._opened.append(base)
-            ptrs.append(base + o)
-        return ptrs
+        check(L.sglk_ipc_get_handle(inp.data_ptr(), buf, C.byref(off)), "ipc_get_handle")
+        return self._gather_ipc_meta((bytes(buf), int(off.value)))
+
+    def _gather_ipc_meta(self, shard_data):
+        """custom_all_reduce.py:360-382: broadcast_object_list per rank over the CPU group (all_gather_object is not
+        usable with gloo under inference mode)."""
+        all_data = [[None] for _ in range(self.world_size)]
+        all_data[self.rank][0] = shard_data
+        ranks = sorted(dist.get_process_group_ranks(group=self.group))
+        for i, rank in enumerate(ranks):
+            dist.broadcast_object_list(all_data[i], src=rank, group=self.group, device="cpu")
+        handles = [d[0][0] for d in all_data]
+        offsets = [d[0][1] for d in all_data]
+        return handles, offsets
 
     def register_buffer(self, inp: torch.Tensor):
         """custom_all_reduce.py:384-386."""
-        ptrs = self._exchange(inp.data_ptr())
-        arr = (C.c_void_p * self.world_size)(*ptrs)
-        check(lib().sglk_ar_register_buffer(self._ptr, inp.data_ptr(), arr), "ar_register_buffer")
+        handles, offsets = self._get_ipc_meta(inp)
+        self._ops.register_buffer(self._ptr, inp, handles, offsets)
+
+    def register_graph_buffers(self):
+        """custom_all_reduce.py:388-393 (HIP branch)."""
+        handle, offset = self._ops.get_graph_buffer_ipc_meta(self._ptr)
+        handles, offsets = self._gather_ipc_meta((bytes(handle.numpy().tobytes()), offset))
+        self._ops.register_graph_buffers(self._ptr, handles, offsets)
 
     # ---- reductions -------------------------------------------------------------------------------
     def should_custom_ar(self, inp: torch.Tensor) -> bool:
@@ -126,9 +149,15 @@ class CustomAllreduce:
         return out
 
     def custom_all_reduce(self, input: torch.Tensor) -> Optional[torch.Tensor]:
-        """custom_all_reduce.py:475-498: None when this communicator does not take the tensor."""
-        if not self.should_custom_ar(input):
+        """custom_all_reduce.py:475-498: None when this communicator does not take the tensor; inside capture() the
+        captured launch reads the input where it lies (registered after the capture), the warm-up run before the
+        capture only mimics the allocation; outside, the input is copied into the registered staging buffer."""
+        if self.disabled or not self.should_custom_ar(input):
             return None
+        if self._IS_CAPTURING:
+            if torch.cuda.is_current_stream_capturing():
+                return self.all_reduce_reg(input)
+            return torch.empty_like(input)
         return self.all_reduce_unreg(input)
 
     def all_gather_reg(self, inp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -165,20 +194,14 @@ class CustomAllreduce:
                 "then are NaN-filled and this communicator is disabled")
 
     def close(self):
-        L = lib()
         failed = False
         if self._ptr:
             torch.cuda.synchronize()
             failed = not self.failed and bool(self.stuck_blocks())
-            L.sglk_ar_dispose(self._ptr)
+            self._ops.dispose(self._ptr)  # also closes the peer mappings this communicator opened
             self._ptr = 0
             self.disabled = True
-        for p in self._opened:
-            L.sglk_ipc_close(p)
-        self._opened = []
-        if self._meta:
-            L.sglk_free_uncached(self._meta)
-            self._meta = 0
+        self.meta = None  # the tensor owns the uncached allocation
         if failed:
             self.failed = True
             raise SglkError(f"peer-to-peer all-reduce: rank {self.rank} had a barrier time-out that nobody checked for; "

@@ -207,9 +207,12 @@ def decode_attention_shared_prefix(q, k_buffer, v_buffer, o, kv_indptr, kv_indic
 # ------------------------------------------------------------------------------------------- A2
 def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,
                          kv_indices, custom_mask, is_causal, mask_indptr, max_len_extend, sm_scale=None,
-                         logit_cap=0.0, skip_prefix_custom_mask=True, sliding_window_size=-1):
+                         logit_cap=0.0, skip_prefix_custom_mask=True, sliding_window_size=-1, total_prefix=None):
     """Same signature as triton_ops/extend_attention.py:306-438.  With sliding_window_size > 0 the caller lists only the
-    window's prefix tokens in kv_indices (triton_backend.py:75-103) and the reference's window mask applies to them."""
+    window's prefix tokens in kv_indices (triton_backend.py:75-103) and the reference's window mask applies to them.
+    total_prefix (an addition): the number of valid entries of kv_indices (kv_indptr[-1], which the caller knows on the
+    host); without it the size of kv_indices stands in, which overstates the prefix of an over-allocated index buffer
+    and may pick the split + merge form where the plain kernel would do (same result, one launch more)."""
     _need_gpu(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr, kv_indices)
     T, Hq, D = q_extend.shape
     Hkv, Dv = v_extend.shape[1], v_extend.shape[2]
@@ -244,7 +247,9 @@ def extend_attention_fwd(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buf
             int(max_len_extend), float(sm_scale), float(logit_cap), _attn_dtype(q_extend, k_buffer, v_buffer),
             _stream(q_extend)), "extend_attention_masked")
         return
-    splits = extend_attention_split_plan(T, Hq, B, max_len_extend, kv_indices.numel() if kv_indptr.numel() > 1 else 0, D,
+    if total_prefix is None:
+        total_prefix = kv_indices.numel() if kv_indptr.numel() > 1 else 0
+    splits = extend_attention_split_plan(T, Hq, B, max_len_extend, int(total_prefix), D,
                                          q_extend.dtype) if (D == Dv and k_buffer is not None) else 1
     if splits > 1:
         return extend_attention_split(q_extend, k_extend, v_extend, o_extend, k_buffer, v_buffer, qo_indptr, kv_indptr,

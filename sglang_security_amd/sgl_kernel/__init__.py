@@ -257,6 +257,28 @@ def merge_state_v2(v_a: torch.Tensor, s_a: torch.Tensor, v_b: torch.Tensor, s_b:
 merge_state = merge_state_v2  # attention.py:12-28: same contract, older kernel
 
 
+# ---- allreduce.py (ROCm branch, :5-50) --------------------------------------------------------------------------
+_ALLREDUCE = ("init_custom_ar", "all_reduce_reg", "all_reduce_unreg", "dispose", "meta_size", "register_buffer",
+              "get_graph_buffer_ipc_meta", "register_graph_buffers", "allocate_meta_buffer", "get_meta_buffer_ipc_handle")
+__all__ += list(_ALLREDUCE)
+
+
+def __getattr__(name: str):
+    # The all-reduce functions live in the `allreduce` submodule, which loads common_ops.so (torch op registrations
+    # from C++) when first imported; importing it lazily keeps `import sgl_kernel` free of that side effect until a
+    # communicator is built, and `from sgl_kernel import init_custom_ar` / `sgl_kernel.allreduce.*` both work, as with
+    # the reference package (python/sgl_kernel/__init__.py:15).
+    if name in _ALLREDUCE or name == "allreduce":
+        import importlib
+
+        mod = importlib.import_module(__name__ + ".allreduce")
+        return mod if name == "allreduce" else getattr(mod, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
 def install(name: str = "sgl_kernel") -> None:
     """Make `import sgl_kernel` resolve to this module (the hook a deployment uses to swap the kernels in)."""
     sys.modules[name] = sys.modules[__name__]
+    import importlib
+
+    sys.modules[name + ".allreduce"] = importlib.import_module(__name__ + ".allreduce")

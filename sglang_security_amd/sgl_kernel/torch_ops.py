@@ -7,9 +7,13 @@ here torch.library does the same from Python and the implementations call libsgl
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import ops as _ops
+
+COMMON_OPS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "common_ops.so")
 
 _SCHEMAS = {
     "awq_dequantize": "(Tensor qweight, Tensor scales, Tensor qzeros) -> Tensor",
@@ -80,12 +84,47 @@ _IMPLS = {
 }
 
 
+# Shape functions for the "Meta" key: what a tracer (torch.compile, FakeTensorMode, make_fx) needs to see through an
+# op without running it.  The in-place ops (`Tensor!` arguments, no result) have nothing to compute.
+def _meta_awq_dequantize(qweight, scales, qzeros):
+    return scales.new_empty((qweight.shape[0], qweight.shape[1] * 8))
+
+
+def _meta_scaled_mm(a, b, sa, sb, dt, bias=None):
+    return a.new_empty((a.shape[0], b.shape[1]), dtype=dt)
+
+
+def _meta_moe_fused_gate(x, bias, ng, tg, k, ns, rs):
+    return [x.new_empty((x.shape[0], k), dtype=torch.float32), x.new_empty((x.shape[0], k), dtype=torch.int32)]
+
+
+def _meta_awq_gemm(x, packed, scales, qzeros, bias, ws):
+    return x.new_empty(x.shape[:-1] + (scales.shape[-1],))
+
+
+_META = {
+    "awq_dequantize": _meta_awq_dequantize,
+    "fp8_scaled_mm": _meta_scaled_mm,
+    "fp8_blockwise_scaled_mm": _meta_scaled_mm,
+    "moe_fused_gate": _meta_moe_fused_gate,
+    "awq_gemm": _meta_awq_gemm,
+}
+
+
 def register_torch_ops() -> None:
     global _lib
     if _lib is not None:
         return
+    from .._lib import lib as _load_libsglk
+
     lib = torch.library.Library("sgl_kernel", "FRAGMENT")
     for name, schema in _SCHEMAS.items():
         lib.define(name + schema)
         lib.impl(name, _IMPLS[name], "CUDA")
+        lib.impl(name, _META.get(name, lambda *a, **k: None), "Meta")
     _lib = lib  # keep the registrations alive
+    # the all-reduce op set (torch_extension_rocm.cc:25-55) comes from C++: see csrc/torch/allreduce_ops.cc
+    if not os.path.exists(COMMON_OPS):
+        raise ImportError(f"{COMMON_OPS} is missing: run `python -m sglang_security_amd.build`")
+    _load_libsglk()  # common_ops.so links against libsglk.so: have it mapped first
+    torch.ops.load_library(COMMON_OPS)

@@ -91,6 +91,46 @@ def test_sgl_kernel_mirror_matches_the_reference():
     assert not bad, "\n".join(bad)
     for fname, lacking in missing.items():
         assert lacking == SGL_KERNEL_NOT_MIRRORED[fname], (fname, sorted(lacking ^ SGL_KERNEL_NOT_MIRRORED[fname]))
+    # the ROCm all-reduce surface is defined under `if torch.version.hip` in the reference: the extractor must see it
+    assert set(API["sgl_kernel"]["allreduce.py"]) == {
+        "init_custom_ar", "all_reduce_reg", "all_reduce_unreg", "dispose", "meta_size", "register_buffer",
+        "get_graph_buffer_ipc_meta", "register_graph_buffers", "allocate_meta_buffer", "get_meta_buffer_ipc_handle"}
+
+
+def test_allreduce_torch_ops_carry_the_reference_schemas():
+    """torch_extension_rocm.cc:25-55: the ops exist under torch.ops.sgl_kernel with the reference's schemas (the
+    schema strings of that file, as data), and the Python-registered ops answer on the Meta key."""
+    import torch
+
+    import sglang_security_amd.sgl_kernel.allreduce  # noqa: F401  (loads common_ops.so)
+
+    want = {
+        "init_custom_ar": "sgl_kernel::init_custom_ar(Tensor meta, Tensor rank_data, str[] handles, int[] offsets, int rank, bool full_nvlink) -> int",
+        "all_reduce_reg": "sgl_kernel::all_reduce_reg(int fa, Tensor inp, Tensor! out) -> ()",
+        "all_reduce_unreg": "sgl_kernel::all_reduce_unreg(int fa, Tensor inp, Tensor reg_buffer, Tensor! out) -> ()",
+        "register_buffer": "sgl_kernel::register_buffer(int fa, Tensor t, str[] handles, int[] offsets) -> ()",
+    }
+    def shape(schema):
+        return ([(a.name, str(a.type), bool(a.alias_info and a.alias_info.is_write)) for a in schema.arguments],
+                [str(r.type) for r in schema.returns])
+
+    for name, schema in want.items():
+        assert shape(getattr(torch.ops.sgl_kernel, name).default._schema) == shape(torch._C.parse_schema(schema)), name
+    for name in ("dispose", "meta_size", "get_graph_buffer_ipc_meta", "register_graph_buffers", "allocate_meta_buffer",
+                 "get_meta_buffer_ipc_handle"):
+        assert hasattr(torch.ops.sgl_kernel, name)
+    assert torch.ops.sgl_kernel.meta_size.default() > 0
+    # fake / meta registrations of the Python-registered ops
+    qw = torch.empty(256, 16, dtype=torch.int32, device="meta")
+    sc = torch.empty(2, 128, dtype=torch.float16, device="meta")
+    assert torch.ops.sgl_kernel.awq_dequantize(qw, sc, qw).shape == (256, 128)
+    a = torch.empty(7, 64, dtype=torch.float8_e4m3fn, device="meta")
+    b = torch.empty(64, 32, dtype=torch.float8_e4m3fn, device="meta")
+    s1 = torch.empty(7, dtype=torch.float32, device="meta")
+    out = torch.ops.sgl_kernel.fp8_scaled_mm(a, b, s1, s1, torch.bfloat16, None)
+    assert out.shape == (7, 32) and out.dtype == torch.bfloat16
+    x = torch.empty(3, 64, dtype=torch.bfloat16, device="meta")
+    assert torch.ops.sgl_kernel.rmsnorm(x, x, x[0], 1e-6, False) is None
 
 
 def _class_cases():
@@ -114,11 +154,10 @@ def _class_cases():
                         "pretty_print", "total_size", "evict", "inc_lock_ref", "dec_lock_ref", "evictable_size",
                         "protected_size", "all_values_flatten", "take_events"], set()),
         "CustomAllreduce": (CustomAllreduce,
-                            ["__init__", "should_custom_ar", "all_reduce_reg", "all_reduce_unreg", "custom_all_reduce",
-                             "register_buffer", "close"],
-                            # graph-buffer registration by capture scope and the NVIDIA shared-buffer path
-                            {"capture", "register_graph_buffers", "create_shared_buffer", "free_shared_buffer",
-                             "all_reduce"}),
+                            ["__init__", "capture", "should_custom_ar", "all_reduce_reg", "all_reduce_unreg",
+                             "custom_all_reduce", "register_buffer", "register_graph_buffers", "close"],
+                            # the NVIDIA shared-buffer path (cudaMalloc + cudaIpc through CudaRTLibrary)
+                            {"create_shared_buffer", "free_shared_buffer", "all_reduce"}),
         "GroupCoordinator": (GroupCoordinator,
                              ["all_reduce", "reduce_scatter", "all_gather_into_tensor", "all_gather", "barrier", "destroy"],
                              # control plane (object / tensor-dict broadcast, point-to-point, pipeline neighbours)

@@ -62,6 +62,49 @@ for rep in range(3):
         fails.append(("graph", rep, float(out.float().mean())))
     dist.barrier()
 assert comm.custom_all_reduce(torch.zeros(3, device="cuda")) is None  # 12 bytes: not a multiple of 16
+# the reference's graph path (custom_all_reduce.py:335-348, 388-393, 475-498): inputs nobody registered, captured inside
+# capture(); leaving the context exchanges their handles (register_graph_buffers) and only then may the graph run
+ins = [(torch.randn(3, 8192, generator=torch.Generator().manual_seed(500 + r)) * 4).to(torch.bfloat16) for r in range(world)]
+xg = torch.empty(3, 8192, dtype=torch.bfloat16, device="cuda")
+g2 = torch.cuda.CUDAGraph()
+with comm.capture():
+    with torch.cuda.stream(s):
+        w = comm.custom_all_reduce(xg)          # warm-up before the capture: mimics the allocation only
+        assert w is not None and w.shape == xg.shape
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g2, stream=s):
+            o1 = comm.custom_all_reduce(xg)
+            mid = o1 * 1                        # an input that lives in the graph's own memory pool
+            o2 = comm.custom_all_reduce(mid)
+assert int(comm._ops.get_graph_buffer_ipc_meta(comm._ptr)[0].numel()) == 0   # both inputs are registered now
+dist.barrier()
+for rep in range(2):
+    scale = float(rep + 1)
+    xg.copy_((ins[rank] * scale).to(torch.bfloat16))
+    torch.cuda.synchronize()
+    dist.barrier()
+    g2.replay()
+    torch.cuda.synchronize()
+    want1 = oracle.allreduce_sum([(t * scale).to(torch.bfloat16).reshape(-1) for t in ins], torch.bfloat16)
+    want2 = oracle.allreduce_sum([want1] * world, torch.bfloat16)
+    if not torch.equal(o1.cpu().reshape(-1).view(torch.uint8), want1.view(torch.uint8)):
+        fails.append(("capture", rep, 1))
+    if not torch.equal(o2.cpu().reshape(-1).view(torch.uint8), want2.view(torch.uint8)):
+        fails.append(("capture", rep, 2))
+    dist.barrier()
+# an unregistered input outside a capture is an error, as in the reference (custom_all_reduce_hip.cuh:528-531)
+try:
+    comm.all_reduce_reg(torch.zeros(64, dtype=torch.bfloat16, device="cuda"))
+    fails.append(("unregistered input accepted",))
+except RuntimeError:
+    pass
+# the reference binding's argument checks (custom_all_reduce.hip:18-27)
+try:
+    comm._ops.init_custom_ar(comm.meta, comm.rank_data, [b"x" * 64] * 3, [0, 0, 0], 0, True)
+    fails.append(("odd world accepted",))
+except Exception as e:
+    if "Odd num gpus" not in str(e):
+        fails.append(("odd world", str(e)[:80]))
 # all-gather of registered inputs, eager and default algorithm all-reduce of the same buffer afterwards
 part = torch.full((3, 520), float(rank), dtype=torch.bfloat16, device="cuda")
 comm.register_buffer(part)

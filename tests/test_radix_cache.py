@@ -303,6 +303,88 @@ def test_fixed_mode_returns_orphaned_slots():
     assert sorted(int(t) for f in alloc.freed for t in f) == list(range(1, 31))
 
 
+class CountingAlloc(Alloc):
+    """An allocator stand-in that hands slots out and notices a slot returned twice."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.free_list = list(range(1, n + 1))
+
+    def alloc(self, n):
+        out, self.free_list = self.free_list[:n], self.free_list[n:]
+        assert len(out) == n, "pool exhausted"
+        return torch.tensor(out, dtype=torch.int64)
+
+    def free(self, idx):
+        super().free(idx)
+        self.free_list.extend(int(t) for t in torch.as_tensor(idx).reshape(-1))
+
+
+@pytest.mark.parametrize("users", [("alice", "alice", "alice"), ("alice", "bob", "alice")])
+def test_fixed_mode_request_cycles_share_prefix_slots(users):
+    """compat_fork="fixed" through the scheduler's own life cycle (match_prefix -> inc_lock_ref -> cache_finished_req,
+    radix_cache.py:160-197 of the reference): a finishing request inserts its whole req_to_token row, prefix slots
+    included, and at the private root that insert overwrites the very child it matched.  The overwritten child's slots
+    that the new node names again belong to the new node: no slot still in the tree may reach the allocator, and no
+    slot may reach it twice."""
+    alloc, pool = CountingAlloc(4096), ReqPool(rows=4, width=512)
+    tree = RadixCache(pool, alloc, 1, Judge(), get_epoch_fn=lambda: 0)
+    base = list(range(1000, 1100))
+    for i, user in enumerate(users):
+        toks = base + [5000 + 10 * i + j for j in range(20)]
+        r = Req(f"r{i}", toks, user)
+        r.req_pool_idx = i
+        v, node = tree.match_prefix(rid=r.rid, user_id=user, key=toks[:-1])
+        r.prefix_indices, r.last_node = v, node
+        tree.inc_lock_ref(node)
+        pool.write((i, slice(0, len(v))), v.to(torch.int32))
+        fresh = alloc.alloc(len(toks) - len(v))
+        pool.write((i, slice(len(v), len(toks))), fresh.to(torch.int32))
+        r.output_ids = [7]
+        tree.cache_finished_req(r)
+        tree.evict(0)  # drains the free queue into the allocator
+        live = set(tree.all_values_flatten().tolist())
+        assert len(alloc.free_list) == len(set(alloc.free_list)), "a slot was returned twice"
+        assert not (live & set(alloc.free_list)), "a slot the tree still maps went back to the allocator"
+        assert tree.evictable_size() == tree.total_size() and tree.protected_size() == 0
+        # conservation: every slot is either in the tree or in the allocator
+        assert len(live) + len(alloc.free_list) == 4096
+    tree.evict(10 ** 9)
+    assert sorted(alloc.free_list) == list(range(1, 4097))
+
+
+def test_grace_node_survives_later_matches_until_locked():
+    """The hit-rate release can cut off the very node match_prefix returns (radix_cache.py:385-411).  The scheduler
+    matches many requests before it locks one, so that node must still resolve when inc_lock_ref arrives: the lock walks
+    up from it into the live ancestors, as the reference does with its dead TreeNode object."""
+    epoch = [0]
+    alloc = Alloc()
+    tree = RadixCache(None, alloc, 1, Judge(), compat_fork=True, get_epoch_fn=lambda: epoch[0])
+    a, b = list(range(10, 50)), list(range(10, 50)) + list(range(200, 230))
+    tree.insert(a, torch.arange(1, 41), user_id="0")
+    tree.insert(b, torch.arange(1, 71), user_id="0")
+    # window 0: one hit on the leaf; window 1: enough hits by one user to trip the release
+    tree.match_prefix(b, user_id="0")
+    epoch[0] = 1
+    tree.match_prefix(b, user_id="0")  # rolls the window: hit_pre = 1, u_cnt_pre = 1
+    node = None
+    for _ in range(40):
+        v, node = tree.match_prefix(b, user_id="0")
+        if not any(d["key"] == list(range(200, 230)) for d in tree.dump()):
+            break
+    else:
+        pytest.skip("release did not trigger with this script")
+    assert node.alive
+    tree.match_prefix(list(range(900, 910)), user_id="0")  # other requests are matched before the lock arrives
+    tree.match_prefix(a, user_id="0")
+    assert node.alive
+    before = tree.protected_size()
+    tree.inc_lock_ref(node)
+    assert tree.protected_size() > before  # the live ancestors on the returned prefix are now protected
+    tree.dec_lock_ref(node)
+    assert tree.protected_size() == before
+
+
 @pytest.mark.gpu
 def test_traces_on_the_gpu_box():
     """The trace suite again under the gpu marker: the native tree is host code, but this puts the bit-exact radix

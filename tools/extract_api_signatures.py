@@ -42,9 +42,24 @@ def params(fn: ast.FunctionDef):
     return out
 
 
+def _is_hip_test(test) -> bool:
+    """`torch.version.hip is not None` (how sgl_kernel/allreduce.py:5 selects its ROCm definitions)."""
+    return "torch.version.hip" in ast.unparse(test)
+
+
 def module_functions(path):
+    """Top-level functions, plus those defined under a module-level `if torch.version.hip ...:` -- the ROCm branch is
+    the interface this package mirrors; the `else:` (NVIDIA) branch of such a test is left out."""
     tree = ast.parse(open(path).read())
-    return {n.name: {"line": n.lineno, "params": params(n)} for n in tree.body if isinstance(n, ast.FunctionDef)}
+    out = {}
+    for n in tree.body:
+        if isinstance(n, ast.FunctionDef):
+            out[n.name] = {"line": n.lineno, "params": params(n)}
+        elif isinstance(n, ast.If) and _is_hip_test(n.test):
+            for m in n.body:
+                if isinstance(m, ast.FunctionDef):
+                    out[m.name] = {"line": m.lineno, "params": params(m), "branch": "torch.version.hip"}
+    return out
 
 
 def class_methods(path, cls):
