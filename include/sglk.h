@@ -124,6 +124,49 @@ SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const vo
  * (absorbed MLA 576 / 512 with the values a view of the key rows, head size 64, fp32) is routed to the per-request
  * kernels over the same lists with max_kv_splits splits per request, their partials in the workspace: the same result,
  * a group's shared rows fetched once per request (from L2 after the first). */
+/* The per-step plan of the shared-prefix kernel.  A decode step calls the kernel once per layer over the same
+ * request table, so the groups, every request's remainder range and every prefix block's slot range, column owners
+ * and first pool slots are resolved once per step, ON THE DEVICE, into `plan` (sglk_decode_shared_plan_bytes() bytes,
+ * 16-byte aligned, contents rewritten by every plan call: the fixed-address metadata a captured graph replays over,
+ * python/sglang/srt/model_executor/cuda_graph_runner.py:491-533).  B <= 1024.
+ *   sglk_decode_shared_plan: groups are found from the table itself -- requests whose lists start with the same
+ *     pool slot matched the same radix-tree node (mem_cache/radix_cache.py:120-150 hands every such request the same
+ *     slots); a group's shared length is the longest slot prefix common to all its members, the newest token
+ *     excluded.  Members need not be neighbours in the batch.  Groups of one request, and groups sharing fewer than
+ *     min_share slots (0: 32), take no prefix blocks.  One level: requests that share a short system prompt and, in
+ *     sub-groups, longer prefixes form ONE group with the short length.
+ *   sglk_decode_shared_plan_from_groups: the caller's groups (group_indptr / prefix_lens as for
+ *     sglk_decode_attention_shared_prefix, members contiguous), kept as given.
+ *   sglk_decode_metadata_shared: sglk_decode_metadata followed by sglk_decode_shared_plan, one call for the
+ *     backend's init_forward_metadata / ..._replay_cuda_graph (triton_backend.py:281-337,627-730).
+ *   sglk_decode_attention_shared_planned: the kernel of sglk_decode_attention_shared_prefix_xs driven by a plan
+ *     (same workspace, same result).  Its grid depends on B and the head counts only, never on the groups.
+ *     num_kv_splits (may be NULL): the per-request split counts of sglk_decode_metadata.  When given, the per-request
+ *     kernels of sglk_decode_attention are launched as well, and a word of the plan decides ON THE DEVICE which of
+ *     the two forms works and which leaves at once: a batch in which no group shares anything is walked per request
+ *     with those split counts (what a caller that cannot read the plan back, such as a captured graph, needs). */
+SGLK_API int64_t sglk_decode_shared_plan_bytes(int B, int Hq, int Hkv, int max_kv_splits);
+SGLK_API int sglk_decode_shared_plan(const int32_t* req_to_token, int64_t row_stride,
+                                     const void* req_pool_indices, int idx_is64, const void* seq_lens,
+                                     int lens_is64, const int32_t* kv_indptr, const int32_t* kv_indices, int B,
+                                     int Hq, int Hkv, int max_kv_splits, int min_share, int32_t* plan,
+                                     void* stream);
+SGLK_API int sglk_decode_shared_plan_from_groups(const int32_t* kv_indptr, const int32_t* kv_indices,
+                                                 const int32_t* group_indptr, const int32_t* prefix_lens, int G,
+                                                 int B, int Hq, int Hkv, int max_kv_splits, int32_t* plan,
+                                                 void* stream);
+SGLK_API int sglk_decode_metadata_shared(const int32_t* req_to_token, int64_t row_stride,
+                                         const void* req_pool_indices, int idx_is64, const void* seq_lens,
+                                         int lens_is64, int32_t* kv_indptr, int32_t* kv_indices,
+                                         int32_t* num_kv_splits, int bs, int num_head, int num_kv_head,
+                                         int max_kv_splits, int device_core_count, int min_share, int32_t* plan,
+                                         void* stream);
+SGLK_API int sglk_decode_attention_shared_planned(
+    const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, const int32_t* plan, float* workspace, int max_kv_splits, int B, int Hq, int Hkv,
+    int D, int Dv, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+    int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+    float logit_cap, int dtype, float* xsum_out, int64_t xs_stride, const int32_t* num_kv_splits, void* stream);
 SGLK_API int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits);
 SGLK_API int sglk_decode_shared_workspace_init(void* workspace, int B, int Hq, void* stream);
 SGLK_API int sglk_decode_shared_workspace_status(const void* workspace, int B, int Hq);

@@ -17,12 +17,16 @@ It reads the same fields of the objects the reference passes around:
                  .generate_attn_arg_prefill)
   layer        : .layer_id, .tp_q_head_num, .tp_k_head_num, .qk_head_dim, .v_head_dim, .scaling, .logit_cap
 
-One extension: when `forward_batch.prefix_groups = (group_indptr, prefix_lens)` is set (the radix-tree hit the
-scheduler found: requests of a group share their first prefix_lens slots), decode takes the shared-prefix
-kernel, which reads that part of the KV pool once per group.
+Decode batches take the shared-prefix kernel without being told anything beyond what the reference backend is told:
+the metadata call (eager, graph capture and graph replay alike) finds, on the device and at fixed addresses, the groups
+of requests whose req_to_token rows start with the same pool slots -- the radix-tree hit RadixCache.match_prefix handed
+them -- and lays the step's work out for the kernel, which reads a group's shared part of the KV pool once.  A batch in
+which nobody shares anything is walked per request (the device decides; see ops.decode_attention_shared_planned).
+`share_prefix=False` (or SGLK_SHARE_PREFIX=0) keeps every batch on the per-request kernel.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -44,8 +48,9 @@ class ForwardMetadata:
     qo_indptr: Optional[torch.Tensor]
     custom_mask: Optional[torch.Tensor] = None
     mask_indptr: Optional[torch.Tensor] = None
-    prefix_groups: Optional[tuple] = None
+    shared_plan: Optional[torch.Tensor] = None       # the step's plan of the shared-prefix kernel (device resident)
     shared_workspace: Optional[torch.Tensor] = None
+    total_prefix: Optional[int] = None               # extend: entries of kv_indices in use
     # sliding-window layers (triton_backend.py:146-148)
     window_kv_indptr: Optional[torch.Tensor] = None
     window_kv_indices: Optional[torch.Tensor] = None
@@ -53,8 +58,14 @@ class ForwardMetadata:
 
 
 class SglkAttnBackend:
-    def __init__(self, model_runner, skip_prefill: bool = False, kv_indptr_buf: Optional[torch.Tensor] = None):
+    def __init__(self, model_runner, skip_prefill: bool = False, kv_indptr_buf: Optional[torch.Tensor] = None,
+                 share_prefix: Optional[bool] = None):
         self.device = model_runner.device
+        if share_prefix is None:
+            share_prefix = os.environ.get("SGLK_SHARE_PREFIX", "1") != "0"
+        self.share_prefix = bool(share_prefix)
+        self.kv_pool = getattr(model_runner, "token_to_kv_pool", None)
+        self._pool_16bit = None  # found on first use: an fp8 pool has no one-launch shared-prefix kernel
         self.req_to_token = model_runner.req_to_token_pool.req_to_token
         max_bs = self.req_to_token.shape[0]
         self.kv_indptr = kv_indptr_buf if kv_indptr_buf is not None else torch.zeros(
@@ -110,6 +121,23 @@ class SglkAttnBackend:
     def _shared_workspace(self, bs: int):
         return ops.decode_shared_workspace(bs, self.num_head, self.v_head_dim, self.max_kv_splits, self.device)
 
+    def _shares(self, bs: int) -> bool:
+        """Whether decode batches of bs requests go through the plan + shared-prefix kernel (16-bit pools of head
+        size 128 have the one-launch kernel; a plan covers up to 1024 requests; 16 splits at most)."""
+        if self._pool_16bit is None:
+            try:
+                self._pool_16bit = self.kv_pool.get_key_buffer(0).dtype in (torch.float16, torch.bfloat16)
+            except Exception:
+                self._pool_16bit = False
+        return (self.share_prefix and self._pool_16bit and self.head_dim == 128 and self.v_head_dim == 128
+                and 0 < bs <= 1024 and self.max_kv_splits <= 16 and not self.sliding_window_size)
+
+    def _plan_buffer(self, max_bs: int):
+        """Room for the plan of any batch of up to max_bs requests (the size is not monotonic in the batch size)."""
+        need = max(int(lib().sglk_decode_shared_plan_bytes(b, self.num_head, self.num_kv_head, self.max_kv_splits))
+                   for b in range(1, max_bs + 1))
+        return torch.zeros(need // 4, dtype=torch.int32, device=self.device)
+
     def init_forward_metadata(self, forward_batch):
         """triton_backend.py:271-446."""
         bs = forward_batch.batch_size
@@ -118,6 +146,7 @@ class SglkAttnBackend:
         mode = forward_batch.forward_mode
         is_mode = lambda name: bool(getattr(mode, name, lambda: False)())
         if mode.is_decode_or_idle():
+            plan = None
             if spec_info is None:
                 ops.kv_indptr_cumsum(forward_batch.seq_lens, kv_indptr)
                 kv_indptr = kv_indptr[: bs + 1]
@@ -129,10 +158,13 @@ class SglkAttnBackend:
                 bs = kv_indptr.shape[0] - 1
             attn_logits, attn_lse, num_kv_splits = self._decode_buffers(bs)
             self.get_num_kv_splits(num_kv_splits, forward_batch.seq_lens)
-            groups = getattr(forward_batch, "prefix_groups", None) if spec_info is None else None
+            if spec_info is None and self._shares(bs):
+                plan = ops.decode_shared_plan_buffer(bs, self.num_head, self.num_kv_head, self.max_kv_splits, self.device)
+                ops.decode_shared_plan(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
+                                       kv_indices, self.num_head, self.num_kv_head, self.max_kv_splits, plan)
             self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
-                                                    None, prefix_groups=groups,
-                                                    shared_workspace=self._shared_workspace(bs) if groups else None)
+                                                    None, shared_plan=plan,
+                                                    shared_workspace=self._shared_workspace(bs) if plan is not None else None)
             if self.sliding_window_size and spec_info is None:  # :297-316
                 wp, wi, wl = self._window_lists(forward_batch.seq_lens, forward_batch.req_pool_indices, bs)
                 wsplits = torch.empty((bs,), dtype=torch.int32, device=self.device)
@@ -185,7 +217,8 @@ class SglkAttnBackend:
         ops.kv_indptr_cumsum(forward_batch.extend_seq_lens, qo_indptr)
         qo_indptr = qo_indptr[: bs + 1]
         max_extend_len = int(forward_batch.extend_seq_lens.max().item())
-        self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr)
+        self.forward_metadata = ForwardMetadata(None, None, max_extend_len, None, kv_indptr, kv_indices, qo_indptr,
+                                                total_prefix=total_prefix)
         if self.sliding_window_size:  # :412-421: the window over the cached prefix
             wp, wi, _ = self._window_lists(forward_batch.extend_prefix_lens, forward_batch.req_pool_indices, bs)
             self.forward_metadata.window_kv_indptr, self.forward_metadata.window_kv_indices = wp, wi
@@ -198,6 +231,7 @@ class SglkAttnBackend:
         self.cuda_graph_kv_indices = kv_indices_buf if kv_indices_buf is not None else torch.zeros(
             (max_bs * self.max_context_len,), dtype=torch.int32, device=self.device)
         self.cuda_graph_shared_workspace = self._shared_workspace(max_bs)
+        self.cuda_graph_shared_plan = self._plan_buffer(min(max_bs, 1024)) if self._shares(1) else None
         if self.sliding_window_size:  # :480-490 (window + 1 slots per request: what update_sliding_window_buffer lists)
             self.cuda_graph_window_kv_indices = torch.zeros((max_bs * (self.sliding_window_size + 1),), dtype=torch.int32,
                                                             device=self.device)
@@ -206,17 +240,17 @@ class SglkAttnBackend:
 
     def init_forward_metadata_capture_cuda_graph(self, bs: int, num_tokens: int, req_pool_indices: torch.Tensor,
                                                  seq_lens: torch.Tensor, encoder_lens=None, forward_mode=None,
-                                                 spec_info=None, prefix_groups=None):
+                                                 spec_info=None):
         """triton_backend.py:494-625 (decode only)."""
         if forward_mode is not None and not forward_mode.is_decode_or_idle():
             raise SglkError("graph capture is implemented for decode batches")
-        ops.decode_metadata(self.req_to_token, req_pool_indices, seq_lens, self.kv_indptr, self.cuda_graph_kv_indices,
-                            self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head, self.max_kv_splits,
-                            self.device_core_count)
+        plan = self.cuda_graph_shared_plan if (spec_info is None and self._shares(bs)) else None
+        self._graph_metadata(bs, req_pool_indices, seq_lens, plan)
         self.forward_metadata = ForwardMetadata(self.cuda_graph_attn_logits, self.cuda_graph_attn_lse, None,
                                                 self.cuda_graph_num_kv_splits, self.kv_indptr, self.cuda_graph_kv_indices,
-                                                None, prefix_groups=prefix_groups,
-                                                shared_workspace=self.cuda_graph_shared_workspace)
+                                                None, shared_plan=plan,
+                                                shared_workspace=self.cuda_graph_shared_workspace if plan is not None else None)
+        self._graph_plan_bs = bs if plan is not None else None
         if self.sliding_window_size:  # :523-541
             wp, wi, wl = self._window_lists(seq_lens, req_pool_indices, bs, self.cuda_graph_window_kv_indices)
             self.get_num_kv_splits(self.cuda_graph_window_num_kv_splits[:bs], wl)
@@ -227,13 +261,23 @@ class SglkAttnBackend:
     def init_forward_metadata_replay_cuda_graph(self, bs: int, req_pool_indices: torch.Tensor, seq_lens: torch.Tensor,
                                                 seq_lens_sum: int, encoder_lens=None, forward_mode=None, spec_info=None,
                                                 seq_lens_cpu=None):
-        """triton_backend.py:627-730: rewrite kv_indptr / kv_indices / num_kv_splits in place (one launch)."""
-        ops.decode_metadata(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
-                            self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head,
-                            self.max_kv_splits, self.device_core_count)
+        """triton_backend.py:627-730: rewrite kv_indptr / kv_indices / num_kv_splits -- and the shared-prefix plan: the
+        groups of THIS step's batch -- in place, in one call."""
+        plan = self.cuda_graph_shared_plan if (spec_info is None and self._shares(bs)) else None
+        self._graph_metadata(bs, req_pool_indices, seq_lens, plan)
         if self.sliding_window_size:  # :656-675
             _, _, wl = self._window_lists(seq_lens, req_pool_indices, bs, self.cuda_graph_window_kv_indices)
             self.get_num_kv_splits(self.cuda_graph_window_num_kv_splits[:bs], wl)
+
+    def _graph_metadata(self, bs, req_pool_indices, seq_lens, plan):
+        if plan is not None:
+            ops.decode_metadata_shared(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
+                                       self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head,
+                                       self.num_kv_head, self.max_kv_splits, self.device_core_count, plan)
+        else:
+            ops.decode_metadata(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
+                                self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head,
+                                self.max_kv_splits, self.device_core_count)
 
     def get_cuda_graph_seq_len_fill_value(self):
         return 1
@@ -262,7 +306,7 @@ class SglkAttnBackend:
             forward_batch.token_to_kv_pool.get_key_buffer(layer.layer_id),
             forward_batch.token_to_kv_pool.get_value_buffer(layer.layer_id), md.qo_indptr, kv_indptr, kv_indices,
             md.custom_mask, True, md.mask_indptr, md.max_extend_len, layer.scaling, layer.logit_cap,
-            sliding_window_size=window)
+            sliding_window_size=window, total_prefix=md.total_prefix if window < 0 else None)
         return o
 
     @staticmethod
@@ -287,10 +331,11 @@ class SglkAttnBackend:
                 raise SglkError("sliding-window layer, but model_runner.sliding_window_size was not set")
             ops.decode_attention_fwd(q3, kb, vb, o3, md.window_kv_indptr, md.window_kv_indices, md.attn_logits, md.attn_lse,
                                      md.window_num_kv_splits, self.max_kv_splits, layer.scaling, layer.logit_cap)
-        elif md.prefix_groups is not None:  # every shape: the library routes those without a tile kernel per request
-            gi, pl = md.prefix_groups
-            ops.decode_attention_shared_prefix(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, gi, pl, md.shared_workspace,
-                                               self.max_kv_splits, layer.scaling, layer.logit_cap)
+        elif md.shared_plan is not None and q3.dtype in (torch.float16, torch.bfloat16) and kb.dtype == q3.dtype:
+            # the plan's groups, or (decided on the device) the per-request kernels when nobody shares anything
+            ops.decode_attention_shared_planned(q3, kb, vb, o3, md.kv_indptr[: q3.shape[0] + 1], md.kv_indices,
+                                                md.shared_plan, md.shared_workspace, self.max_kv_splits, layer.scaling,
+                                                layer.logit_cap, num_kv_splits=md.num_kv_splits)
         else:
             ops.decode_attention_fwd(q3, kb, vb, o3, md.kv_indptr, md.kv_indices, md.attn_logits, md.attn_lse,
                                      md.num_kv_splits, self.max_kv_splits, layer.scaling, layer.logit_cap)

@@ -299,8 +299,10 @@ __global__ void __launch_bounds__(128) decode_stage2(const float* __restrict__ a
                                                      const int32_t* __restrict__ kv_indptr,
                                                      const int32_t* __restrict__ num_kv_splits, int max_kv_splits,
                                                      int Hq, int Dv, int64_t o_stride_b, int64_t o_stride_h,
-                                                     float* __restrict__ xsum_out, int64_t xs_stride) {
+                                                     float* __restrict__ xsum_out, int64_t xs_stride,
+                                                     const int32_t* __restrict__ gate = nullptr) {
   __shared__ float xs_red[2];
+  if (gate && *gate != 0) return;  // see decode_stage1_mfma128
   const int b = blockIdx.x, h = blockIdx.y;
   const int len = kv_indptr[b + 1] - kv_indptr[b];
   const int splits = max(num_kv_splits[b], 1);
@@ -388,8 +390,11 @@ __global__ void __launch_bounds__(256, 2) decode_stage1_mfma128(
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits,
     float* __restrict__ attn_lse, const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv,
     int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
-    int64_t v_stride_h, float sm_scale, float logit_cap, int pair64) {
+    int64_t v_stride_h, float sm_scale, float logit_cap, int pair64, const int32_t* __restrict__ gate = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];
+  // gate: a device word that says, when non-zero, that another kernel of the same launch sequence does this work
+  // (the shared-prefix kernel found groups to share); the whole grid then leaves at once
+  if (gate && *gate != 0) return;
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   char* kl = lds_all + wid * kLdsPerWave;
@@ -702,6 +707,276 @@ static constexpr uint64_t kSharedWaitTicks = 200000000ull;  // 2 s of the 100 MH
 static constexpr int kTailDone = 1 << 16;                   // a finished tail block adds this to the pair's counter
 static constexpr int kPrefixPF = 2;                         // prefix tiles in flight per block
 
+// ---------------------------------------------------------------------------------------------
+// The per-step plan of the shared-prefix kernel.  One decode step runs the kernel once per layer over the same
+// request table, so everything that does not depend on the layer is resolved once, on the device, at fixed
+// addresses (a graph replay only rewrites the plan's contents):
+//   * which requests share their first slots (groups), found from the request table itself;
+//   * per request: where its private remainder starts in kv_indices, how long it is, how many prefix partials
+//     its merge has to wait for;
+//   * per prefix block ("item"): the slot range it streams, the request that owns each of its 64 columns, and
+//     the pool slots of its first two tiles -- one trip to memory fetches all of it, the second fetches rows.
+// Layout (int32 words): header[16] | order[Bcap] | tail[Bcap][4] | group_indptr[Bcap + 1] | prefix_lens[Bcap] |
+// leader[Bcap] | lcp[Bcap] | items[max_items][kPlanItemInts] (16-byte aligned).
+// ---------------------------------------------------------------------------------------------
+static constexpr int kPlanHdr = 16;
+static constexpr int kPlanItemInts = 144;   // header[16], column owner[64], first slots[64]
+static constexpr int kPlanMaxB = 1024;      // one block assembles the plan
+enum { kPlanNItems = 0, kPlanNGroups = 1, kPlanB = 2, kPlanHeads = 3, kPlanSplits = 4, kPlanMaxItems = 5 };
+
+__host__ __device__ inline int shared_prefix_splits(int B, int heads, int Hkv, int max_kv_splits) {
+  // enough 64-column blocks to cover the CUs once, as far as max_kv_splits allows
+  const int col_blocks = (B * heads + 63) / 64;
+  const int per = col_blocks * Hkv > 0 ? col_blocks * Hkv : 1;
+  int s = 256 / per;
+  s = s < max_kv_splits ? s : max_kv_splits;
+  return s < 1 ? 1 : s;
+}
+__host__ __device__ inline int plan_max_items(int B, int heads, int splits) {
+  // sum over groups of ceil(columns / 64) <= ceil(B * heads / 64) + (groups that share: at most B / 2)
+  return splits * ((B * heads + 63) / 64 + B / 2 + 1);
+}
+struct PlanView {
+  int32_t *hdr, *order, *tail, *group_indptr, *prefix_lens, *leader, *lcp, *items;
+  int64_t words;
+};
+__host__ __device__ inline PlanView plan_view(int32_t* base, int Bcap, int max_items) {
+  PlanView v;
+  v.hdr = base;
+  v.order = base + kPlanHdr;
+  v.tail = v.order + Bcap;
+  v.group_indptr = v.tail + 4 * (int64_t)Bcap;
+  v.prefix_lens = v.group_indptr + Bcap + 1;
+  v.leader = v.prefix_lens + Bcap;
+  v.lcp = v.leader + Bcap;
+  const int64_t off = ((v.lcp + Bcap - base) + 3) / 4 * 4;
+  v.items = base + off;
+  v.words = off + (int64_t)max_items * kPlanItemInts;
+  return v;
+}
+
+__device__ __forceinline__ int block_min_256(int v, int* red) {
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = min(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const int r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// One block per request: its leader (the first request of the batch whose list starts with the same pool slot --
+// two requests that matched the same radix-tree node hold the same slots) and the length of the slot prefix it
+// shares with that leader, the newest token excluded.
+__global__ void __launch_bounds__(256) shared_plan_lcp_kernel(const int32_t* __restrict__ req_to_token, int64_t row_stride,
+                                                              const void* req_pool_indices, int idx_is64,
+                                                              const void* seq_lens, int lens_is64, int B,
+                                                              int32_t* __restrict__ leader_out,
+                                                              int32_t* __restrict__ lcp_out) {
+  __shared__ int red[256];
+  const int b = blockIdx.x;
+  const int64_t rb = ld_idx(req_pool_indices, idx_is64, b);
+  const int lenb = (int)ld_idx(seq_lens, lens_is64, b);
+  const int32_t* c = req_to_token + rb * row_stride;
+  int lead = b;
+  if (lenb >= 2) {
+    const int fb = c[0];
+    for (int i = threadIdx.x; i < b; i += 256) {
+      const int64_t ri = ld_idx(req_pool_indices, idx_is64, i);
+      if ((int)ld_idx(seq_lens, lens_is64, i) >= 2 && req_to_token[ri * row_stride] == fb) {
+        lead = i;
+        break;
+      }
+    }
+  }
+  lead = block_min_256(lead, red);
+  if (lead == b) {
+    if (threadIdx.x == 0) {
+      leader_out[b] = b;
+      lcp_out[b] = max(lenb - 1, 0);
+    }
+    return;
+  }
+  const int64_t rl = ld_idx(req_pool_indices, idx_is64, lead);
+  const int n = min((int)ld_idx(seq_lens, lens_is64, lead), lenb) - 1;
+  const int32_t* a = req_to_token + rl * row_stride;
+  int first = n;
+  for (int base = 0; base < n; base += 1024) {
+    int mine = n;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = base + (int)threadIdx.x + 256 * u;
+      if (j < n && a[j] != c[j]) mine = min(mine, j);
+    }
+    const int m = block_min_256(mine, red);
+    if (m < n) {
+      first = m;
+      break;
+    }
+  }
+  if (threadIdx.x == 0) {
+    leader_out[b] = lead;
+    lcp_out[b] = first;
+  }
+}
+
+// caller-given groups of adjacent requests -> the (leader, shared length) form the assembly takes
+__global__ void __launch_bounds__(256) shared_plan_from_groups_kernel(const int32_t* __restrict__ group_indptr,
+                                                                      const int32_t* __restrict__ prefix_lens, int G, int B,
+                                                                      int32_t* __restrict__ leader_out,
+                                                                      int32_t* __restrict__ lcp_out) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int lo = 0, hi = G - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (group_indptr[mid] <= b)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  leader_out[b] = group_indptr[lo];
+  lcp_out[b] = prefix_lens[lo];
+}
+
+__device__ __forceinline__ int plan_active_splits(int plen, int prefix_splits) {
+  if (plen <= 0) return 0;
+  const int per_p = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+  return cdiv_i(plen, per_p);
+}
+
+// exclusive scan of v[0 .. n) (n <= 1024) by a block of 1024 threads; returns the total
+__device__ __forceinline__ int block_excl_scan_1024(int* v, int* tmp, int n) {
+  const int t = threadIdx.x;
+  const int x = t < n ? v[t] : 0;
+  tmp[t] = x;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int add = t >= o ? tmp[t - o] : 0;
+    __syncthreads();
+    tmp[t] += add;
+    __syncthreads();
+  }
+  const int total = tmp[1023];
+  if (t < n) v[t] = tmp[t] - x;
+  __syncthreads();
+  return total;
+}
+
+// One block: groups, member order, per-request tail records and the prefix items, from (leader, lcp).
+// single_ok: groups of one request keep their prefix (the caller asked for it); otherwise a request alone in its
+// group, or a group that shares fewer than min_share slots, walks its whole list as a private remainder.
+__global__ void __launch_bounds__(1024) shared_plan_assemble_kernel(const int32_t* __restrict__ kv_indptr,
+                                                                    const int32_t* __restrict__ kv_indices, int B,
+                                                                    int heads, int prefix_splits, int max_items,
+                                                                    int min_share, int single_ok, int32_t* plan_base) {
+  __shared__ int lead[kPlanMaxB], gid[kPlanMaxB], rank[kPlanMaxB], gsize[kPlanMaxB], gplen[kPlanMaxB], ioff[kPlanMaxB],
+      tmp[1024];
+  const PlanView pv = plan_view(plan_base, B, max_items);
+  const int t = threadIdx.x;
+  if (t < B) {
+    lead[t] = pv.leader[t];
+    gsize[t] = lead[t] == t ? 1 : 0;  // for the scan: leaders in batch order number the groups
+  }
+  __syncthreads();
+  const int G = block_excl_scan_1024(gsize, tmp, B);  // gsize[leader] = group index of that leader
+  int my_gid = 0;
+  if (t < B) my_gid = gsize[lead[t]];
+  __syncthreads();
+  if (t < B) {
+    gid[t] = my_gid;
+    gsize[t] = 0;
+    gplen[t] = 0x7fffffff;
+  }
+  __syncthreads();
+  if (t < B) {
+    atomicAdd(&gsize[my_gid], 1);
+    atomicMin(&gplen[my_gid], pv.lcp[t]);
+    int r = 0;
+    for (int i = 0; i < t; ++i) r += lead[i] == lead[t] ? 1 : 0;
+    rank[t] = r;
+  }
+  __syncthreads();
+  int my_plen = 0, my_cbs = 0, my_aps = 0;
+  if (t < G) {
+    my_plen = gplen[t];
+    if ((!single_ok && gsize[t] < 2) || my_plen < min_share) my_plen = 0;
+    my_aps = plan_active_splits(my_plen, prefix_splits);
+    my_cbs = my_plen > 0 ? cdiv_i(gsize[t] * heads, 64) : 0;
+    gplen[t] = my_plen;
+    ioff[t] = my_aps * my_cbs;
+  }
+  __syncthreads();
+  // group starts (member offsets) and item offsets
+  const int my_size = t < G ? gsize[t] : 0;
+  __syncthreads();
+  block_excl_scan_1024(gsize, tmp, G);   // gsize[g] = first member's position in `order`
+  const int n_items = min(block_excl_scan_1024(ioff, tmp, G), max_items);
+  if (t < G) {
+    pv.group_indptr[t] = gsize[t];
+    pv.prefix_lens[t] = my_plen;
+    if (t == G - 1) pv.group_indptr[G] = gsize[t] + my_size;
+  }
+  if (t < B) {
+    const int g = gid[t];
+    pv.order[gsize[g] + rank[t]] = t;
+    const int plen = gplen[g];
+    const int aps = plan_active_splits(plen, prefix_splits);
+    const int start = kv_indptr[t] + plen;
+    // prefix blocks whose 64 columns touch this request (its rank in the group decides the columns)
+    const int pb = ((rank[t] + 1) * heads - 1) / 64 - (rank[t] * heads) / 64 + 1;
+    pv.tail[4 * t + 0] = start;
+    pv.tail[4 * t + 1] = kv_indptr[t + 1] - start;
+    pv.tail[4 * t + 2] = pb * aps;
+    pv.tail[4 * t + 3] = aps;
+  }
+  if (t == 0) {
+    pv.hdr[kPlanNItems] = n_items;
+    pv.hdr[kPlanNGroups] = G;
+    pv.hdr[kPlanB] = B;
+    pv.hdr[kPlanHeads] = heads;
+    pv.hdr[kPlanSplits] = prefix_splits;
+    pv.hdr[kPlanMaxItems] = max_items;
+  }
+  __syncthreads();
+  __threadfence_block();  // `order` is read back below
+  // items of group g: (split, column block) in that order, so that the blocks of one split start together
+  if (t < G && my_plen > 0) {
+    const int per_split = cdiv_i(cdiv_i(my_plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+    const int first_member = pv.order[gsize[t]];
+    for (int k = 0; k < my_aps * my_cbs; ++k) {
+      const int j = ioff[t] + k;
+      if (j >= max_items) break;
+      const int split = k / my_cbs, cb = k % my_cbs;
+      int32_t* it = pv.items + (int64_t)j * kPlanItemInts;
+      it[0] = kv_indptr[first_member];  // every member lists the same slots for the prefix: walk the first one's
+      it[1] = per_split * split;
+      it[2] = min(per_split * (split + 1), my_plen);
+      it[3] = cb;
+      it[4] = split;
+      it[5] = t;
+      it[6] = gsize[t];
+      it[7] = my_size * heads;
+    }
+  }
+  __syncthreads();
+  __threadfence_block();
+  for (int w = t; w < n_items * 128; w += 1024) {
+    int32_t* it = pv.items + (int64_t)(w >> 7) * kPlanItemInts;
+    const int e = w & 127;
+    if (e < 64) {
+      const int col = it[3] * 64 + e;
+      it[16 + e] = col < it[7] ? pv.order[it[6] + col / heads] : -1;
+    } else {
+      int tok = it[1] + (e - 64);
+      tok = tok < it[2] ? tok : it[1];
+      it[80 + (e - 64)] = kv_indices[it[0] + tok];
+    }
+  }
+}
+
 struct SharedWs {
   float* part_o;    // [B * Hq][prefix_splits][128]
   float* part_lse;  // [B * Hq][prefix_splits]
@@ -729,15 +1004,20 @@ __device__ __forceinline__ int active_prefix_splits(int plen, int prefix_splits)
 // ROPE: q is not read; the query rows, and every request's new K / V row, come from the qkv projection's split-K
 // partial sums (qp).  A (request, kv head) pair's tail block (one head tile only) writes the pair's new pool rows
 // before it walks the request's list, whose last entry is that row's slot.
-template <typename T, bool ROPE>
+// PLAN: group_indptr / prefix_lens are not read; plan_hdr, plan_tail and plan_items (the per-step plan above) say what
+// every block does, and the prefix blocks loop over the items (their number varies from step to step, the grid of a
+// captured launch does not).
+template <typename T, bool ROPE, bool PLAN>
 __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const void* __restrict__ q, QkvPartials qp, void* k_buffer, void* v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
-    const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, int num_groups, SharedWs ws,
+    const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, int num_groups,
+    const int32_t* __restrict__ plan_hdr, const int32_t* __restrict__ plan_tail, const int32_t* __restrict__ plan_items,
+    SharedWs ws,
     int prefix_splits, int n_prefix_blocks, int col_blocks, int B, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
     float logit_cap, void* __restrict__ o, int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out,
-    int64_t xs_stride) {
+    int64_t xs_stride, int gated) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];  // 32 KiB: the prefix role's two stages of K + V tiles,
                                                                   // or the tail role's four V tiles
   __shared__ int wait_failed;
@@ -748,7 +1028,74 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   const int heads = Hq / Hkv;
   ATTN_STAMP(0);
 
-  if ((int)blockIdx.x < n_prefix_blocks) {
+  if constexpr (PLAN) {
+    if ((int)blockIdx.x < n_prefix_blocks) {
+      // ---- prefix block (planned): block index = item * Hkv + kvh; items past the grid are taken in further rounds
+      const int kvh = blockIdx.x % Hkv;
+      const int items_per_round = n_prefix_blocks / Hkv;
+      int j = blockIdx.x / Hkv;
+      const int n_items = plan_hdr[kPlanNItems];
+      const int c = wid * 16 + hl;
+      const int frow = threadIdx.x >> 4;
+      while (true) {
+        // One trip: the item's header (uniform address: scalar loads), this lane's column owner and this thread's four
+        // first rows.  The first item is read before n_items is known (its address is inside the plan whatever j is).
+        const int32_t* it = plan_items + (int64_t)j * kPlanItemInts;
+        const int list_off = it[0], t0 = it[1], t1 = it[2], cb = it[3], split = it[4];
+        const int req = it[16 + c];
+        const int pre[4] = {it[80 + frow], it[80 + frow + 16], it[80 + 32 + frow], it[80 + 32 + frow + 16]};
+        if (j >= n_items) break;  // block-uniform
+        const bool ok = req >= 0;
+        const int head = kvh * heads + (cb * 64 + c) % heads;
+        BlockAttn<T, 1> st;
+        st.init();
+        int qpos[1] = {0};
+        const int32_t* const plist = kv_indices + list_off;
+        if constexpr (ROPE) {
+          const int64_t pos = ok ? qp.positions[req] : 0;
+          st.template run<false, true, kPrefixPF>(
+              lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
+              qpos, 0, sm_scale, logit_cap, [&]() { load_q_rotated<T>(st.qf[0], qp, req, pos, head * 128, ok); }, nullptr,
+              pre);
+        } else {
+          st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
+                          : nullptr);
+          st.template run<false, true, kPrefixPF>(
+              lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
+              qpos, 0, sm_scale, logit_cap, typename BlockAttn<T, 1>::NoHook(), nullptr, pre);
+        }
+        const float tot = st.total(0);
+        ATTN_STAMP(1);
+        if (ok) {
+          const float inv = 1.0f / tot;
+          const int ob = (req * Hq + head) * prefix_splits + split;
+          const auto ro = ws.rsrc_o();
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, st.oacc[0][n] * inv), ro,
+                                                   ob * 512 + (16 * n + 4 * g) * 4, 0, kSc1);
+          if (g == 0)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (st.m[0] + log2f(tot)) * 0.6931471805599453f),
+                                                  ws.rsrc_lse(), ob * 4, 0, kSc1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
+        __syncthreads();
+        ATTN_STAMP(2);
+        // one count per request this block's columns touch: the first column of every owner
+        if (threadIdx.x < 64) {
+          const int owner = it[16 + threadIdx.x];
+          const int before = threadIdx.x ? it[16 + threadIdx.x - 1] : -1;
+          if (owner >= 0 && owner != before)
+            __hip_atomic_fetch_add(ws.counters + (int64_t)owner * Hkv + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        j += items_per_round;
+        if (j >= n_items) break;
+      }
+      return;
+    }
+  } else if ((int)blockIdx.x < n_prefix_blocks) {
     // ---- prefix block: index = ((grp * prefix_splits + split) * col_blocks + cb) * Hkv + kvh, so that the blocks of
     // one kv head are congruent modulo Hkv (with 8 kv heads: one XCD and its L2 per kv head)
 #ifdef SGLK_ATTN_PRIO
@@ -832,10 +1179,23 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     pos = qp.positions[b];
     new_slot = ld_idx(qp.loc, qp.loc_is64, b);
   }
-  const int grp = find_group(group_indptr, num_groups, b);
-  const int plen = prefix_lens[grp];
-  const int start = kv_indptr[b] + plen;
-  const int len = kv_indptr[b + 1] - start;
+  int start, len, expect_partials, aps;
+  if constexpr (PLAN) {
+    // gated: a plan without prefix items hands the whole batch to the per-request kernels launched beside this one
+    if (gated && plan_hdr[kPlanNItems] == 0) return;
+    const int4v rec = *reinterpret_cast<const int4v*>(plan_tail + 4 * (int64_t)b);  // uniform address: one scalar load
+    start = rec[0];
+    len = rec[1];
+    expect_partials = rec[2];
+    aps = rec[3];
+  } else {
+    const int grp = find_group(group_indptr, num_groups, b);
+    const int plen = prefix_lens[grp];
+    start = kv_indptr[b] + plen;
+    len = kv_indptr[b + 1] - start;
+    aps = active_prefix_splits(plen, prefix_splits);
+    expect_partials = prefix_blocks_of(b - group_indptr[grp], heads) * aps;
+  }
   const int splits = tail_splits(len, kWavesPerBlock);
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
   const int s0 = per_split * wid;
@@ -880,10 +1240,9 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   }
   ATTN_STAMP(1);
   // ---- wait for the pair's prefix partials
-  const int aps = active_prefix_splits(plen, prefix_splits);
   int* const counter = ws.counters + (int64_t)b * Hkv + kvh;
   if (threadIdx.x == 0) {
-    const int expect = prefix_blocks_of(b - group_indptr[grp], heads) * aps;
+    const int expect = expect_partials;
     int failed = 0;
     if (expect > 0) {
       const uint64_t t_start = wall_clock64();
@@ -1048,12 +1407,12 @@ int sglk_common_prefix_len(const int32_t* req_to_token, int64_t row_stride, cons
   return SGLK_OK;
 }
 
-int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+static int decode_attention_impl(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
                              const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
                              int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
                              int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
                              int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
-                             int dtype, float* xsum_out, int64_t xs_stride, void* stream) {
+                             int dtype, float* xsum_out, int64_t xs_stride, void* stream, const int32_t* gate) {
   const int kvf = dtype >> SGLK_KV_SHIFT;  // fp8 pool format, 0: pool elements of the query type
   dtype &= (1 << SGLK_KV_SHIFT) - 1;
   SGLK_CHECK(kvf == 0 || dtype == SGLK_F16 || dtype == SGLK_BF16, "decode_attention: an fp8 pool needs fp16 / bf16 queries");
@@ -1086,6 +1445,7 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
   const bool fast8 = kvf != 0 && D == 128 && Dv == 128 && aligned16(q) && al8(k_buffer) && al8(v_buffer) &&
                      aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
                      (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) && (v_stride_h % 8 == 0);
+  SGLK_CHECK(!gate || fast, "decode_attention: a gated launch needs the 16-bit head-size-128 kernel");
   if (fast8) {
     const int head_tiles = (group + 15) / 16;
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -1130,7 +1490,7 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
                        hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer,
                                           v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
                                           max_kv_splits, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,
-                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, 0));
+                                          k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, 0, gate));
   } else if (pair64) {
     // head size 64 on the 128-wide tile kernel: Hkv / 2 pairs of kv heads, 2 * group query heads per pair
     const int head_tiles = (2 * group + 15) / 16;
@@ -1176,9 +1536,21 @@ int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_
   SGLK_DISPATCH_FLOAT(dtype, T,
                       hipLaunchKernelGGL((decode_stage2<T>), dim3(B, Hq), dim3(128), 0, s, attn_logits, attn_lse, o,
                                          kv_indptr, num_kv_splits, max_kv_splits, Hq, Dv, o_stride_b, o_stride_h,
-                                         xsum_out, xs_stride));
+                                         xsum_out, xs_stride, gate));
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
+}
+
+int sglk_decode_attention_xs(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
+                             const int32_t* kv_indices, float* attn_logits, float* attn_lse, const int32_t* num_kv_splits,
+                             int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv, int64_t q_stride_b,
+                             int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                             int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap,
+                             int dtype, float* xsum_out, int64_t xs_stride, void* stream) {
+  return decode_attention_impl(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
+                               max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n,
+                               v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream,
+                               nullptr);
 }
 
 int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buffer, void* o, const int32_t* kv_indptr,
@@ -1226,15 +1598,17 @@ SGLK_API int sglk_debug_attn_stamps(void* dst) {
 
 static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_buffer, void* v_buffer, void* o,
                                 const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* group_indptr,
-                                const int32_t* prefix_lens, int G, float* workspace, int max_kv_splits, int B, int Hq,
+                                const int32_t* prefix_lens, int G, const int32_t* plan, float* workspace,
+                                int max_kv_splits, int B, int Hq,
                                 int Hkv, int D, int Dv, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n,
                                 int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b,
                                 int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, float* xsum_out,
-                                int64_t xs_stride, void* stream) {
+                                int64_t xs_stride, void* stream, bool gated = false) {
   SGLK_CHECK(!xsum_out || xs_stride >= B, "decode_attention_shared_prefix: xs_stride smaller than B");
-  SGLK_CHECK((q || qp) && k_buffer && v_buffer && o && kv_indptr && kv_indices && group_indptr && prefix_lens && workspace,
+  SGLK_CHECK((q || qp) && k_buffer && v_buffer && o && kv_indptr && kv_indices && workspace &&
+                 (plan || (group_indptr && prefix_lens)),
              "decode_attention_shared_prefix: null pointer");
-  SGLK_CHECK(B >= 0 && G > 0 && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
+  SGLK_CHECK(B >= 0 && (plan || G > 0) && Hq > 0 && Hkv > 0 && Hq % Hkv == 0, "decode_attention_shared_prefix: bad shape");
   SGLK_CHECK(max_kv_splits > 0 && max_kv_splits <= kSharedMaxSplits,
              "decode_attention_shared_prefix: max_kv_splits must be in 1..16");
   if (B == 0) return SGLK_OK;
@@ -1262,12 +1636,11 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
                                     o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
   }
   const int heads = Hq / Hkv;
-  // prefix splits: enough 64-column blocks to cover the CUs once, as far as max_kv_splits allows
   static const int env_sp = getenv("SGLK_SHARED_SPLITS") ? atoi(getenv("SGLK_SHARED_SPLITS")) : 0;
   const int head_tiles = (heads + 15) / 16;
   const int col_blocks = (B * heads + 63) / 64;  // upper bound per group; blocks past a group's columns leave at once
-  int prefix_splits = std::max(1, std::min(max_kv_splits, 256 / std::max(1, col_blocks * Hkv)));
-  if (env_sp > 0) prefix_splits = std::min(env_sp, max_kv_splits);
+  int prefix_splits = shared_prefix_splits(B, heads, Hkv, max_kv_splits);
+  if (env_sp > 0 && !plan) prefix_splits = std::min(env_sp, max_kv_splits);  // (a plan was built for its own count)
   SharedWs ws;
   const int64_t rows = (int64_t)B * Hq * prefix_splits;
   SGLK_CHECK(rows * 512 < ((int64_t)1 << 31), "decode_attention_shared_prefix: B * Hq * max_kv_splits too large");
@@ -1277,24 +1650,38 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
   ws.error = ws.counters + (int64_t)B * Hq;
   ws.part_o = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
   ws.part_lse = ws.part_o + rows * 128;
-  const int n_prefix = G * prefix_splits * col_blocks * Hkv;
+  // planned: one round of blocks for a batch that is one group; more items (many small groups) take further rounds
+  const int n_prefix = (plan ? 1 : G) * prefix_splits * col_blocks * Hkv;
   const int n_tail = B * Hkv * head_tiles;
+  PlanView pv{};
+  if (plan) {
+    SGLK_CHECK(B <= kPlanMaxB, "decode_attention_shared_prefix: a plan covers at most %d requests", kPlanMaxB);
+    pv = plan_view(const_cast<int32_t*>(plan), B, plan_max_items(B, heads, prefix_splits));
+    SGLK_CHECK(aligned16(plan), "decode_attention_shared_prefix: plan must be 16-byte aligned");
+  }
   const size_t lds = kBlockAttnLds;  // the prefix role's two stages; the tail role's four V tiles fit in the same bytes
   static_assert(kWavesPerBlock * kTileBytes <= kBlockAttnLds, "LDS of the prefix role must cover the tail role");
-#define SGLK_SHARED_LAUNCH(ROPE, QP)                                                                                   \
+#define SGLK_SHARED_LAUNCH(ROPE, PLAN, QP)                                                                             \
   SGLK_DISPATCH_HALF(dtype, T,                                                                                         \
-                     hipLaunchKernelGGL((decode_shared_fused_kernel<T, ROPE>), dim3(n_prefix + n_tail), dim3(256), lds, s, \
-                                        q, QP, k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G,  \
-                                        ws, prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles, q_stride_b,    \
-                                        q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, \
-                                        o, o_stride_b, o_stride_h, xsum_out, xs_stride))
+                     hipLaunchKernelGGL((decode_shared_fused_kernel<T, ROPE, PLAN>), dim3(n_prefix + n_tail), dim3(256), \
+                                        lds, s, q, QP, k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr,          \
+                                        prefix_lens, G, pv.hdr, pv.tail, pv.items, ws, prefix_splits, n_prefix,          \
+                                        col_blocks, B, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,          \
+                                        k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o, o_stride_b,          \
+                                        o_stride_h, xsum_out, xs_stride, gated ? 1 : 0))
   if (qp) {
     // a pair's single tail block writes the pair's new rows: more than one head tile would need them across blocks
     if (head_tiles != 1)
       return fail(SGLK_EUNSUP, "decode_attention_shared_prefix_rope: at most 16 query heads per kv head (got %d)", heads);
-    SGLK_SHARED_LAUNCH(true, *qp);
+    if (plan) {
+      SGLK_SHARED_LAUNCH(true, true, *qp);
+    } else {
+      SGLK_SHARED_LAUNCH(true, false, *qp);
+    }
+  } else if (plan) {
+    SGLK_SHARED_LAUNCH(false, true, QkvPartials{});
   } else {
-    SGLK_SHARED_LAUNCH(false, QkvPartials{});
+    SGLK_SHARED_LAUNCH(false, false, QkvPartials{});
   }
 #undef SGLK_SHARED_LAUNCH
   SGLK_LAUNCH_CHECK();
@@ -1311,7 +1698,7 @@ int sglk_decode_attention_shared_prefix_xs(const void* q, const void* k_buffer, 
                                            void* stream) {
   SGLK_CHECK(q, "decode_attention_shared_prefix: null pointer");
   return launch_shared_prefix(q, nullptr, const_cast<void*>(k_buffer), const_cast<void*>(v_buffer), o, kv_indptr,
-                              kv_indices, group_indptr, prefix_lens, G, workspace, max_kv_splits, B, Hq, Hkv, D, Dv,
+                              kv_indices, group_indptr, prefix_lens, G, nullptr, workspace, max_kv_splits, B, Hq, Hkv, D, Dv,
                               q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h,
                               sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
 }
@@ -1344,7 +1731,7 @@ int sglk_decode_attention_shared_prefix_rope(const float* qkv_partials, int spli
   qp.loc = loc;
   qp.loc_is64 = loc_is64;
   return launch_shared_prefix(nullptr, &qp, k_buffer, v_buffer, o, kv_indptr, kv_indices, group_indptr, prefix_lens, G,
-                              workspace, max_kv_splits, B, Hq, Hkv, D, Dv, 0, 0, k_stride_n, k_stride_h, v_stride_n,
+                              nullptr, workspace, max_kv_splits, B, Hq, Hkv, D, Dv, 0, 0, k_stride_n, k_stride_h, v_stride_n,
                               v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
 }
 
@@ -1359,5 +1746,104 @@ int sglk_decode_attention_shared_prefix(const void* q, const void* k_buffer, con
                                                 G, workspace, max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b, q_stride_h,
                                                 k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h,
                                                 sm_scale, logit_cap, dtype, nullptr, 0, stream);
+}
+
+// ---- the per-step plan of the shared-prefix kernel -------------------------------------------------------------
+int64_t sglk_decode_shared_plan_bytes(int B, int Hq, int Hkv, int max_kv_splits) {
+  if (B <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || max_kv_splits <= 0) return 0;
+  const int heads = Hq / Hkv;
+  const PlanView pv = plan_view(nullptr, B, plan_max_items(B, heads, shared_prefix_splits(B, heads, Hkv, max_kv_splits)));
+  return ((pv.words * 4 + 255) / 256) * 256;
+}
+
+static int plan_assemble(const int32_t* kv_indptr, const int32_t* kv_indices, int B, int Hq, int Hkv, int max_kv_splits,
+                         int min_share, int single_ok, int32_t* plan, hipStream_t s) {
+  const int heads = Hq / Hkv;
+  const int splits = shared_prefix_splits(B, heads, Hkv, max_kv_splits);
+  hipLaunchKernelGGL(shared_plan_assemble_kernel, dim3(1), dim3(1024), 0, s, kv_indptr, kv_indices, B, heads, splits,
+                     plan_max_items(B, heads, splits), min_share, single_ok, plan);
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
+}
+
+int sglk_decode_shared_plan(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,
+                            const void* seq_lens, int lens_is64, const int32_t* kv_indptr, const int32_t* kv_indices, int B,
+                            int Hq, int Hkv, int max_kv_splits, int min_share, int32_t* plan, void* stream) {
+  SGLK_CHECK(req_to_token && req_pool_indices && seq_lens && kv_indptr && kv_indices && plan,
+             "decode_shared_plan: null pointer");
+  SGLK_CHECK(B > 0 && B <= kPlanMaxB && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && max_kv_splits > 0 &&
+                 max_kv_splits <= kSharedMaxSplits,
+             "decode_shared_plan: bad shape (1 <= B <= %d, max_kv_splits in 1..16)", kPlanMaxB);
+  SGLK_CHECK(aligned16(plan), "decode_shared_plan: plan must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int heads = Hq / Hkv;
+  const PlanView pv = plan_view(plan, B, plan_max_items(B, heads, shared_prefix_splits(B, heads, Hkv, max_kv_splits)));
+  hipLaunchKernelGGL(shared_plan_lcp_kernel, dim3(B), dim3(256), 0, s, req_to_token, row_stride, req_pool_indices, idx_is64,
+                     seq_lens, lens_is64, B, pv.leader, pv.lcp);
+  SGLK_LAUNCH_CHECK();
+  return plan_assemble(kv_indptr, kv_indices, B, Hq, Hkv, max_kv_splits, min_share > 0 ? min_share : kMinBlockKV, 0, plan, s);
+}
+
+int sglk_decode_shared_plan_from_groups(const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* group_indptr,
+                                        const int32_t* prefix_lens, int G, int B, int Hq, int Hkv, int max_kv_splits,
+                                        int32_t* plan, void* stream) {
+  SGLK_CHECK(kv_indptr && kv_indices && group_indptr && prefix_lens && plan, "decode_shared_plan_from_groups: null pointer");
+  SGLK_CHECK(B > 0 && B <= kPlanMaxB && G > 0 && G <= B && Hq > 0 && Hkv > 0 && Hq % Hkv == 0 && max_kv_splits > 0 &&
+                 max_kv_splits <= kSharedMaxSplits,
+             "decode_shared_plan_from_groups: bad shape (1 <= G <= B <= %d, max_kv_splits in 1..16)", kPlanMaxB);
+  SGLK_CHECK(aligned16(plan), "decode_shared_plan_from_groups: plan must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int heads = Hq / Hkv;
+  const PlanView pv = plan_view(plan, B, plan_max_items(B, heads, shared_prefix_splits(B, heads, Hkv, max_kv_splits)));
+  hipLaunchKernelGGL(shared_plan_from_groups_kernel, dim3((B + 255) / 256), dim3(256), 0, s, group_indptr, prefix_lens, G, B,
+                     pv.leader, pv.lcp);
+  SGLK_LAUNCH_CHECK();
+  return plan_assemble(kv_indptr, kv_indices, B, Hq, Hkv, max_kv_splits, 1, 1, plan, s);
+}
+
+int sglk_decode_metadata_shared(const int32_t* req_to_token, int64_t row_stride, const void* req_pool_indices, int idx_is64,
+                                const void* seq_lens, int lens_is64, int32_t* kv_indptr, int32_t* kv_indices,
+                                int32_t* num_kv_splits, int bs, int num_head, int num_kv_head, int max_kv_splits,
+                                int device_core_count, int min_share, int32_t* plan, void* stream) {
+  if (int rc = sglk_decode_metadata(req_to_token, row_stride, req_pool_indices, idx_is64, seq_lens, lens_is64, kv_indptr,
+                                    kv_indices, num_kv_splits, bs, num_head, num_kv_head, max_kv_splits, device_core_count,
+                                    stream))
+    return rc;
+  if (bs == 0) return SGLK_OK;
+  return sglk_decode_shared_plan(req_to_token, row_stride, req_pool_indices, idx_is64, seq_lens, lens_is64, kv_indptr,
+                                 kv_indices, bs, num_head, num_kv_head, max_kv_splits, min_share, plan, stream);
+}
+
+int sglk_decode_attention_shared_planned(const void* q, const void* k_buffer, const void* v_buffer, void* o,
+                                         const int32_t* kv_indptr, const int32_t* kv_indices, const int32_t* plan,
+                                         float* workspace, int max_kv_splits, int B, int Hq, int Hkv, int D, int Dv,
+                                         int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
+                                         int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                         float sm_scale, float logit_cap, int dtype, float* xsum_out, int64_t xs_stride,
+                                         const int32_t* num_kv_splits, void* stream) {
+  SGLK_CHECK(q && plan, "decode_attention_shared_planned: null pointer");
+  if (num_kv_splits) {
+    // A batch in which nobody shares anything (the plan holds no prefix item) is better served by the per-request
+    // kernels, whose split counts follow the sequence lengths and the CU count.  Whether that is so is known on the
+    // device only, and a captured launch sequence cannot change: both forms are launched, and the blocks of the one
+    // the plan does not select leave at once (the word both read is the plan's item count).
+    const int kvf = dtype >> SGLK_KV_SHIFT;
+    const bool tile = kvf == 0 && ((dtype & ((1 << SGLK_KV_SHIFT) - 1)) == SGLK_F16 || (dtype & ((1 << SGLK_KV_SHIFT) - 1)) == SGLK_BF16) &&
+                      D == 128 && Dv == 128;
+    if (tile) {
+      SGLK_CHECK(workspace, "decode_attention_shared_planned: null pointer");
+      float* logits = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
+      float* lse = logits + (int64_t)B * Hq * max_kv_splits * Dv;
+      if (int rc = decode_attention_impl(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, logits, lse, num_kv_splits,
+                                         max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b, q_stride_h, k_stride_n, k_stride_h,
+                                         v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out,
+                                         xs_stride, stream, plan + kPlanNItems))
+        return rc;
+    }
+  }
+  return launch_shared_prefix(q, nullptr, const_cast<void*>(k_buffer), const_cast<void*>(v_buffer), o, kv_indptr,
+                              kv_indices, nullptr, nullptr, 0, plan, workspace, max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b,
+                              q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale,
+                              logit_cap, dtype, xsum_out, xs_stride, stream, num_kv_splits != nullptr);
 }
 }

@@ -237,11 +237,15 @@ struct BlockAttn {
   // after_fetch runs once the first tiles' loads are on their way (e.g. to assemble the Q operand in their shadow)
   // KV8: the rows are 128 one-byte codes of an fp8 pool (kbase / vbase byte pointers, strides in bytes): they travel
   // as 8-byte pieces and are widened through `lut` when parked.
+  // pre_rows: the pool rows of the first PF tiles, already in registers (pre_rows[2 * p + i] = the row of token
+  // t_begin + p * kTile + frow + 16 * i, clamped as fetch_idx clamps): a caller that could fetch them together with
+  // its own metadata saves the tile loop its first trip to memory.
   template <bool CAUSAL, bool GATHER, int PF = 1, typename Hook = NoHook, bool KV8 = false>
   __device__ __forceinline__ void run(char* lds, const uint16_t* kbase, const uint16_t* vbase, int64_t k_stride_n,
                                       int64_t v_stride_n, const int32_t* idx, int t_begin, int t_end,
                                       const int (&qpos)[NC], int wave_qmax, float sm_scale, float logit_cap,
-                                      Hook after_fetch = Hook(), const uint16_t* lut = nullptr) {
+                                      Hook after_fetch = Hook(), const uint16_t* lut = nullptr,
+                                      const int* pre_rows = nullptr) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int hl = lane & 15, g = lane >> 4;
@@ -340,7 +344,14 @@ struct BlockAttn {
     __syncthreads();  // a previous run() may still be reading the stages
 #pragma unroll
     for (int p = 0; p < PF; ++p)
-      if (t_begin + p * kTile < t_end) fetch_idx(rowi[p], t_begin + p * kTile);
+      if (t_begin + p * kTile < t_end) {
+        if (pre_rows) {
+          rowi[p][0] = pre_rows[2 * p];
+          rowi[p][1] = pre_rows[2 * p + 1];
+        } else {
+          fetch_idx(rowi[p], t_begin + p * kTile);
+        }
+      }
 #pragma unroll
     for (int p = 0; p < PF; ++p)
       if (t_begin + p * kTile < t_end) fetch(kreg[p], vreg[p], rowi[p]);

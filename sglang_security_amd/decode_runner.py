@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -387,8 +388,7 @@ class LlamaDecoder:
     def step_fused(self):
         c = self.cfg
         self.prepare_for_decode()
-        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
-                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        self._metadata()
         torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
         sm_scale = 1.0 / math.sqrt(c.head_dim)
         q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
@@ -459,8 +459,7 @@ class LlamaDecoder:
         and round once, where the reduction launch would have."""
         c = self.cfg
         self.prepare_for_decode()
-        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
-                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        self._metadata()
         torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
         sm_scale = 1.0 / math.sqrt(c.head_dim)
         q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
@@ -515,8 +514,7 @@ class LlamaDecoder:
         launch: 11 launches per layer at most, 8 with every hand-over."""
         c = self.cfg
         self.prepare_for_decode()
-        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
-                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        self._metadata()
         torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
         sm_scale = 1.0 / math.sqrt(c.head_dim)
         q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
@@ -587,8 +585,7 @@ class LlamaDecoder:
             return self.step_fp8()
         c = self.cfg
         self.prepare_for_decode()
-        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
-                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        self._metadata()
         torch.index_select(self.embed, 0, self.input_ids, out=self.hidden)
         sm_scale = 1.0 / math.sqrt(c.head_dim)
         q_view = self.qkv[:, : self.q_size].view(self.B, c.q_heads, c.head_dim)
@@ -670,9 +667,37 @@ class LlamaDecoder:
             self.group_indptr = torch.tensor([0, self.B], dtype=torch.int32, device=self.device)
             self.group_prefix = torch.tensor([self.prefix_len], dtype=torch.int32, device=self.device)
             self.shared_ws = ops.decode_shared_workspace(self.B, c.q_heads, c.head_dim, self.max_kv_splits, self.device)
+            # "derived": the groups are found on the device from the request table, once per step, as the attention
+            # backend does (nothing about the batch is told to the kernel); "given": the plan is laid out from
+            # group_indptr / group_prefix; "legacy": the kernel reads group_indptr / group_prefix itself, per layer
+            self.plan_mode = getattr(self, "plan_mode", None) or os.environ.get("SGLK_SHARED_PLAN", "derived")
+            self.shared_plan = None
+            if self.plan_mode != "legacy" and c.head_dim == 128 and self.B <= 1024:
+                self.shared_plan = ops.decode_shared_plan_buffer(self.B, c.q_heads, c.kv_heads, self.max_kv_splits,
+                                                                 self.device)
         return self.shared
 
+    def _metadata(self):
+        """kv_indptr / kv_indices / num_kv_splits and, with prefix sharing on, the step's plan (one call)."""
+        c = self.cfg
+        plan = getattr(self, "shared_plan", None) if getattr(self, "shared", False) else None
+        if plan is not None and self.plan_mode == "derived":
+            ops.decode_metadata_shared(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr,
+                                       self.kv_indices, self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits,
+                                       self.cu_count, plan)
+            return
+        ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
+                            self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
+        if plan is not None:
+            ops.decode_shared_plan_from_groups(self.kv_indptr, self.kv_indices, self.group_indptr, self.group_prefix,
+                                               self.B, c.q_heads, c.kv_heads, self.max_kv_splits, plan)
+
     def attention(self, li, q_view, o_view, sm_scale, xsum_out=None):
+        if getattr(self, "shared", False) and getattr(self, "shared_plan", None) is not None:
+            ops.decode_attention_shared_planned(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr,
+                                                self.kv_indices, self.shared_plan, self.shared_ws, self.max_kv_splits,
+                                                sm_scale, 0.0, xsum_out)
+            return
         if getattr(self, "shared", False):
             ops.decode_attention_shared_prefix_xs(q_view, self.k_pool[li], self.v_pool[li], o_view, self.kv_indptr,
                                                   self.kv_indices, self.group_indptr, self.group_prefix, self.shared_ws,

@@ -369,27 +369,3 @@ class RadixCache:
                             need_check=bool(f[3]), owner=None if f[4] == -1 else str(self._user_name(f[4])),
                             epoch=f[5], hit_count=f[6], hit_pre=f[7], u_cnt_pre=f[8], n_users=f[9]))
         return out
-
-
-def build_prefix_groups(prefix_indices: List[torch.Tensor], seq_lens, device=None):
-    """Group the requests of a decode batch by the radix-tree prefix they matched.
-
-    prefix_indices[b] is the slot tensor RadixCache.match_prefix returned for request b (requests that hit the same
-    node hold the same slots).  Returns (order, group_indptr, prefix_lens): `order` is a permutation that makes the
-    members of a group adjacent (identity when they already are), group_indptr [G + 1] and prefix_lens [G] are the
-    int32 tensors the shared-prefix decode kernel takes.  A group's prefix length is capped at min(seq_len) - 1 of its
-    members (the newest token is never shared); requests without a hit form groups of one with prefix length 0."""
-    n = len(prefix_indices)
-    lens = [int(x) for x in (seq_lens.tolist() if hasattr(seq_lens, "tolist") else seq_lens)]
-    buckets: Dict[tuple, List[int]] = {}
-    for b, p in enumerate(prefix_indices):
-        key = (int(p[0]), int(p[-1]), int(p.numel())) if p is not None and p.numel() > 0 else ("none", b, 0)
-        buckets.setdefault(key, []).append(b)
-    order, indptr, plens = [], [0], []
-    for key, members in buckets.items():
-        order.extend(members)
-        indptr.append(len(order))
-        plens.append(max(0, min(key[2], min(lens[b] for b in members) - 1)))
-    dev = device if device is not None else (prefix_indices[0].device if n and prefix_indices[0] is not None else "cpu")
-    return (torch.tensor(order, dtype=torch.int64, device=dev), torch.tensor(indptr, dtype=torch.int32, device=dev),
-            torch.tensor(plens, dtype=torch.int32, device=dev))

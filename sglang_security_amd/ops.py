@@ -77,6 +77,85 @@ def decode_metadata(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indi
         "decode_metadata")
 
 
+def decode_shared_plan_buffer(B, Hq, Hkv, max_kv_splits, device) -> torch.Tensor:
+    """An int32 buffer for the per-step plan of the shared-prefix decode kernel (up to B requests)."""
+    n = int(lib().sglk_decode_shared_plan_bytes(B, Hq, Hkv, max_kv_splits))
+    if n <= 0:
+        raise SglkError("decode_shared_plan_buffer: bad shape")
+    return torch.zeros(n // 4, dtype=torch.int32, device=device)
+
+
+def _plan_room(plan, B, Hq, Hkv, max_kv_splits, what):
+    need = int(lib().sglk_decode_shared_plan_bytes(B, Hq, Hkv, max_kv_splits))
+    if plan.dtype != torch.int32 or plan.numel() * 4 < need:
+        raise SglkError(f"{what}: plan must be an int32 buffer of at least {need} bytes")
+
+
+def decode_shared_plan(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, Hq, Hkv, max_kv_splits, plan,
+                       min_share=0):
+    """Find the groups of requests that share their first slots and lay the step's work out for
+    decode_attention_shared_planned (device work only: no host synchronisation, fixed addresses)."""
+    _need_gpu(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, plan)
+    B = seq_lens.shape[0]
+    _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_shared_plan")
+    check(lib().sglk_decode_shared_plan(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices), _ptr(seq_lens),
+        _is64(seq_lens), _ptr(kv_indptr), _ptr(kv_indices), B, Hq, Hkv, max_kv_splits, int(min_share), _ptr(plan),
+        _stream(seq_lens)), "decode_shared_plan")
+
+
+def decode_shared_plan_from_groups(kv_indptr, kv_indices, group_indptr, prefix_lens, B, Hq, Hkv, max_kv_splits, plan):
+    _need_gpu(kv_indptr, kv_indices, group_indptr, prefix_lens, plan)
+    _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_shared_plan_from_groups")
+    check(lib().sglk_decode_shared_plan_from_groups(
+        _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr), _ptr(prefix_lens), group_indptr.shape[0] - 1, B, Hq, Hkv,
+        max_kv_splits, _ptr(plan), _stream(kv_indptr)), "decode_shared_plan_from_groups")
+
+
+def decode_metadata_shared(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits, num_head,
+                           num_kv_head, max_kv_splits, device_core_count, plan, min_share=0):
+    """decode_metadata + decode_shared_plan in one call."""
+    _need_gpu(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits, plan)
+    _plan_room(plan, seq_lens.shape[0], num_head, num_kv_head, max_kv_splits, "decode_metadata_shared")
+    check(lib().sglk_decode_metadata_shared(
+        _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices),
+        _ptr(seq_lens), _is64(seq_lens), _ptr(kv_indptr), _ptr(kv_indices), _ptr(num_kv_splits),
+        seq_lens.shape[0], num_head, num_kv_head, max_kv_splits, device_core_count, int(min_share), _ptr(plan),
+        _stream(seq_lens)), "decode_metadata_shared")
+
+
+def decode_shared_plan_read(plan, B):
+    """Host view of a plan's grouping (synchronises; tests and logging): dict with num_groups, n_items, order,
+    group_indptr, prefix_lens."""
+    h = plan[:16].cpu().tolist()
+    G = h[1]
+    base = 16
+    order = plan[base: base + B].cpu().tolist()
+    gi0 = base + B + 4 * B
+    return dict(n_items=h[0], num_groups=G, order=order, group_indptr=plan[gi0: gi0 + G + 1].cpu().tolist(),
+                prefix_lens=plan[gi0 + B + 1: gi0 + B + 1 + G].cpu().tolist())
+
+
+def decode_attention_shared_planned(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, plan, workspace, max_kv_splits,
+                                    sm_scale, logit_cap=0.0, xsum_out=None, num_kv_splits=None):
+    """decode_attention_shared_prefix with the groups and the work layout taken from a per-step plan.  With
+    num_kv_splits the per-request kernels are launched beside it and the plan decides on the device which of the two
+    runs (no group shares anything: per request)."""
+    _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, plan, workspace)
+    B, Hq, D = q.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    need = decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits)
+    if workspace.numel() * workspace.element_size() < need:
+        raise SglkError(f"decode_attention_shared_planned: workspace too small ({need} bytes needed)")
+    _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_attention_shared_planned")
+    check(lib().sglk_decode_attention_shared_planned(
+        _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(plan), _ptr(workspace),
+        max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1), k_buffer.stride(0), k_buffer.stride(1),
+        v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1), float(sm_scale), float(logit_cap),
+        _attn_dtype(q, k_buffer, v_buffer), _ptr(xsum_out), 0 if xsum_out is None else xsum_out.stride(0),
+        _ptr(num_kv_splits), _stream(q)), "decode_attention_shared_planned")
+
+
 def prepare_for_decode(req_to_token, req_pool_indices, seq_lens, positions, out_cache_loc):
     """positions = seq_lens; out_cache_loc = req_to_token[req_pool_indices, seq_lens]; seq_lens += 1 (one launch)."""
     _need_gpu(req_to_token, req_pool_indices, seq_lens, positions, out_cache_loc)

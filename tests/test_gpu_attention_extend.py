@@ -197,6 +197,132 @@ def test_shared_prefix_decode_vs_oracle(dtype, groups, Hq, Hkv, max_splits):
     assert (o - want).abs().max().item() < tol
 
 
+def _run_planned(ops, q, kb, vb, ptr, ind, plan, max_splits, dtype, sm, cap=0.0, num_kv_splits=None):
+    B, Hq, D = q.shape
+    o = torch.full((B, Hq, D), float("nan"), dtype=dtype, device=DEV)
+    ws = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
+    ops.decode_attention_shared_planned(q.to(DEV), kb.to(DEV), vb.to(DEV), o, ptr.to(DEV), ind.to(DEV), plan, ws, max_splits,
+                                        sm, cap, None, num_kv_splits)
+    torch.cuda.synchronize()
+    assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
+    return o
+
+
+@pytest.mark.parametrize("groups,Hq,Hkv,max_splits", [
+    ([(5, 96, 1, 40)], 32, 8, 4),
+    ([(3, 200, 1, 30), (1, 0, 5, 90), (7, 33, 1, 300)], 32, 8, 8),
+    ([(40, 64, 1, 10)], 8, 8, 2),
+    ([(2, 1, 1, 1), (2, 700, 600, 600)], 16, 2, 16),
+    ([(21, 150, 1, 70), (3, 40, 1, 5)], 28, 4, 5),
+    ([(3, 70, 1, 40)], 32, 1, 3),
+    ([(4, 64, 0, 0), (2, 0, 1, 3)], 8, 2, 2),
+    ([(2, 40, 1, 9)] * 23, 32, 8, 8),                   # many small groups: more prefix items than one round of blocks
+])
+def test_shared_prefix_planned_from_groups_equals_the_unplanned_kernel(groups, Hq, Hkv, max_splits):
+    """The plan laid out from the caller's groups drives the same blocks over the same ranges as the kernel that reads
+    the group arrays itself: bit-identical outputs."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    q, kb, vb, ptr, ind, gi, pls = _group_batch(groups, Hq, Hkv, dtype, seed=len(groups) + Hq)
+    sm = 1.0 / math.sqrt(128)
+    B = q.shape[0]
+    want = _run_shared(ops, q, kb, vb, ptr, ind, gi, pls, max_splits, dtype, sm)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV)
+    ops.decode_shared_plan_from_groups(ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV), B, Hq, Hkv, max_splits, plan)
+    got = _run_planned(ops, q, kb, vb, ptr, ind, plan, max_splits, dtype, sm)
+    view = ops.decode_shared_plan_read(plan, B)
+    assert view["num_groups"] == len(groups) and view["order"] == list(range(B))
+    assert view["group_indptr"] == gi.tolist() and view["prefix_lens"] == pls.tolist()
+    assert torch.equal(got.cpu().view(torch.int16), want.to(dtype).view(torch.int16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_shared_prefix_plan_derived_from_the_request_table(dtype, seed):
+    """Groups found on the device from req_to_token rows: members scattered over the batch, ragged lengths, a group
+    whose common part is shorter than the shared tree node (lists that diverge early), requests that share nothing, a
+    request of one token (a padded graph row).  Against the oracle, and the grouping itself against a host restatement."""
+    import oracle
+    import random
+
+    ops = _ops()
+    rng = random.Random(seed)
+    Hq, Hkv, D, max_splits = 32, 8, 128, 8
+    specs = [(6, 130), (1, 0), (9, 64), (3, 33), (2, 20), (1, 0), (4, 257)]   # (members, shared slots)
+    nxt = 1
+    rows = []
+    for members, shared in specs:
+        base = list(range(nxt, nxt + shared))
+        nxt += shared
+        for m in range(members):
+            tail = rng.randrange(1, 90)
+            rows.append(base + list(range(nxt, nxt + tail)))
+            nxt += tail
+    rows.append([nxt])          # one token only
+    nxt += 1
+    rng.shuffle(rows)
+    B = len(rows)
+    lens = [len(r) for r in rows]
+    width = max(lens) + 4
+    r2t = torch.zeros(B + 3, width, dtype=torch.int32)
+    rpi = torch.tensor(rng.sample(range(B + 3), B), dtype=torch.int64)        # rows of the table in any order
+    for b, r in enumerate(rows):
+        r2t[rpi[b], : len(r)] = torch.tensor(r, dtype=torch.int32)
+    gen = torch.Generator().manual_seed(seed)
+    kb = torch.randn(nxt + 1, Hkv, D, generator=gen).to(dtype)
+    vb = torch.randn(nxt + 1, Hkv, D, generator=gen).to(dtype)
+    q = torch.randn(B, Hq, D, generator=gen).to(dtype)
+    seq = torch.tensor(lens, dtype=torch.int64)
+    ptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    ind = torch.zeros(sum(lens), dtype=torch.int32, device=DEV)
+    ns = torch.zeros(B, dtype=torch.int32, device=DEV)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV)
+    ops.decode_metadata_shared(r2t.to(DEV), rpi.to(DEV), seq.to(DEV), ptr, ind, ns, Hq, Hkv, max_splits, 256, plan)
+    torch.cuda.synchronize()
+    # host restatement of the grouping rule: leader = first request with the same first slot (lists of two tokens and
+    # more); shared length = the longest slot prefix common to the leader and every member, newest token excluded;
+    # fewer than two members or fewer than 32 shared slots: nothing shared
+    leader = []
+    for b in range(B):
+        lead = b
+        if lens[b] >= 2:
+            for i in range(b):
+                if lens[i] >= 2 and rows[i][0] == rows[b][0]:
+                    lead = i
+                    break
+        leader.append(lead)
+    leaders = sorted(set(leader))
+    want_order, want_indptr, want_plen = [], [0], []
+    for L in leaders:
+        members = [b for b in range(B) if leader[b] == L]
+        plen = lens[L] - 1
+        for b in members:
+            n = min(lens[L], lens[b]) - 1
+            k = 0
+            while k < n and rows[L][k] == rows[b][k]:
+                k += 1
+            plen = min(plen, k)
+        if len(members) < 2 or plen < 32:
+            plen = 0
+        want_order += members
+        want_indptr.append(len(want_order))
+        want_plen.append(plen)
+    view = ops.decode_shared_plan_read(plan, B)
+    assert view["num_groups"] == len(leaders)
+    assert view["order"] == want_order and view["group_indptr"] == want_indptr and view["prefix_lens"] == want_plen
+    assert any(p > 0 for p in want_plen) and view["n_items"] > 0
+    assert torch.equal(ind.cpu(), torch.tensor([s for r in rows for s in r], dtype=torch.int32))
+    sm = 1.0 / math.sqrt(D)
+    want = oracle.decode_attention(q, kb, vb, ptr.cpu(), ind.cpu(), torch.ones(B, dtype=torch.int32), sm)
+    o = _run_planned(ops, q, kb, vb, ptr, ind, plan, max_splits, dtype, sm).float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o).all()
+    assert (o - want).abs().max().item() < tol
+    # the same launch sequence with the per-request kernels beside it: the plan has items, so they leave at once
+    o_g = _run_planned(ops, q, kb, vb, ptr, ind, plan, max_splits, dtype, sm, num_kv_splits=ns).float().cpu()
+    assert torch.equal(o_g, o)
+
+
 def test_shared_prefix_decode_golden(golden):
     """The committed shared-prefix decode vector (Triton fp32 / reference CPU bf16), one group of 4 requests."""
     ops = _ops()

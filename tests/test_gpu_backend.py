@@ -65,12 +65,14 @@ def test_pools_and_set_kv_buffer():
 
 
 @pytest.mark.parametrize("graph_state", [False, True])
-def test_backend_decode_matches_oracle(graph_state):
-    """Radix-style batch (shared 100-token prefix + private tails) through init_forward_metadata / forward_decode,
-    per-request and shared-prefix paths, eager and fixed-address (graph) metadata."""
+@pytest.mark.parametrize("share", [True, False])
+def test_backend_decode_matches_oracle(graph_state, share):
+    """Radix-style batch (shared 100-token prefix + private tails) through init_forward_metadata / forward_decode with
+    nothing but the reference's own arguments: the backend finds the group on the device (share=True: the shared-prefix
+    kernel runs) or is told to keep to the per-request kernel; eager and fixed-address (graph) metadata."""
     import oracle
+    from sglang_security_amd import ops
     from sglang_security_amd.attention import SglkAttnBackend
-    from sglang_security_amd.mem_cache.radix_cache import build_prefix_groups
 
     Hq, Hkv, D, B = 16, 4, 128, 5
     mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
@@ -93,7 +95,7 @@ def test_backend_decode_matches_oracle(graph_state):
     fb = types.SimpleNamespace(forward_mode=_Mode(True), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
                                seq_lens=seq_lens, seq_lens_sum=sum(lens), out_cache_loc=torch.tensor(slots_new, device=DEV),
                                token_to_kv_pool=kv)
-    be = SglkAttnBackend(mr)
+    be = SglkAttnBackend(mr, share_prefix=share)
     layer = _layer(0, Hq, Hkv, D)
     if graph_state:
         be.init_cuda_graph_state(8)
@@ -101,6 +103,12 @@ def test_backend_decode_matches_oracle(graph_state):
         be.init_forward_metadata_replay_cuda_graph(B, fb.req_pool_indices, seq_lens, sum(lens))
     else:
         be.init_forward_metadata(fb)
+    md = be.forward_metadata
+    assert (md.shared_plan is not None) == share
+    if share:
+        plan = ops.decode_shared_plan_read(md.shared_plan, B)
+        assert plan["num_groups"] == 1 and plan["order"] == list(range(B)) and plan["group_indptr"] == [0, B]
+        assert plan["prefix_lens"] == [100] and plan["n_items"] > 0
     o = be.forward(q, k_new, v_new, layer, fb)
     # oracle over the pool AFTER the write of the new token
     kb, vb = kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu()
@@ -110,16 +118,126 @@ def test_backend_decode_matches_oracle(graph_state):
     ind = torch.cat([r2t.req_to_token[b, : lens[b]].cpu() for b in range(B)])
     want = oracle.decode_attention(q.cpu().view(B, Hq, D), kb, vb, ptr, ind, torch.ones(B, dtype=torch.int32), layer.scaling)
     assert (o.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
-    # the same batch with the radix-tree groups handed over
-    order, gi, pl = build_prefix_groups([prefix] * B, lens, device=DEV)
-    assert order.tolist() == list(range(B)) and gi.tolist() == [0, B] and pl.tolist() == [100]
-    fb.prefix_groups = (gi, pl)
-    if graph_state:
-        be.init_forward_metadata_capture_cuda_graph(B, B, fb.req_pool_indices, seq_lens, prefix_groups=(gi, pl))
-    else:
-        be.init_forward_metadata(fb)
-    o2 = be.forward(q, k_new, v_new, layer, fb, save_kv_cache=False)
-    assert (o2.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
+    if share:
+        assert ops.decode_shared_workspace_status(md.shared_workspace, B, Hq) == 0
+
+
+def test_backend_decode_nobody_shares_takes_the_per_request_kernels():
+    """A batch whose requests share nothing: the plan holds no prefix item, and the launch sequence (which a captured
+    graph could not change) hands the batch to the per-request kernels on the device -- same numbers as the oracle."""
+    import oracle
+    from sglang_security_amd import ops
+    from sglang_security_amd.attention import SglkAttnBackend
+
+    Hq, Hkv, D, B = 8, 2, 128, 3
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    g = torch.Generator().manual_seed(5)
+    lens = [70, 33, 129]
+    for b in range(B):
+        r2t.req_to_token[b, : lens[b]] = alloc.alloc(lens[b]).int()
+    for buf in (kv.k_buffer[0], kv.v_buffer[0]):
+        buf.copy_(torch.randn(buf.shape, generator=g).to(torch.bfloat16))
+    seq_lens = torch.tensor(lens, device=DEV)
+    q = torch.randn(B, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    fb = types.SimpleNamespace(forward_mode=_Mode(True), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                               seq_lens=seq_lens, seq_lens_sum=sum(lens), out_cache_loc=None, token_to_kv_pool=kv)
+    be = SglkAttnBackend(mr)
+    be.init_forward_metadata(fb)
+    plan = ops.decode_shared_plan_read(be.forward_metadata.shared_plan, B)
+    assert plan["n_items"] == 0 and plan["num_groups"] == B and plan["prefix_lens"] == [0, 0, 0]
+    layer = _layer(0, Hq, Hkv, D)
+    o = be.forward(q, None, None, layer, fb, save_kv_cache=False)
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    ind = torch.cat([r2t.req_to_token[b, : lens[b]].cpu() for b in range(B)])
+    want = oracle.decode_attention(q.cpu().view(B, Hq, D), kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu(), ptr, ind,
+                                   torch.ones(B, dtype=torch.int32), layer.scaling)
+    assert (o.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
+
+
+def test_backend_graph_replay_in_batch_prefix_shape():
+    """The shape of benchmark/bench_in_batch_prefix/bench_in_batch_prefix.py:112-116 -- 10 prefixes x 32 requests, the
+    requests of the ten groups interleaved in the batch as a scheduler would leave them -- through a REAL HIP graph:
+    captured once on one batch, replayed on another whose groups differ (other prefixes, other lengths, other members),
+    with only init_forward_metadata_replay_cuda_graph in between.  The shared-prefix path must equal the per-request
+    kernel on the same pool (both are within the reference's tolerance of the oracle; between themselves they differ
+    by summation order only)."""
+    from sglang_security_amd import ops
+    from sglang_security_amd.attention import SglkAttnBackend
+
+    Hq, Hkv, D = 32, 8, 128
+    n_prefix, per, B = 10, 32, 320
+    P, S = 96, 24
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D, max_bs=B + 1, max_ctx=256, pool=32768)
+    g = torch.Generator().manual_seed(7)
+    for buf in (kv.k_buffer[0], kv.v_buffer[0]):
+        buf.copy_(torch.randn(buf.shape, generator=g).to(torch.bfloat16))
+    layer = _layer(0, Hq, Hkv, D)
+
+    def batch(seed, plen_of, slen_of):
+        """Rows of req_to_token for 10 groups x 32 requests, members interleaved: request b belongs to group b % 10."""
+        rows, lens = [], []
+        prefixes = [alloc.alloc(plen_of(gi)) for gi in range(n_prefix)]
+        for b in range(B):
+            gi = b % n_prefix
+            tail = alloc.alloc(slen_of(b))
+            rows.append(torch.cat([prefixes[gi], tail]))
+            lens.append(rows[-1].numel())
+        return rows, lens
+
+    be_shared, be_plain = SglkAttnBackend(mr, share_prefix=True), SglkAttnBackend(mr, share_prefix=False)
+    outs = {}
+    static_rpi = torch.arange(B, device=DEV, dtype=torch.int32)
+    static_lens = torch.ones(B, device=DEV, dtype=torch.int32)
+    q = torch.randn(B, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
+    graphs = {}
+    for name, be in (("shared", be_shared), ("plain", be_plain)):
+        be.init_cuda_graph_state(B)
+        rows, lens = batch(1, lambda gi: P, lambda b: S)
+        for b in range(B):
+            r2t.req_to_token[b, : lens[b]] = rows[b].int()
+        static_lens.copy_(torch.tensor(lens, dtype=torch.int32))
+        be.init_forward_metadata_capture_cuda_graph(B, B, static_rpi, static_lens)
+        fb = types.SimpleNamespace(forward_mode=_Mode(True), batch_size=B, req_pool_indices=static_rpi, seq_lens=static_lens,
+                                   seq_lens_sum=sum(lens), out_cache_loc=None, token_to_kv_pool=kv)
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            be.forward(q, None, None, layer, fb, save_kv_cache=False)      # warm-up outside the capture
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=stream):
+                outs[name] = be.forward(q, None, None, layer, fb, save_kv_cache=False)
+        graphs[name] = gr
+    # a different batch: ragged prefixes (one of them shorter than a tile: that group does not share), ragged tails
+    rows, lens = batch(2, lambda gi: 17 if gi == 3 else 64 + 9 * gi, lambda b: 1 + (b * 7) % 37)
+    for b in range(B):
+        r2t.req_to_token[b, : lens[b]] = rows[b].int()
+    static_lens.copy_(torch.tensor(lens, dtype=torch.int32))
+    for name, be in (("shared", be_shared), ("plain", be_plain)):
+        be.init_forward_metadata_replay_cuda_graph(B, static_rpi, static_lens, sum(lens))
+        graphs[name].replay()
+    torch.cuda.synchronize()
+    plan = ops.decode_shared_plan_read(be_shared.cuda_graph_shared_plan, B)
+    assert plan["num_groups"] == n_prefix
+    assert sorted(plan["order"]) == list(range(B))
+    for gi in range(n_prefix):                      # members of a group are the requests b with b % 10 == gi, in order
+        lo, hi = plan["group_indptr"][gi], plan["group_indptr"][gi + 1]
+        assert plan["order"][lo:hi] == list(range(gi, B, n_prefix))
+        assert plan["prefix_lens"][gi] == (0 if gi == 3 else 64 + 9 * gi)
+    assert ops.decode_shared_workspace_status(be_shared.cuda_graph_shared_workspace, B, Hq) == 0
+    a, b_ = outs["shared"].float().cpu(), outs["plain"].float().cpu()
+    assert torch.isfinite(a).all()
+    torch.testing.assert_close(a, b_, atol=2e-2, rtol=1e-2)
+    # and against the oracle on a sample of requests from different groups
+    import oracle
+
+    pick = [0, 3, 13, 157, 319]
+    ptr = torch.zeros(len(pick) + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.tensor([lens[i] for i in pick]), 0)
+    ind = torch.cat([rows[i].int().cpu() for i in pick])
+    want = oracle.decode_attention(q.cpu().view(B, Hq, D)[pick], kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu(), ptr, ind,
+                                   torch.ones(len(pick), dtype=torch.int32), layer.scaling)
+    assert (a.view(B, Hq, D)[pick] - want).abs().max().item() < 2e-2
 
 
 def test_backend_extend_matches_oracle():

@@ -343,7 +343,6 @@ def test_backend_decode_and_extend_over_fp8_pool():
 
     import oracle
     from sglang_security_amd.attention import SglkAttnBackend
-    from sglang_security_amd.mem_cache.radix_cache import build_prefix_groups
     from test_gpu_backend import _Mode, _layer, _runner
 
     fmt, dt = "e5m2fnuz", torch.float8_e5m2fnuz
@@ -406,10 +405,19 @@ def test_backend_decode_and_extend_over_fp8_pool():
     want_d = oracle.decode_attention(qd.cpu().view(B, Hq, D), pool_k, pool_v, ptr, ind, torch.ones(B, dtype=torch.int32),
                                      layer.scaling)
     assert (od.float().cpu().view(B, Hq, D) - want_d).abs().max().item() < 2e-2
-    order, gi, pl = build_prefix_groups([prefix] * B, lens, device=DEV)
-    fbd.prefix_groups = (gi, pl)
-    be.init_forward_metadata(fbd)
-    od2 = be.forward(qd, kd, vd, layer, fbd, save_kv_cache=False)
+    # an fp8 pool has no one-launch shared-prefix kernel: the backend lays no plan out and keeps to the per-request
+    # kernels, which read the pool's bytes
+    assert be.forward_metadata.shared_plan is None
+    # the shared-prefix entry point itself, handed the groups, routes an fp8 pool per request: the same numbers
+    from sglang_security_amd import ops
+
+    md = be.forward_metadata
+    gi = torch.tensor([0, B], dtype=torch.int32, device=DEV)
+    pl = torch.tensor([64], dtype=torch.int32, device=DEV)
+    od2 = torch.empty_like(od)
+    ws = ops.decode_shared_workspace(B, Hq, D, 8, DEV)
+    ops.decode_attention_shared_prefix(qd.view(B, Hq, D), kv.get_key_buffer(0), kv.get_value_buffer(0), od2.view(B, Hq, D),
+                                       md.kv_indptr, md.kv_indices, gi, pl, ws, 8, layer.scaling, 0.0)
     torch.cuda.synchronize()
     assert (od2.float().cpu().view(B, Hq, D) - want_d).abs().max().item() < 2e-2
 
