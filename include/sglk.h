@@ -480,6 +480,44 @@ SGLK_API int sglk_awq_gemm_silu_mul(const void* x, const int32_t* packed, const 
                                     int64_t x_stride, int64_t out_stride, int dtype, const float* xsum,
                                     int64_t xs_stride, float* xsum_out, int64_t xs_out_stride,
                                     void* stream);
+/* Several projections of one decoder layer in ONE launch: job i + 1 multiplies what job i wrote.  The layer's
+ * projections (layers/quantization/awq.py:197-215 per linear; models/llama.py:245-267 for their order) each cost a
+ * launch with its own fill (the first weights and activations on their way, 3-4 us) and drain; here one persistent
+ * block per CU walks the jobs, requests the next job's first weights, scales and zeros before it finishes the
+ * current one, and hands over through write-through stores and relaxed counters (no fence, no kernel boundary).
+ * kind SGLK_CHAIN_PARTIAL: what sglk_awq_gemm_partial does (fp32 split sums to `partial`, splits as
+ * sglk_awq_gemm_partial_splits says; splits_expected, when non-zero, must equal that count).
+ * kind SGLK_CHAIN_SILU_MUL: what sglk_awq_gemm_silu_mul does (out, out_stride, xsum_out, xs_out_stride).
+ * Every job takes the block sums of its x from its producer (xsum_in, xs_stride >= M).  M <= 64; at most 8 jobs;
+ * shapes as the two entry points require; every job's column tiles x splits must fit the device's CUs.
+ * Same bits as the separate launches.  A job may read what an EARLIER job of the chain wrote only if no job before
+ * that writer read the same addresses (the L2s of the XCDs are not coherent inside a launch): distinct buffers per
+ * hand-over.  sync: sglk_awq_chain_sync_bytes() bytes of device memory, ZERO before the first launch that uses it
+ * (every launch leaves it zero); one chain at a time per sync buffer.  A block that waits two seconds for its
+ * producers raises the error word (sglk_awq_chain_status, synchronising: 1) and goes on rather than hang. */
+#define SGLK_CHAIN_PARTIAL 0
+#define SGLK_CHAIN_SILU_MUL 1
+typedef struct sglk_chain_job {
+  int kind;
+  int N, K;
+  int splits_expected;
+  const void* x;
+  int64_t x_stride;
+  const int32_t* packed;
+  const void* scales;
+  const int32_t* qzeros;
+  const float* xsum_in;
+  int64_t xs_stride;
+  void* out;
+  int64_t out_stride;
+  float* partial;
+  float* xsum_out;
+  int64_t xs_out_stride;
+} sglk_chain_job;
+SGLK_API int64_t sglk_awq_chain_sync_bytes(void);
+SGLK_API int sglk_awq_chain_status(const void* sync);
+SGLK_API int sglk_awq_chain(const sglk_chain_job* jobs, int njobs, void* sync, int M, int group_size, int dtype,
+                            void* stream);
 /* sglk_act_and_mul that also writes the block sums of its output rows (d % 128 == 0). */
 SGLK_API int sglk_act_and_mul_xs(void* out, const void* x, int64_t rows, int d, int act, int dtype,
                                  float* xsum_out, int64_t xs_stride, void* stream);

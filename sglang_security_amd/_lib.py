@@ -124,6 +124,9 @@ _SIGS = {
     "sglk_bmm_fp8": (i32, [p, p, p, p, p, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i32, i32, i32, p]),
     "sglk_moe_align_block_size": (i32, [p, i32, i64, i32, i32, p, p, p, p, p]),
     "sglk_topk_softmax": (i32, [p, p, p, p, i32, i32, i32, i64, i32, p]),
+    "sglk_awq_chain_sync_bytes": (i64, []),
+    "sglk_awq_chain_status": (i32, [p]),
+    "sglk_awq_chain": (i32, [p, i32, p, i32, i32, i32, p]),
     "sglk_ar_meta_size": (i64, []),
     "sglk_ar_init": (i64, [p, i32, i32, i32, i64]),
     "sglk_ar_init_handles": (i64, [p, p, i64, p, p, i32, i32, i32, i64]),

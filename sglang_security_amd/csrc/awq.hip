@@ -616,15 +616,88 @@ struct ZpOnMatrixCores<bf16_t> {
 // row-major to partial[split][M][N] and returns; the consumer kernel adds the splits up.
 // MT: 32-row tiles of the 64-row block that are multiplied (batches of up to 32 rows skip the matrix work of the
 // rows they do not have; staging, reduction and stores keep the 64-row shape, the skipped tile is zeros).
-template <typename T, bool XS_EXT, int MT = 2>
-__global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
-    const uint16_t* __restrict__ x, const int32_t* __restrict__ packed, const uint16_t* __restrict__ scales,
-    const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
-    float* __restrict__ partial, int* __restrict__ tickets, int M, int N, int K, int stages_per_split, int splits,
-    int64_t x_stride, int64_t out_stride, const float* __restrict__ xsum_in, int64_t xs_stride, int partial_mode,
-    int act_mode, float* __restrict__ xsum_out, int64_t xs_out_stride) {
+//
+// One projection is a WideJob.  awq_gemm_wide_kernel runs one job, a block per (column tile, split, row block).
+// awq_chain_kernel (CHAIN) runs a list of jobs in ONE launch of persistent blocks, job j + 1 reading what job j wrote:
+// block b takes (column tile b % grid_x, split b / grid_x) of every job with nblocks > b.  What a block needs from
+// the next job that does not depend on the previous one -- its first two stages of weights, scales and zeros -- is
+// requested before the block finishes the current job (the in-block reduction, the stores, the hand-over), so the
+// fill of job j + 1 runs under the drain of job j instead of behind a kernel boundary.  Hand-over: outputs are stored
+// write-through, a block counts itself done once its stores are acknowledged (one of eight counters per job, spread
+// over the memory channels), and a block starts the activation fetch of job j + 1 when the counters of job j add up
+// to all its blocks.  Relaxed agent-scope accesses only, never a fence (a fence writes every L2 back).  The grid must
+// be resident at once (one block per CU: the launcher checks the CU count), and the wait is bounded all the same: a
+// block that sees no progress for two seconds raises the error word and goes on instead of hanging the GPU.
+// A chain must not read an address that another block wrote earlier IN THE SAME LAUNCH unless nobody on the reader's
+// XCD read it before the write (the L2s of the XCDs are not coherent with each other inside a launch): every buffer a
+// job hands to the next is written once and read after.
+struct WideJob {
+  const uint16_t* x;
+  const int32_t* packed;
+  const uint16_t* scales;
+  const int32_t* qzeros;
+  const uint16_t* bias;
+  uint16_t* out;
+  float* partial;
+  int* tickets;
+  const float* xsum_in;
+  float* xsum_out;
+  int64_t x_stride, out_stride, xs_stride, xs_out_stride;
+  int N, K, stages_per_split, splits, partial_mode, act_mode;
+  int grid_x, nblocks;  // chain only: column tiles, blocks that take part (grid_x * splits)
+};
+static constexpr int kChainMaxJobs = 8;
+struct ChainJobs {
+  WideJob job[kChainMaxJobs];
+  int njobs;
+};
+// sync words of a chain, 128 bytes apart: done[job][8], then the exit counter, then the error word
+static constexpr int kChainSyncStride = 32;
+static constexpr int kChainExitWord = kChainMaxJobs * 8 * kChainSyncStride;
+static constexpr int kChainErrorWord = kChainExitWord + kChainSyncStride;
+static constexpr int kChainSyncInts = kChainErrorWord + kChainSyncStride;
+static constexpr uint64_t kChainWaitTicks = 200000000ull;  // 2 s of the 100 MHz wall clock
+
+// Block-wide: returns once every block of job `job - 1` has counted itself done (job 0 waits for nothing).
+__device__ __forceinline__ void chain_wait(int* __restrict__ sync, const WideJob* __restrict__ jobs, int job, char* smem) {
+  if (job > 0 && threadIdx.x < 64) {
+    const int target = jobs[job - 1].nblocks;
+    int* const word = sync + ((job - 1) * 8 + ((int)threadIdx.x & 7)) * kChainSyncStride;
+    const uint64_t t_start = wall_clock64();
+    uint32_t polls = 0;
+    while (true) {
+      int v = (int)threadIdx.x < 8 ? __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+      if ((++polls & 255u) == 0 && wall_clock64() - t_start > kChainWaitTicks) {
+        if (threadIdx.x == 0) __hip_atomic_store(sync + kChainErrorWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// A block's last act: the block that leaves last clears the counters for the next launch.
+__device__ __forceinline__ void chain_leave(int* __restrict__ sync, int njobs) {
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(sync + kChainExitWord, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == (int)gridDim.x - 1) {
+      for (int i = 0; i < njobs * 8; ++i)
+        __hip_atomic_store(sync + i * kChainSyncStride, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sync + kChainExitWord, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <typename T, bool XS_EXT, int MT, bool CHAIN>
+__device__ __forceinline__ void wide_body(const WideJob* __restrict__ jobs, int njobs, int M, int* __restrict__ sync,
+                                          char* smem) {
   constexpr bool ZPM = ZpOnMatrixCores<T>::value;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   float* xsumS = reinterpret_cast<float*>(smem + Wide::kXsumOff);
   int* flag = reinterpret_cast<int*>(smem + Wide::kFlagOff);
   const int tid = threadIdx.x;
@@ -633,28 +706,75 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   const int kw = wid & 3, nw = wid >> 2;
   const int i16 = lane & 15, g = lane >> 4;
   const int r32 = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.z * kGemmBM;
-  const int total_stages = K / Wide::kStageK;
-  const int st0 = blockIdx.y * stages_per_split;
-  const int nst = min(stages_per_split, total_stages - st0);
-  const int n0 = blockIdx.x * 128 + nw * 64;
-  const int64_t nstrips = N / 16;
-  const int qcols = N / 8;
-  [[maybe_unused]] const int blin = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int m0 = CHAIN ? 0 : blockIdx.z * kGemmBM;
+  // ---- the job this block works on (set_job), under the names the single-job kernel's parameters had
+  const uint16_t* x = nullptr;
+  const int32_t* packed = nullptr;
+  const uint16_t* scales = nullptr;
+  const int32_t* qzeros = nullptr;
+  const float* xsum_in = nullptr;
+  int64_t x_stride = 0, xs_stride = 0;
+  int N = 0, bx = 0, by = 0;
+  int st0 = 0, nst = 0, n0 = 0, qcols = 0;
+  int64_t nstrips = 0;
+  uint32_t xoff[8];
+  uint32_t wvoff = 0;
+  [[maybe_unused]] const int blin = CHAIN ? (int)blockIdx.x : (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+  auto set_job = [&](int jj) {
+    const WideJob& J = jobs[jj];
+    x = J.x;
+    packed = J.packed;
+    scales = J.scales;
+    qzeros = J.qzeros;
+    xsum_in = J.xsum_in;
+    x_stride = J.x_stride;
+    xs_stride = J.xs_stride;
+    N = J.N;
+    if constexpr (CHAIN) {
+      bx = (int)blockIdx.x % J.grid_x;
+      by = (int)blockIdx.x / J.grid_x;
+    } else {
+      bx = blockIdx.x;
+      by = blockIdx.y;
+    }
+    const int total_stages = J.K / Wide::kStageK;
+    st0 = by * J.stages_per_split;
+    nst = min(J.stages_per_split, total_stages - st0);
+    n0 = bx * 128 + nw * 64;
+    nstrips = N / 16;
+    qcols = N / 8;
+    // ---- x DMA: wave w fills pieces 8w .. 8w+7 of a stage; piece p = (tile p >> 4, rows 4 * (p & 15) + g)
+    // byte offset of this lane's 16-byte source chunk inside stage 0, biased so that "uniform base + 32-bit lane offset
+    // + instruction offset" addresses it: piece j is issued with instruction offset 1024 * (j & 3) (which also moves
+    // its LDS destination), the base is moved back by 3072 bytes, and the lane offset carries 3072 - 1024 * (j & 3)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = 8 * wid + j;
+      const int row = 4 * (p & 15) + g;
+      xoff[j] = (uint32_t)(2 * (min(m0 + row, M - 1) * x_stride + 128 * (p >> 4) + 8 * (i16 ^ (row & 15))) + 3072 -
+                           1024 * (j & 3));
+    }
+    // ---- weights: strip t of group gq is 1 KiB at ((gq * nstrips) + n0/16 + t) * 1024 (see load_w)
+    wvoff = (uint32_t)((((int64_t)kw * nstrips + (n0 >> 4) + (r32 >> 4)) * 64 + i16 + 16 * h) * 16);
+  };
+  // first job with work for this block at or after `from` (a single-job launch: job 0)
+  auto next_job = [&](int from) {
+    if constexpr (CHAIN) {
+      int jj = from;
+      while (jj < njobs && (int)blockIdx.x >= jobs[jj].nblocks) ++jj;
+      return jj;
+    } else {
+      return from;
+    }
+  };
+  int job = next_job(0);
+  if (CHAIN && job >= njobs) {
+    chain_leave(sync, njobs);
+    return;
+  }
+  set_job(job);
   SGLK_STAMP(0);
 
-  // ---- x DMA: wave w fills pieces 8w .. 8w+7 of a stage; piece p = (tile p >> 4, rows 4 * (p & 15) + g)
-  // byte offset of this lane's 16-byte source chunk inside stage 0, biased so that "uniform base + 32-bit lane offset +
-  // instruction offset" addresses it: piece j is issued with instruction offset 1024 * (j & 3) (which also moves its
-  // LDS destination), the base is moved back by 3072 bytes, and the lane offset carries 3072 - 1024 * (j & 3)
-  uint32_t xoff[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int p = 8 * wid + j;
-    const int row = 4 * (p & 15) + g;
-    xoff[j] = (uint32_t)(2 * (min(m0 + row, M - 1) * x_stride + 128 * (p >> 4) + 8 * (i16 ^ (row & 15))) + 3072 -
-                         1024 * (j & 3));
-  }
   // four 1-KiB pieces as raw instructions in the scalar-base form (uniform 64-bit base in SGPRs, 32-bit lane offset,
   // instruction offset): through the builtin every piece costs two 64-bit vector adds for its address
   // Look-ahead requests past the split's end are issued with every lane switched off (live = 0): the instruction
@@ -742,7 +862,6 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   // it is this lane's B operand source of k-step 2 d + j.  Issued as raw instructions so that the compiler neither
   // counts them nor waits for them: the counted vmcnt at each stage boundary (bound to the registers through its
   // operands) is the only wait.
-  const uint32_t wvoff = (uint32_t)((((int64_t)kw * nstrips + (n0 >> 4) + (r32 >> 4)) * 64 + i16 + 16 * h) * 16);
   auto load_w = [&](int stage, int4v(&w)[4]) {
     const char* src = reinterpret_cast<const char*>(packed) + (int64_t)(st0 + min(stage, nst - 1)) * 4 * nstrips * 1024;
     uint64_t saved;
@@ -771,13 +890,16 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
   // so the matrix cores add straight into it; moving to the next group multiplies R by s_g / s_{g+1}.
   // A column whose scale is zero keeps its previous unit (see below); non-finite scales propagate.
   float16v R[2][2];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) R[ct][rt][e] = 0.f;
   float s_cur[2] = {1.f, 1.f};
+  auto reset_acc = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) R[ct][rt][e] = 0.f;
+    s_cur[0] = s_cur[1] = 1.f;
+  };
   // AWQ order {0,4,1,5,2,6,3,7} in arithmetic: a table lookup here would be a load the stage pipeline waits for
   const int zsh = 4 * (((r32 & 7) >> 1) + 4 * (r32 & 1));
   // A operand of k-step s, row tile rt: 16 bytes at row 32 rt + r, chunk 2 s + h of this wave's x tile
@@ -888,6 +1010,26 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
 #endif
 
   int4v wreg[3][4];
+  if constexpr (CHAIN) {
+    // what the first job needs and no other job writes: its first two stages of scales, zeros and weights
+    issue_sz(0, 0);
+    load_w(0, wreg[0]);
+    issue_sz(1, 1);
+    load_w(1, wreg[1]);
+  }
+  while (true) {
+  reset_acc();
+  msk[0] = msk[1] = nib_mask;
+  orc[0] = orc[1] = or_const;
+  if constexpr (CHAIN) {
+    // the activations of this job are what the job before it wrote: wait until all of its blocks have counted
+    // themselves done, then fetch the first stage; everything older (the prefetched weights) lands with it
+    chain_wait(sync, jobs, job, smem);
+    issue_x(0, 0);
+    SGLK_STAMP(19);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(wreg[0][0]), "+v"(wreg[0][1]), "+v"(wreg[0][2]), "+v"(wreg[0][3]),
+                 "+v"(wreg[1][0]), "+v"(wreg[1][1]), "+v"(wreg[1][2]), "+v"(wreg[1][3])::"memory");
+  } else {
   // prologue: sz(0), w(0), x(0), sz(1), w(1); then X(0)
   issue_sz(0, 0);
   load_w(0, wreg[0]);
@@ -900,6 +1042,7 @@ __global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
     SGLK_STAMP(20);
   }
   stage_wait(wreg[0]);  // sz(0), w(0), x(0) landed; sz(1) and w(1) fly on
+  }
   SGLK_STAMP(21);
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -1022,6 +1165,29 @@ stages_done:
   asm volatile("" ::: "memory");
 
   SGLK_STAMP(12);
+  // ---- what the epilogue needs of this job; in a chain the next job's set-up follows at once
+  const WideJob& EJ = jobs[job];
+  const int ebx = bx, eby = by, eN = N;
+  const int done_job = job;
+  if constexpr (CHAIN) {
+    job = next_job(job + 1);
+    if (job < njobs) {
+      set_job(job);
+      issue_sz(0, 0);
+      load_w(0, wreg[0]);
+      issue_sz(1, 1);
+      load_w(1, wreg[1]);
+    }
+  }
+  [&]() {
+  uint16_t* const out = EJ.out;
+  float* const partial = EJ.partial;
+  int* const tickets = EJ.tickets;
+  const uint16_t* const bias = EJ.bias;
+  float* const xsum_out = EJ.xsum_out;
+  const int64_t out_stride = EJ.out_stride, xs_out_stride = EJ.xs_out_stride;
+  const int splits = EJ.splits, partial_mode = EJ.partial_mode, act_mode = EJ.act_mode;
+  const int N = eN;  // (shadows the job variable, which may already name the next job)
   // ---- add the four k-waves of each column chunk up through LDS.  red[wave][tile = 2 ct + rt][j][lane] holds
   // registers 4 j .. 4 j + 3 of a wave's tile (128 KiB: the x stages); wave w then finishes the block's tile
   // (column tile cc = w >> 1 of four, row tile w & 1).
@@ -1056,9 +1222,9 @@ stages_done:
     // Wave w finishes registers 8 hf .. 8 hf + 7 (hf = w & 1) of output tile (column tile cc2 = w >> 2, row tile
     // rt = (w >> 1) & 1); the block's row sums (for the next projection's zero-point term) go to xsum_out, two
     // blocks per 128-column group, by one atomic add per row and block (two addends: order-independent).
-    float* rs = reinterpret_cast<float*>(smem + Wide::kSzOff);  // [2 column tiles][64 rows], the sz ring is idle now
+    float* rs = reinterpret_cast<float*>(smem + Wide::kXsumOff);  // [2 column tiles][64 rows]: the block-sum slots are idle now
     const int cc2 = wid >> 2, rt = (wid >> 1) & 1, hf = wid & 1;
-    const int ncol = blockIdx.x * 64 + 32 * cc2 + r32;
+    const int ncol = ebx * 64 + 32 * cc2 + r32;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
       const int j = 2 * hf + jj;
@@ -1089,7 +1255,7 @@ stages_done:
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (tid < 64 && m0 + tid < M)
-        atomicAdd(&xsum_out[(int64_t)(blockIdx.x >> 1) * xs_out_stride + m0 + tid], rs[tid] + rs[64 + tid]);
+        atomicAdd(&xsum_out[(int64_t)(ebx >> 1) * xs_out_stride + m0 + tid], rs[tid] + rs[64 + tid]);
     }
     return;
   }
@@ -1098,15 +1264,15 @@ stages_done:
   float4v fin[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) fin[j] = ksum(cc, frt, j);
-  // lane (r, h) of wave w now holds rows 32 frt + e + 8 j + 4 h (fin[j][e]) of column blockIdx.x * 128 + 32 cc + r
-  const int n = blockIdx.x * 128 + 32 * cc + r32;
+  // lane (r, h) of wave w now holds rows 32 frt + e + 8 j + 4 h (fin[j][e]) of column ebx * 128 + 32 cc + r
+  const int n = ebx * 128 + 32 * cc + r32;
   const int mrow = m0 + 32 * frt + 4 * h;
   if constexpr ((SGLK_ABL & 64) != 0) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::"v"(fin[0]), "v"(fin[1]), "v"(fin[2]), "v"(fin[3]) : "memory");
     SGLK_STAMP(15);
   }
   if (partial_mode) {
-    float* dst = partial + (int64_t)blockIdx.y * M * N;
+    float* dst = partial + (int64_t)eby * M * N;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1139,7 +1305,7 @@ stages_done:
   // split-K: slab[tile][split] holds the block's 64 x 128 fp32 tile as [wave w][j][lane] float4.
   // Slabs are written and read with 16-byte agent-scope (write-through / cache-bypassing) accesses, so that no
   // whole-cache write-back or invalidate is needed around the ticket.
-  const int tile = blockIdx.z * gridDim.x + blockIdx.x;
+  const int tile = (CHAIN ? 0 : (int)(blockIdx.z * gridDim.x)) + ebx;
   float* const tslab = partial + (int64_t)tile * splits * Wide::kTileFloats;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(tslab, 0, splits * Wide::kTileFloats * 4, 0x00020000);
   constexpr int kSc1 = 16;  // cache policy bit of the buffer instructions: agent scope
@@ -1147,7 +1313,7 @@ stages_done:
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, fin[j]), rsrc, voff + j * 1024,
-                                           (int)blockIdx.y * Wide::kTileFloats * 4, kSc1);
+                                           eby * Wide::kTileFloats * 4, kSc1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
   __builtin_amdgcn_s_barrier();
   if (tid == 0) {
@@ -1189,6 +1355,38 @@ stages_done:
         if (m < M) out[(int64_t)m * out_stride + n] = Conv<T>::from_f32(a[j][e] + bv);
       }
   }
+  }();
+  if constexpr (!CHAIN) break;
+  // ---- hand-over: every store of this block acknowledged, then one count; the next job starts at the top
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (tid == 0)
+    __hip_atomic_fetch_add(sync + (done_job * 8 + ((int)blockIdx.x & 7)) * kChainSyncStride, 1, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+  if (job >= njobs) break;
+  }  // while (true): jobs
+  if constexpr (CHAIN) chain_leave(sync, njobs);
+}
+
+template <typename T, bool XS_EXT, int MT = 2>
+__global__ void __launch_bounds__(512, 2) awq_gemm_wide_kernel(
+    const uint16_t* __restrict__ x, const int32_t* __restrict__ packed, const uint16_t* __restrict__ scales,
+    const int32_t* __restrict__ qzeros, const uint16_t* __restrict__ bias, uint16_t* __restrict__ out,
+    float* __restrict__ partial, int* __restrict__ tickets, int M, int N, int K, int stages_per_split, int splits,
+    int64_t x_stride, int64_t out_stride, const float* __restrict__ xsum_in, int64_t xs_stride, int partial_mode,
+    int act_mode, float* __restrict__ xsum_out, int64_t xs_out_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const WideJob job{x,         packed,     scales,    qzeros,        bias, out, partial,          tickets, xsum_in,
+                    xsum_out,  x_stride,   out_stride, xs_stride,    xs_out_stride, N,   K,       stages_per_split,
+                    splits,    partial_mode, act_mode, 0,            0};
+  wide_body<T, XS_EXT, MT, false>(&job, 1, M, nullptr, smem);
+}
+
+// The jobs of a chain, one persistent block per CU (see wide_body).  Block sums always come from the producers.
+template <typename T, int MT>
+__global__ void __launch_bounds__(512, 2) awq_chain_kernel(const ChainJobs cj, int M, int* __restrict__ sync) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  wide_body<T, true, MT, true>(cj.job, cj.njobs, M, sync, smem);
 }
 
 struct GemmPlan {
@@ -1410,6 +1608,97 @@ int sglk_awq_gemm_silu_mul(const void* x, const int32_t* packed, const void* sca
   wp.splits = 1;
   return launch_awq_wide(wp, x, packed, scales, qzeros, nullptr, out, nullptr, nullptr, M, N, K, x_stride, out_stride,
                          dtype, xsum, xs_stride, 0, (hipStream_t)stream, 1, xsum_out, xs_out_stride);
+}
+
+// ---- several projections in one launch of persistent blocks (see wide_body) ------------------------------------
+int64_t sglk_awq_chain_sync_bytes(void) { return (int64_t)kChainSyncInts * 4; }
+
+int sglk_awq_chain_status(const void* sync) {
+  if (!sync) return fail(SGLK_EINVAL, "awq_chain_status: null pointer");
+  int word = 0;
+  SGLK_HIP(hipMemcpy(&word, reinterpret_cast<const int*>(sync) + kChainErrorWord, sizeof(int), hipMemcpyDeviceToHost));
+  return word != 0 ? 1 : 0;
+}
+
+int sglk_awq_chain(const sglk_chain_job* jobs, int njobs, void* sync, int M, int group_size, int dtype, void* stream) {
+  SGLK_CHECK(jobs && sync, "awq_chain: null pointer");
+  SGLK_CHECK(njobs >= 1 && njobs <= kChainMaxJobs, "awq_chain: 1..%d jobs", kChainMaxJobs);
+  SGLK_CHECK(M > 0 && M <= kGemmBM, "awq_chain: at most %d rows (got %d)", kGemmBM, M);
+  SGLK_CHECK(dtype == SGLK_F16 || dtype == SGLK_BF16, "awq_chain: 16-bit activations only");
+  static int cu_count = 0;
+  if (!cu_count) {
+    int dev = 0;
+    SGLK_HIP(hipGetDevice(&dev));
+    SGLK_HIP(hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, dev));
+  }
+  ChainJobs cj{};
+  cj.njobs = njobs;
+  int grid = 0;
+  for (int i = 0; i < njobs; ++i) {
+    const sglk_chain_job& a = jobs[i];
+    SGLK_CHECK(a.x && a.packed && a.scales && a.qzeros && a.xsum_in, "awq_chain: job %d: null pointer", i);
+    SGLK_CHECK(a.kind == SGLK_CHAIN_PARTIAL || a.kind == SGLK_CHAIN_SILU_MUL, "awq_chain: job %d: unknown kind %d", i, a.kind);
+    SGLK_CHECK(a.N > 0 && a.K > 0, "awq_chain: job %d: bad shape", i);
+    SGLK_CHECK(aligned16(a.x) && a.x_stride % 8 == 0, "awq_chain: job %d: x rows must be 16-byte aligned", i);
+    SGLK_CHECK(a.xs_stride >= M, "awq_chain: job %d: xs_stride smaller than M", i);
+    WidePlan wp = plan_awq_wide(M, a.N, a.K, group_size, true);
+    if (!wp.ok)
+      return fail(SGLK_EUNSUP, "awq_chain: job %d needs K %% 512 == 0, N %% 128 == 0 and group size 128 (K=%d N=%d G=%d)", i,
+                  a.K, a.N, group_size);
+    WideJob& j = cj.job[i];
+    j = WideJob{};
+    if (a.kind == SGLK_CHAIN_SILU_MUL) {
+      SGLK_CHECK(a.out && a.N % 256 == 0 && a.out_stride >= a.N / 2, "awq_chain: job %d: gated activation needs out and N %% 256 == 0", i);
+      SGLK_CHECK(!a.xsum_out || a.xs_out_stride >= M, "awq_chain: job %d: xs_out_stride smaller than M", i);
+      wp.stages_per_split = a.K / Wide::kStageK;  // the activation needs whole sums: one split
+      wp.splits = 1;
+      j.act_mode = 1;
+    } else {
+      SGLK_CHECK(a.partial, "awq_chain: job %d: no room for the partial sums", i);
+      SGLK_CHECK(a.splits_expected == 0 || a.splits_expected == wp.splits,
+                 "awq_chain: job %d: the caller expects %d splits, the plan has %d", i, a.splits_expected, wp.splits);
+      j.partial_mode = 1;
+    }
+    j.x = (const uint16_t*)a.x;
+    j.packed = a.packed;
+    j.scales = (const uint16_t*)a.scales;
+    j.qzeros = a.qzeros;
+    j.out = (uint16_t*)a.out;
+    j.partial = a.partial;
+    j.xsum_in = a.xsum_in;
+    j.xsum_out = a.xsum_out;
+    j.x_stride = a.x_stride;
+    j.out_stride = a.kind == SGLK_CHAIN_SILU_MUL ? a.out_stride : a.N;
+    j.xs_stride = a.xs_stride;
+    j.xs_out_stride = a.xs_out_stride;
+    j.N = a.N;
+    j.K = a.K;
+    j.stages_per_split = wp.stages_per_split;
+    j.splits = wp.splits;
+    j.grid_x = a.N / 128;
+    j.nblocks = j.grid_x * wp.splits;
+    grid = std::max(grid, j.nblocks);
+  }
+  // every block waits for blocks of the same launch: all of them must be resident at once (one per CU)
+  if (grid > cu_count)
+    return fail(SGLK_EUNSUP, "awq_chain: %d blocks do not fit the %d CUs of this device at once", grid, cu_count);
+  hipStream_t s = (hipStream_t)stream;
+#define SGLK_CHAIN_LAUNCH(MQ)                                                                                       \
+  {                                                                                                                 \
+    static bool attr_set = false;                                                                                   \
+    if (!attr_set) {                                                                                                \
+      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_chain_kernel<T, MQ>),                         \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));                        \
+      attr_set = true;                                                                                              \
+    }                                                                                                               \
+    hipLaunchKernelGGL((awq_chain_kernel<T, MQ>), dim3(grid), dim3(512), Wide::kLds, s, cj, M, (int*)sync);         \
+  }
+  SGLK_DISPATCH_HALF(dtype, T, {
+    if (M <= 32) SGLK_CHAIN_LAUNCH(1) else SGLK_CHAIN_LAUNCH(2)
+  });
+#undef SGLK_CHAIN_LAUNCH
+  SGLK_LAUNCH_CHECK();
+  return SGLK_OK;
 }
 
 int sglk_awq_gemm_xs(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros, const void* bias,

@@ -45,6 +45,8 @@ struct f16_t {
 typedef short short8 __attribute__((ext_vector_type(8)));
 typedef short short4v __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef int int4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));

@@ -340,6 +340,12 @@ class LlamaDecoder:
         self.fold_rope = False
         # gate_up with the activation in its epilogue: columns interleaved in blocks of 64 (gate, up, gate, up, ...)
         self.fused_act = self.fused and c.inter % 128 == 0 and c.hidden % 512 == 0
+        # gate_up and down in one launch of persistent blocks (ops.awq_chain), SGLK_CHAIN=1: off by default -- the
+        # hand-over between the two jobs (stores acknowledged, count, poll, first activation stage fetched) takes as
+        # long as the kernel boundary and the prologue it replaces, and the step measured 4 % slower with it
+        self.chain = self.fused and self.B <= 64 and os.environ.get("SGLK_CHAIN", "0") == "1"
+        if self.chain:
+            self.chain_sync = ops.awq_chain_sync(self.device)
         if self.fused_act:
             for L in self.layers:
                 w = L["gate_up"]
@@ -429,6 +435,14 @@ class LlamaDecoder:
                 self._tp_sum()
                 ops.fused_add_rmsnorm_ex(self.hidden, self.residual, L["ln2"], c.eps, xsum_out=self.xs_hidden,
                                          zero_out=self.xs_act if self.fused_act else None)
+            if self.fused_act and tp is None and self.chain:
+                # gate_up (+ activation) and down in one launch of persistent blocks: the down projection's first
+                # weights are on their way while gate_up's blocks still reduce and store
+                il, w = L["gate_up_il"], L["down"]
+                self._timed("gate_up+down", lambda: ops.awq_chain(
+                    [ops.chain_silu_mul(self.hidden, il[0], il[1], il[2], self.xs_hidden, self.act, self.xs_act),
+                     ops.chain_partial(self.act, w.packed, w.scales, w.qzeros, self.xs_act, P)], self.chain_sync))
+                continue
             if self.fused_act:
                 il = L["gate_up_il"]
                 self._timed("gate_up", lambda: ops.awq_gemm_silu_mul(self.hidden, il[0], il[1], il[2], self.act,

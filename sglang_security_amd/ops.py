@@ -5,6 +5,7 @@ Function names and argument order follow the reference callers they replace (cit
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from typing import Optional
 
@@ -1140,6 +1141,71 @@ def awq_gemm_silu_mul(x, packed, scales, qzeros, out, xsum=None, xsum_out=None):
                                        0 if xsum is None else xsum.stride(0), _ptr(xsum_out),
                                        0 if xsum_out is None else xsum_out.stride(0), _stream(x)), "awq_gemm_silu_mul")
     return out
+
+
+class _ChainJob(C.Structure):
+    # sglk_chain_job (include/sglk.h)
+    _fields_ = [("kind", C.c_int), ("N", C.c_int), ("K", C.c_int), ("splits_expected", C.c_int), ("x", C.c_void_p),
+                ("x_stride", C.c_int64), ("packed", C.c_void_p), ("scales", C.c_void_p), ("qzeros", C.c_void_p),
+                ("xsum_in", C.c_void_p), ("xs_stride", C.c_int64), ("out", C.c_void_p), ("out_stride", C.c_int64),
+                ("partial", C.c_void_p), ("xsum_out", C.c_void_p), ("xs_out_stride", C.c_int64)]
+
+
+def awq_chain_sync(device) -> torch.Tensor:
+    """The counters of awq_chain (zero-filled; every launch leaves them zero)."""
+    return torch.zeros(int(lib().sglk_awq_chain_sync_bytes()) // 4, dtype=torch.int32, device=device)
+
+
+def awq_chain_status(sync) -> int:
+    """1 if a block of a chain launched over `sync` gave up waiting for its producers (synchronises)."""
+    return int(lib().sglk_awq_chain_status(_ptr(sync)))
+
+
+def chain_partial(x, packed, scales, qzeros, xsum, partial):
+    """A job of awq_chain: awq_gemm_partial(x, packed, scales, qzeros, partial, xsum)."""
+    return dict(kind=0, x=x, packed=packed, scales=scales, qzeros=qzeros, xsum=xsum, partial=partial)
+
+
+def chain_silu_mul(x, packed, scales, qzeros, xsum, out, xsum_out=None):
+    """A job of awq_chain: awq_gemm_silu_mul(x, packed, scales, qzeros, out, xsum, xsum_out)."""
+    return dict(kind=1, x=x, packed=packed, scales=scales, qzeros=qzeros, xsum=xsum, out=out, xsum_out=xsum_out)
+
+
+def awq_chain(jobs, sync):
+    """Several projections in one launch of persistent blocks, each multiplying what the one before it wrote (jobs:
+    chain_partial / chain_silu_mul records, in order).  Same bits as the separate launches."""
+    n = len(jobs)
+    arr = (_ChainJob * n)()
+    M = jobs[0]["x"].shape[0]
+    group = None
+    for i, j in enumerate(jobs):
+        x, sc = j["x"], j["scales"]
+        _need_gpu(x, j["packed"], sc, j["qzeros"], j["xsum"])
+        if x.shape[0] != M:
+            raise SglkError("awq_chain: every job multiplies the same rows")
+        K, N = x.shape[1], sc.shape[1]
+        g = K // sc.shape[0]
+        if group is not None and g != group:
+            raise SglkError("awq_chain: one group size per chain")
+        group = g
+        a = arr[i]
+        a.kind, a.N, a.K, a.splits_expected = j["kind"], N, K, 0
+        a.x, a.x_stride = _ptr(x), x.stride(0)
+        a.packed, a.scales, a.qzeros = _ptr(j["packed"]), _ptr(sc), _ptr(j["qzeros"])
+        a.xsum_in, a.xs_stride = _ptr(j["xsum"]), j["xsum"].stride(0)
+        if j["kind"] == 0:
+            part = j["partial"]
+            splits = awq_gemm_partial_splits(M, N, K, g)
+            if part.dtype != torch.float32 or part.numel() < splits * M * N:
+                raise SglkError(f"awq_chain: job {i}: partial must hold {splits} x {M} x {N} fp32")
+            a.partial, a.splits_expected = _ptr(part), splits
+        else:
+            out, xo = j["out"], j.get("xsum_out")
+            _need_gpu(out)
+            a.out, a.out_stride = _ptr(out), out.stride(0)
+            a.xsum_out, a.xs_out_stride = _ptr(xo), 0 if xo is None else xo.stride(0)
+    x0 = jobs[0]["x"]
+    check(lib().sglk_awq_chain(arr, n, _ptr(sync), M, group, dtype_code(x0.dtype), _stream(x0)), "awq_chain")
 
 
 def fused_add_rmsnorm_ex(x, residual, weight, eps, gemma=False, partials=None, splits=0, bias=None, xsum_out=None,

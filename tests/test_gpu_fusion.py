@@ -115,6 +115,46 @@ def test_awq_gemm_partial_and_block_sums(M, K, N):
     assert (out.float().cpu() - want).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("M", [64, 17])
+def test_awq_chain_gate_up_down_equals_separate_launches(M):
+    """gate_up (+ gated activation) and down in one launch of persistent blocks against the two separate launches, at
+    Llama-3-8B's shapes: the activation rows, their block sums and the down projection's split sums must be the same
+    bits; twice over one set of counters (every launch leaves them zero)."""
+    ops = _ops()
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_ops import _awq_case
+
+    hidden, inter = 4096, 14336
+    x, qw, sc, qz = _awq_case(M, hidden, 2 * inter, 128, torch.bfloat16, seed=1)
+    _, qw2, sc2, qz2 = _awq_case(M, inter, hidden, 128, torch.bfloat16, seed=2)
+    xd = x.to(DEV)
+    qi, si, zi = ops.awq_interleave_gate_up(qw.to(DEV), sc.to(DEV), qz.to(DEV))
+    gu = (ops.awq_repack(qi), si, zi)
+    dn = (ops.awq_repack(qw2.to(DEV)), sc2.to(DEV), qz2.to(DEV))
+    xs = _block_sums(xd)
+    splits = ops.awq_gemm_partial_splits(M, hidden, inter)
+    # separate launches
+    act1 = torch.empty(M, inter, dtype=torch.bfloat16, device=DEV)
+    xs_act1 = torch.zeros(inter // 128, M, device=DEV)
+    part1 = torch.full((splits, M, hidden), float("nan"), device=DEV)
+    ops.awq_gemm_silu_mul(xd, *gu, act1, xs, xs_act1)
+    ops.awq_gemm_partial(act1, *dn, part1, xs_act1)
+    # one launch
+    sync = ops.awq_chain_sync(DEV)
+    for rep in range(2):
+        act2 = torch.full((M, inter), float("nan"), dtype=torch.bfloat16, device=DEV)
+        xs_act2 = torch.zeros(inter // 128, M, device=DEV)
+        part2 = torch.full((splits, M, hidden), float("nan"), device=DEV)
+        ops.awq_chain([ops.chain_silu_mul(xd, *gu, xs, act2, xs_act2), ops.chain_partial(act2, *dn, xs_act2, part2)], sync)
+        torch.cuda.synchronize()
+        assert ops.awq_chain_status(sync) == 0
+        assert int(sync.abs().sum()) == 0
+        assert torch.equal(act1.view(torch.int16), act2.view(torch.int16))
+        assert torch.equal(xs_act1, xs_act2)
+        assert torch.equal(part1, part2)
+
+
 def test_attention_block_sums():
     import sys, os
     sys.path.insert(0, os.path.dirname(__file__))

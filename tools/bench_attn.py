@@ -22,6 +22,7 @@ ap.add_argument("--head-major", action="store_true",
                 help="experiment: pools laid out [Hkv][tokens][D] (a kv head's rows contiguous) instead of [tokens][Hkv][D]")
 ap.add_argument("--rope", action="store_true",
                 help="the launch that assembles q and the new K / V rows from split-K partial sums of the qkv projection")
+ap.add_argument("--planned", action="store_true", help="the kernel driven by a per-step plan laid out on the device")
 ap.add_argument("--stamps", action="store_true",
                 help="phase stamps of one launch (library built by ATTN=1 tools/build_abl.sh, named by SGLK_LIB)")
 args = ap.parse_args()
@@ -59,8 +60,21 @@ positions = torch.full((B,), P + Tl - 1, dtype=torch.int64, device=dev)
 loc = ind[(ptr[1:] - 1).long()].to(torch.int64)
 
 
+plan = None
+if args.planned:
+    r2t = torch.zeros(B, P + Tl + 4, dtype=torch.int32, device=dev)
+    for b in range(B):
+        r2t[b, : P + Tl] = rows[b].to(dev)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, args.splits, dev)
+    ops.decode_shared_plan(r2t, torch.arange(B, device=dev), torch.full((B,), P + Tl, device=dev), ptr, ind, Hq, Hkv,
+                           args.splits, plan)
+
+
 def run(i):
     kb, vb = pools[i % args.pools]
+    if plan is not None:
+        ops.decode_attention_shared_planned(q, kb, vb, o, ptr, ind, plan, ws, args.splits, sm, 0.0, xs)
+        return
     if args.rope:
         ops.decode_attention_shared_prefix_rope(parts[i % args.pools], qsplits, B * row_len, None, cos_sin, positions, loc,
                                                 kb, vb, o, ptr, ind, gi, pls, ws, args.splits, sm, 0.0, xs)
