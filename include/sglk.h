@@ -167,6 +167,22 @@ SGLK_API int sglk_decode_attention_shared_planned(
     int D, int Dv, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h,
     int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
     float logit_cap, int dtype, float* xsum_out, int64_t xs_stride, const int32_t* num_kv_splits, void* stream);
+/* sglk_rope_and_store_kv_partial and sglk_decode_attention_shared_planned in ONE launch: the rotation + pool write
+ * (models/llama.py:176-178 rotary_emb, then RadixAttention's set_kv_buffer, triton_backend.py:806-810) runs as the
+ * first blocks of the attention launch; the attention blocks fetch their slot lists and K / V rows meanwhile and wait
+ * per request, on a counter, only where they first need a query row or the new row's slot.  q_out receives the rotated
+ * query rows (row stride q_stride_b elements; the attention reads them from there), the pools receive the new K / V
+ * rows; same bits as the two separate entry points.  launch_in_step: 1 for a step's first call on this plan, 2 for
+ * its second, ... (the counters live in the plan, which sglk_decode_shared_plan* clears once per step; a decoder
+ * layer's index + 1).  16-bit types, D = Dv = 128, rot_dim = 128, interleave = 0; plan is written (the counters). */
+SGLK_API int sglk_decode_attention_shared_planned_rope(
+    const float* qkv_partials, int splits, int64_t part_stride, const void* qkv_bias, const float* cos_sin_cache,
+    const int64_t* positions, int rot_dim, int interleave, const void* loc, int loc_is64, void* q_out,
+    int64_t q_stride_b, void* k_buffer, void* v_buffer, void* o, const int32_t* kv_indptr,
+    const int32_t* kv_indices, int32_t* plan, int launch_in_step, float* workspace, int max_kv_splits, int B,
+    int Hq, int Hkv, int D, int Dv, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+    int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale, float logit_cap, int dtype,
+    float* xsum_out, int64_t xs_stride, void* stream);
 SGLK_API int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits);
 SGLK_API int sglk_decode_shared_workspace_init(void* workspace, int B, int Hq, void* stream);
 SGLK_API int sglk_decode_shared_workspace_status(const void* workspace, int B, int Hq);

@@ -45,6 +45,8 @@ _SIGS = {
     "sglk_decode_shared_plan_from_groups": (i32, [p, p, p, p, i32, i32, i32, i32, i32, p, p]),
     "sglk_decode_metadata_shared": (i32, [p, i64, p, i32, p, i32, p, p, p, i32, i32, i32, i32, i32, i32, p, p]),
     "sglk_decode_attention_shared_planned": (i32, [p] * 8 + [i32] * 6 + [i64] * 8 + [f32, f32, i32, p, i64, p, p]),
+    "sglk_decode_attention_shared_planned_rope": (i32, [p, i32, i64, p, p, p, i32, i32, p, i32, p, i64, p, p, p, p, p, p, i32,
+                                                        p] + [i32] * 6 + [i64] * 6 + [f32, f32, i32, p, i64, p]),
     "sglk_decode_shared_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "sglk_decode_shared_workspace_init": (i32, [p, i32, i32, p]),
     "sglk_decode_shared_workspace_status": (i32, [p, i32, i32]),

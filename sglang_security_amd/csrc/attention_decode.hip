@@ -26,7 +26,7 @@ namespace sglk {
 
 static constexpr int kMinBlockKV = 32;  // decode_attention.py:40 (_MIN_BLOCK_KV)
 
-__device__ __forceinline__ int cdiv_i(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ __forceinline__ int cdiv_i(int a, int b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------------------
 // metadata
@@ -963,6 +963,7 @@ __global__ void __launch_bounds__(1024) shared_plan_assemble_kernel(const int32_
   }
   __syncthreads();
   __threadfence_block();
+  if (t < B) pv.lcp[t] = 0;  // from here on: ready[token] of the attention launches' rope role (read above, long ago)
   for (int w = t; w < n_items * 128; w += 1024) {
     int32_t* it = pv.items + (int64_t)(w >> 7) * kPlanItemInts;
     const int e = w & 127;
@@ -1004,12 +1005,114 @@ __device__ __forceinline__ int active_prefix_splits(int plen, int prefix_splits)
 // ROPE: q is not read; the query rows, and every request's new K / V row, come from the qkv projection's split-K
 // partial sums (qp).  A (request, kv head) pair's tail block (one head tile only) writes the pair's new pool rows
 // before it walks the request's list, whose last entry is that row's slot.
+// ---------------------------------------------------------------------------------------------
+// The rotation + pool write of a decode layer as blocks of the attention launch ("rope role").  The separate kernel
+// (rope_store_partial_kernel: sum the qkv projection's split-K partials, add the bias, round, rotate q and k, write q
+// and the token's new K / V rows) is a launch of a few microseconds between two kernels that wait for each other.
+// Here its blocks hold the lowest indices of the attention launch, never wait for anything, and count every finished
+// (token, part) in ready[token]; the attention blocks fetch their slot lists and K / V rows as before and wait for the
+// count only where they first need a query row (or, the block that walks a request's remainder, the new row's slot).
+// ready[] lives in the step's plan, which clears it once per step; the n-th launch of a step waits for parts * n.
+// Same bits as the separate kernel.  Full rotation of 128-element heads, pairs (d, d + 64).
+// ---------------------------------------------------------------------------------------------
+struct RopeRole {
+  int blocks;        // rope blocks at the head of the grid (a multiple of 8; 0: no rope role)
+  int parts;         // blocks per token
+  int tokens;
+  int target;        // value of ready[t] that says token t is done in this launch
+  int* ready;
+  uint16_t* q_out;   // rotated query rows go here (row stride q_stride_b)
+};
+
+template <typename T>
+__device__ __forceinline__ void store_wt32(uint16_t* p, uint16_t lo, uint16_t hi) {
+  // write-through (agent scope): the readers are other blocks of this launch, possibly on another XCD
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), (uint32_t)lo | ((uint32_t)hi << 16), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename T>
+__device__ __forceinline__ void rope_role_block(int r, const RopeRole& rr, const QkvPartials& qp, int64_t q_stride_b,
+                                                void* k_buffer, void* v_buffer, int64_t k_stride_n, int64_t k_stride_h,
+                                                int64_t v_stride_n, int64_t v_stride_h, int Hq, int Hkv, char* lds) {
+  uint16_t* rowS = reinterpret_cast<uint16_t*>(lds);
+  const int t = r / rr.parts, part = r - t * rr.parts;
+  if (t >= rr.tokens) return;  // padding blocks (the role's block count is rounded up to a multiple of 8)
+  const int total_heads = Hq + 2 * Hkv;
+  const int hpb = cdiv_i(total_heads, rr.parts);
+  const int h0 = part * hpb, h1 = min(h0 + hpb, total_heads);
+  if (h0 < h1) {
+    const int c0 = h0 * 128, ncol = (h1 - h0) * 128;
+    const int64_t pos = qp.positions[t];
+    const int64_t slot = ld_idx(qp.loc, qp.loc_is64, t);
+    for (int v = threadIdx.x; v < (ncol >> 3); v += blockDim.x) {
+      float acc[8];
+      sum_partials(qp.partials, qp.splits, qp.part_stride, (int64_t)t * qp.row_len + c0 + 8 * v, acc);
+      short8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float bj = qp.bias ? Conv<T>::to_f32(qp.bias[c0 + 8 * v + j]) : 0.f;
+        o[j] = (short)Conv<T>::from_f32(acc[j] + bj);
+      }
+      reinterpret_cast<short8*>(rowS)[v] = o;
+    }
+    __syncthreads();
+    const float* cs = qp.cos_sin + pos * 128;
+    uint16_t* qdst = rr.q_out + (int64_t)t * q_stride_b;
+    uint16_t* kdst = reinterpret_cast<uint16_t*>(k_buffer) + slot * k_stride_n;
+    uint16_t* vdst = reinterpret_cast<uint16_t*>(v_buffer) + slot * v_stride_n;
+    const int rot_heads = max(0, min(h1, Hq + Hkv) - h0);  // q and k heads of this block
+    // two neighbouring pairs per thread: elements (p, p + 1) and (p + 64, p + 65) leave as 4-byte stores
+    for (int i = threadIdx.x; i < rot_heads * 32; i += blockDim.x) {
+      const int hl = i >> 5, p = 2 * (i & 31), h = h0 + hl;
+      const uint16_t* v = rowS + hl * 128;
+      uint16_t ra[2], rb[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        float fa, fb;
+        rope_pair(Conv<T>::to_f32(v[p + e]), Conv<T>::to_f32(v[p + e + 64]), cs[p + e], cs[64 + p + e], fa, fb);
+        ra[e] = Conv<T>::from_f32(fa);
+        rb[e] = Conv<T>::from_f32(fb);
+      }
+      uint16_t* d = h < Hq ? qdst + h * 128 : kdst + (int64_t)(h - Hq) * k_stride_h;
+      store_wt32<T>(d + p, ra[0], ra[1]);
+      store_wt32<T>(d + p + 64, rb[0], rb[1]);
+    }
+    // v heads of this block: as they are
+    const int v0 = max(h0, Hq + Hkv);
+    for (int i = threadIdx.x; i < max(0, h1 - v0) * 64; i += blockDim.x) {
+      const int hl = i >> 6, e = 2 * (i & 63), h = v0 + hl;
+      const uint16_t* v = rowS + (h - h0) * 128;
+      store_wt32<T>(vdst + (int64_t)(h - Hq - Hkv) * v_stride_h + e, v[e], v[e + 1]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(rr.ready + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// wave-level: returns once ready[tok] has reached target for every lane's token (tok < 0: nothing to wait for)
+__device__ __forceinline__ void rope_wait(const RopeRole& rr, int tok, int* error_word) {
+  const uint64_t t_start = wall_clock64();
+  uint32_t polls = 0;
+  while (true) {
+    const bool ok = tok < 0 || __hip_atomic_load(rr.ready + tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= rr.target;
+    if (__all(ok)) break;
+    if ((++polls & 255u) == 0 && wall_clock64() - t_start > 200000000ull) {  // two seconds: raise the error word, go on
+      __hip_atomic_store(error_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
 // PLAN: group_indptr / prefix_lens are not read; plan_hdr, plan_tail and plan_items (the per-step plan above) say what
 // every block does, and the prefix blocks loop over the items (their number varies from step to step, the grid of a
 // captured launch does not).
-template <typename T, bool ROPE, bool PLAN>
+// RR: rope role (see above; PLAN only): blocks [0, rr.blocks) rotate and write, the attention blocks follow.
+template <typename T, bool ROPE, bool PLAN, bool RR = false>
 __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
-    const void* __restrict__ q, QkvPartials qp, void* k_buffer, void* v_buffer,
+    const void* q, QkvPartials qp, void* k_buffer, void* v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
     const int32_t* __restrict__ group_indptr, const int32_t* __restrict__ prefix_lens, int num_groups,
     const int32_t* __restrict__ plan_hdr, const int32_t* __restrict__ plan_tail, const int32_t* __restrict__ plan_items,
@@ -1017,7 +1120,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     int prefix_splits, int n_prefix_blocks, int col_blocks, int B, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
     int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, float sm_scale,
     float logit_cap, void* __restrict__ o, int64_t o_stride_b, int64_t o_stride_h, float* __restrict__ xsum_out,
-    int64_t xs_stride, int gated) {
+    int64_t xs_stride, int gated, RopeRole rr) {
   extern __shared__ __attribute__((aligned(16))) char lds_all[];  // 32 KiB: the prefix role's two stages of K + V tiles,
                                                                   // or the tail role's four V tiles
   __shared__ int wait_failed;
@@ -1027,12 +1130,21 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   const int heads = Hq / Hkv;
   ATTN_STAMP(0);
 
+  int bid = blockIdx.x;  // index among the attention blocks
+  if constexpr (RR) {
+    if (bid < rr.blocks) {
+      rope_role_block<T>(bid, rr, qp, q_stride_b, k_buffer, v_buffer, k_stride_n, k_stride_h, v_stride_n, v_stride_h, Hq,
+                         Hkv, lds_all);
+      return;
+    }
+    bid -= rr.blocks;
+  }
   if constexpr (PLAN) {
-    if ((int)blockIdx.x < n_prefix_blocks) {
+    if (bid < n_prefix_blocks) {
       // ---- prefix block (planned): block index = item * Hkv + kvh; items past the grid are taken in further rounds
-      const int kvh = blockIdx.x % Hkv;
+      const int kvh = bid % Hkv;
       const int items_per_round = n_prefix_blocks / Hkv;
-      int j = blockIdx.x / Hkv;
+      int j = bid / Hkv;
       const int n_items = plan_hdr[kPlanNItems];
       const int c = wid * 16 + hl;
       const int frow = threadIdx.x >> 4;
@@ -1057,6 +1169,18 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
               reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
               qpos, 0, sm_scale, logit_cap, [&]() { load_q_rotated<T>(st.qf[0], qp, req, pos, head * 128, ok); }, nullptr,
               pre);
+        } else if constexpr (RR) {
+          // the rows are on their way before the query rows are asked for: the rotation runs in their shadow
+          st.template run<false, true, kPrefixPF>(
+              lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
+              qpos, 0, sm_scale, logit_cap,
+              [&]() {
+                rope_wait(rr, req, ws.error);
+                st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
+                                : nullptr);
+              },
+              nullptr, pre);
         } else {
           st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
                           : nullptr);
@@ -1168,7 +1292,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
 
   // ---- tail block: index = (b * Hkv + kvh) * head_tiles + ht (the kv heads of one request are neighbours in dispatch
   // order: together they fetch whole pool rows)
-  int i = blockIdx.x - n_prefix_blocks;
+  int i = bid - n_prefix_blocks;
   const int ht = i % head_tiles;
   i /= head_tiles;
   const int kvh = i % Hkv, b = i / Hkv;
@@ -1226,6 +1350,15 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const auto ks = wa.begin_kd(kv_indices + start, s0, s1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+              kv_indices + start, s0, s1, sm_scale, logit_cap, ks);
+  } else if constexpr (RR) {
+    // slot lists first, then the wait: the request's query rows and its newest K / V row come from the rope blocks
+    const auto ks = wa.begin_kd(kv_indices + start, s0, s1);
+    rope_wait(rr, b, ws.error);
+    wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                      : nullptr);
     wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
               reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
               kv_indices + start, s0, s1, sm_scale, logit_cap, ks);
@@ -1607,7 +1740,8 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
                                 int Hkv, int D, int Dv, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n,
                                 int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h, int64_t o_stride_b,
                                 int64_t o_stride_h, float sm_scale, float logit_cap, int dtype, float* xsum_out,
-                                int64_t xs_stride, void* stream, bool gated = false) {
+                                int64_t xs_stride, void* stream, bool gated = false, const QkvPartials* rope_src = nullptr,
+                                void* rope_q_out = nullptr, int rope_seq = 0) {
   SGLK_CHECK(!xsum_out || xs_stride >= B, "decode_attention_shared_prefix: xs_stride smaller than B");
   SGLK_CHECK((q || qp) && k_buffer && v_buffer && o && kv_indptr && kv_indices && workspace &&
                  (plan || (group_indptr && prefix_lens)),
@@ -1666,6 +1800,19 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
   }
   const size_t lds = kBlockAttnLds;  // the prefix role's two stages; the tail role's four V tiles fit in the same bytes
   static_assert(kWavesPerBlock * kTileBytes <= kBlockAttnLds, "LDS of the prefix role must cover the tail role");
+  RopeRole rr{};
+  if (rope_src) {
+    // rope role: four blocks per token (a block of 256 threads sums, rotates and writes a quarter of the row's heads)
+    SGLK_CHECK(plan && !qp && rope_q_out && rope_seq > 0, "decode_attention_shared_planned_rope: bad arguments");
+    rr.parts = std::min(4, Hq + 2 * Hkv);
+    rr.tokens = B;
+    rr.blocks = (B * rr.parts + 7) / 8 * 8;
+    rr.target = rr.parts * rope_seq;
+    rr.ready = pv.lcp;
+    rr.q_out = reinterpret_cast<uint16_t*>(rope_q_out);
+    SGLK_CHECK((int64_t)cdiv_i(Hq + 2 * Hkv, rr.parts) * 128 * 2 <= (int64_t)kBlockAttnLds,
+               "decode_attention_shared_planned_rope: too many heads per rope block");
+  }
 #define SGLK_SHARED_LAUNCH(ROPE, PLAN, QP)                                                                             \
   SGLK_DISPATCH_HALF(dtype, T,                                                                                         \
                      hipLaunchKernelGGL((decode_shared_fused_kernel<T, ROPE, PLAN>), dim3(n_prefix + n_tail), dim3(256), \
@@ -1673,8 +1820,17 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
                                         prefix_lens, G, pv.hdr, pv.tail, pv.items, ws, prefix_splits, n_prefix,          \
                                         col_blocks, B, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,          \
                                         k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o, o_stride_b,          \
-                                        o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8)))
-  if (qp) {
+                                        o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8), rr))
+  if (rope_src) {
+    SGLK_DISPATCH_HALF(dtype, T,
+                       hipLaunchKernelGGL((decode_shared_fused_kernel<T, false, true, true>),
+                                          dim3(rr.blocks + n_prefix + n_tail), dim3(256), lds, s, q, *rope_src, k_buffer,
+                                          v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G, pv.hdr, pv.tail,
+                                          pv.items, ws, prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles,
+                                          q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale,
+                                          logit_cap, o, o_stride_b, o_stride_h, xsum_out, xs_stride,
+                                          (gated ? 1 : 0) | (env_delay << 8), rr));
+  } else if (qp) {
     // a pair's single tail block writes the pair's new rows: more than one head tile would need them across blocks
     if (head_tiles != 1)
       return fail(SGLK_EUNSUP, "decode_attention_shared_prefix_rope: at most 16 query heads per kv head (got %d)", heads);
@@ -1850,5 +2006,41 @@ int sglk_decode_attention_shared_planned(const void* q, const void* k_buffer, co
                               kv_indices, nullptr, nullptr, 0, plan, workspace, max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b,
                               q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale,
                               logit_cap, dtype, xsum_out, xs_stride, stream, num_kv_splits != nullptr);
+}
+
+int sglk_decode_attention_shared_planned_rope(const float* qkv_partials, int splits, int64_t part_stride,
+                                              const void* qkv_bias, const float* cos_sin_cache, const int64_t* positions,
+                                              int rot_dim, int interleave, const void* loc, int loc_is64, void* q_out,
+                                              int64_t q_stride_b, void* k_buffer, void* v_buffer, void* o,
+                                              const int32_t* kv_indptr, const int32_t* kv_indices, int32_t* plan,
+                                              int launch_in_step, float* workspace, int max_kv_splits, int B, int Hq, int Hkv,
+                                              int D, int Dv, int64_t k_stride_n, int64_t k_stride_h, int64_t v_stride_n,
+                                              int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h, float sm_scale,
+                                              float logit_cap, int dtype, float* xsum_out, int64_t xs_stride, void* stream) {
+  SGLK_CHECK(qkv_partials && cos_sin_cache && positions && loc && q_out && plan,
+             "decode_attention_shared_planned_rope: null pointer");
+  if (rot_dim != 128 || interleave != 0 || D != 128 || Dv != 128 || (dtype != SGLK_F16 && dtype != SGLK_BF16))
+    return fail(SGLK_EUNSUP, "decode_attention_shared_planned_rope: 16-bit types, full rotation of 128-element heads in the "
+                "(d, d + 64) pairing only (got rot_dim=%d interleave=%d D=%d Dv=%d)", rot_dim, interleave, D, Dv);
+  const int64_t row_len = (int64_t)(Hq + 2 * Hkv) * 128;
+  SGLK_CHECK(splits >= 1 && part_stride >= (int64_t)B * row_len && part_stride % 4 == 0 && aligned16(qkv_partials) &&
+                 aligned16(cos_sin_cache) && (!qkv_bias || aligned16(qkv_bias)) && aligned16(q_out) && q_stride_b % 8 == 0 &&
+                 q_stride_b >= (int64_t)Hq * 128,
+             "decode_attention_shared_planned_rope: bad partial or query layout");
+  SGLK_CHECK(launch_in_step >= 1, "decode_attention_shared_planned_rope: launches of a step are numbered from 1");
+  QkvPartials qp;
+  qp.partials = qkv_partials;
+  qp.splits = splits;
+  qp.part_stride = part_stride;
+  qp.row_len = (int)row_len;
+  qp.bias = reinterpret_cast<const uint16_t*>(qkv_bias);
+  qp.cos_sin = cos_sin_cache;
+  qp.positions = positions;
+  qp.loc = loc;
+  qp.loc_is64 = loc_is64;
+  return launch_shared_prefix(q_out, nullptr, k_buffer, v_buffer, o, kv_indptr, kv_indices, nullptr, nullptr, 0, plan,
+                              workspace, max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b, 128, k_stride_n, k_stride_h,
+                              v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride,
+                              stream, false, &qp, q_out, launch_in_step);
 }
 }

@@ -203,6 +203,11 @@ class LlamaDecoder:
         # layer fusion: block sums of every GEMM input come from its producer, split-K partials go to the consumer
         self.fused = False
         self.fold_rope = False
+        # ... and as blocks of their own at the head of the attention launch (decode_attention_shared_planned_rope):
+        # the attention blocks' first trips to memory run beside the rotation instead of behind a kernel boundary
+        # (SGLK_ROPE_ROLE=1; off: the hand-over from the rope blocks to the attention blocks -- stores acknowledged,
+        # count, poll, query rows fetched -- costs the launch what the separate kernel cost the step: measured equal)
+        self.rope_role = self.fused and c.head_dim == 128 and os.environ.get("SGLK_ROPE_ROLE", "0") == "1"
         self.xs_hidden = torch.zeros(c.hidden // 128, B, dtype=torch.float32, device=device)
         self.xs_attn = torch.zeros(self.q_size // 128, B, dtype=torch.float32, device=device)
         self.xs_act = torch.zeros(c.inter // 128, B, dtype=torch.float32, device=device)
@@ -419,6 +424,13 @@ class LlamaDecoder:
                                                         self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
                                                         self.group_indptr, self.group_prefix, self.shared_ws,
                                                         self.max_kv_splits, sm_scale, 0.0, self.xs_attn)
+            elif self.rope_role and getattr(self, "shared", False) and getattr(self, "shared_plan", None) is not None:
+                # rotation + pool write as the first blocks of the attention launch
+                ops.decode_attention_shared_planned_rope(P, S["qkv"], self.qkv.numel(), L["qkv_bias"], self.cos_sin,
+                                                         self.positions, self.out_cache_loc, q_view, self.k_pool[li],
+                                                         self.v_pool[li], o_view, self.kv_indptr, self.kv_indices,
+                                                         self.shared_plan, li + 1, self.shared_ws, self.max_kv_splits,
+                                                         sm_scale, 0.0, self.xs_attn)
             else:
                 ops.rope_and_store_kv_partial(self.qkv, P, S["qkv"], self.cos_sin, self.positions, self.k_pool[li],
                                               self.v_pool[li], self.out_cache_loc, c.q_heads, c.kv_heads, c.head_dim,

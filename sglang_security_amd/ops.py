@@ -157,6 +157,30 @@ def decode_attention_shared_planned(q, k_buffer, v_buffer, o, kv_indptr, kv_indi
         _ptr(num_kv_splits), _stream(q)), "decode_attention_shared_planned")
 
 
+def decode_attention_shared_planned_rope(partials, splits, part_stride, bias, cos_sin_cache, positions, loc, q_out,
+                                         k_buffer, v_buffer, o, kv_indptr, kv_indices, plan, launch_in_step, workspace,
+                                         max_kv_splits, sm_scale, logit_cap=0.0, xsum_out=None):
+    """rope_and_store_kv_partial + decode_attention_shared_planned in one launch (the rotation as the launch's first
+    blocks).  q_out [B, Hq, 128] (any row stride: a view of the qkv buffer) receives the rotated query rows."""
+    _need_gpu(partials, cos_sin_cache, positions, loc, q_out, k_buffer, v_buffer, o, kv_indptr, kv_indices, plan, workspace)
+    _same_type_pool("decode_attention_shared_planned_rope", o, k_buffer, v_buffer)
+    B, Hq, D = q_out.shape
+    Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]
+    if q_out.stride(1) != D or q_out.stride(2) != 1:
+        raise SglkError("decode_attention_shared_planned_rope: the query heads of a row must be contiguous")
+    need = decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits)
+    if workspace.numel() * workspace.element_size() < need:
+        raise SglkError(f"decode_attention_shared_planned_rope: workspace too small ({need} bytes needed)")
+    _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_attention_shared_planned_rope")
+    check(lib().sglk_decode_attention_shared_planned_rope(
+        _ptr(partials), int(splits), int(part_stride), _ptr(bias), _ptr(cos_sin_cache), _ptr(positions),
+        cos_sin_cache.shape[1], 0, _ptr(loc), _is64(loc), _ptr(q_out), q_out.stride(0), _ptr(k_buffer), _ptr(v_buffer),
+        _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(plan), int(launch_in_step), _ptr(workspace), max_kv_splits, B, Hq,
+        Hkv, D, Dv, k_buffer.stride(0), k_buffer.stride(1), v_buffer.stride(0), v_buffer.stride(1), o.stride(0), o.stride(1),
+        float(sm_scale), float(logit_cap), dtype_code(o.dtype), _ptr(xsum_out),
+        0 if xsum_out is None else xsum_out.stride(0), _stream(o)), "decode_attention_shared_planned_rope")
+
+
 def prepare_for_decode(req_to_token, req_pool_indices, seq_lens, positions, out_cache_loc):
     """positions = seq_lens; out_cache_loc = req_to_token[req_pool_indices, seq_lens]; seq_lens += 1 (one launch)."""
     _need_gpu(req_to_token, req_pool_indices, seq_lens, positions, out_cache_loc)

@@ -155,6 +155,67 @@ def test_awq_chain_gate_up_down_equals_separate_launches(M):
         assert torch.equal(part1, part2)
 
 
+@pytest.mark.parametrize("B,Hq,Hkv,splits", [(64, 32, 8, 4), (5, 16, 4, 3), (3, 8, 8, 1)])
+def test_rope_role_inside_the_attention_launch(B, Hq, Hkv, splits):
+    """The rotation + pool write as the first blocks of the attention launch against the two separate launches: query
+    rows, new pool rows, attention output and its block sums must be the same bits; two 'layers' of one step (the
+    counters the attention blocks wait on grow by launch), then a second step over a fresh plan."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B + Hq)
+    D, P, max_splits = 128, 96, 8
+    tails = [1 + (7 * b) % 40 for b in range(B)]
+    n = 1 + P + sum(tails) + 4
+    row = (Hq + 2 * Hkv) * D
+    r2t = torch.zeros(B, P + 64, dtype=torch.int32)
+    nxt = 1 + P
+    for b in range(B):
+        r2t[b, :P] = torch.arange(1, 1 + P)
+        r2t[b, P: P + tails[b]] = torch.arange(nxt, nxt + tails[b])
+        nxt += tails[b]
+    lens = torch.tensor([P + t for t in tails])
+    loc = torch.tensor([int(r2t[b, lens[b] - 1]) for b in range(B)], device=DEV)
+    pos = (lens - 1).to(DEV)
+    cs = torch.randn(256, D, generator=g).to(DEV)
+    ptr = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    ind = torch.zeros(int(lens.sum()), dtype=torch.int32, device=DEV)
+    ns = torch.zeros(B, dtype=torch.int32, device=DEV)
+    rpi = torch.arange(B, device=DEV)
+    sm = 1.0 / math.sqrt(D)
+    pools = [[torch.randn(n, Hkv, D, generator=g).to(torch.bfloat16).to(DEV) for _ in range(2)] for _ in range(2)]
+    ref_pools = [[t.clone() for t in pair] for pair in pools]
+    ws1 = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
+    ws2 = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
+    plan1 = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV)
+    plan2 = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV)
+    for step in range(2):
+        for plan in (plan1, plan2):
+            ops.decode_metadata_shared(r2t.to(DEV), rpi, lens.to(DEV), ptr, ind, ns, Hq, Hkv, max_splits, 256, plan)
+        for layer in range(2):
+            parts = torch.randn(splits, B, row, generator=g).to(DEV)
+            kb1, vb1 = ref_pools[layer]
+            kb2, vb2 = pools[layer]
+            # separate launches
+            qkv1 = torch.empty(B, row, dtype=torch.bfloat16, device=DEV)
+            ops.rope_and_store_kv_partial(qkv1, parts, splits, cs, pos, kb1, vb1, loc, Hq, Hkv, D)
+            o1 = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=DEV)
+            xs1 = torch.zeros(Hq, B, device=DEV)
+            ops.decode_attention_shared_planned(qkv1[:, : Hq * D].view(B, Hq, D), kb1, vb1, o1, ptr, ind, plan1, ws1,
+                                                max_splits, sm, 0.0, xs1)
+            # one launch
+            qkv2 = torch.zeros(B, row, dtype=torch.bfloat16, device=DEV)
+            o2 = torch.full((B, Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+            xs2 = torch.zeros(Hq, B, device=DEV)
+            ops.decode_attention_shared_planned_rope(parts, splits, B * row, None, cs, pos, loc,
+                                                     qkv2[:, : Hq * D].view(B, Hq, D), kb2, vb2, o2, ptr, ind, plan2,
+                                                     layer + 1, ws2, max_splits, sm, 0.0, xs2)
+            torch.cuda.synchronize()
+            assert ops.decode_shared_workspace_status(ws2, B, Hq) == 0
+            assert torch.equal(qkv1[:, : Hq * D].view(torch.int16), qkv2[:, : Hq * D].view(torch.int16)), (step, layer)
+            assert torch.equal(kb1, kb2) and torch.equal(vb1, vb2), (step, layer)
+            assert torch.equal(o1.view(torch.int16), o2.view(torch.int16)), (step, layer)
+            assert torch.equal(xs1, xs2), (step, layer)
+
+
 def test_attention_block_sums():
     import sys, os
     sys.path.insert(0, os.path.dirname(__file__))
