@@ -338,6 +338,75 @@ def extend_ttft(cfg, B, prefix, suffix, dev):
             "extend_attention_speedup": round(miss / hit, 2)}
 
 
+def in_batch_prefix_attention(cfg, dev, n_prefix=10, per_prefix=32, prefix=1024, suffix=128, layers=8):
+    """Decode attention of the reference's in-batch-prefix workload (benchmark/bench_in_batch_prefix/
+    bench_in_batch_prefix.py:112-116: 10 prefixes x 32 requests, 1024 + 128 tokens), the requests of the ten groups
+    interleaved in the batch, through the attention backend exactly as python/sglang drives it under graphs:
+    init_cuda_graph_state, capture, init_forward_metadata_replay_cuda_graph, replay.  The backend is told nothing about
+    the groups; with prefix sharing on it finds them on the device.  Time per layer launch, sharing on against off."""
+    import types
+
+    from sglang_security_amd.attention import SglkAttnBackend
+    from sglang_security_amd.mem_cache.memory_pool import MHATokenToKVPool, ReqToTokenPool, TokenToKVPoolAllocator
+
+    B = n_prefix * per_prefix
+    Hq, Hkv, D = cfg.q_heads, cfg.kv_heads, cfg.head_dim
+    slots = 1 + n_prefix * prefix + B * (suffix + 1) + 64
+    dt = torch.bfloat16
+    r2t = ReqToTokenPool(B + 1, prefix + suffix + 8, dev)
+    kv = MHATokenToKVPool(slots, 1, dt, Hkv, D, layers, dev)
+    alloc = TokenToKVPoolAllocator(slots, dt, dev, kv)
+    g = torch.Generator(device=dev).manual_seed(0)
+    for l in range(layers):
+        kv.k_buffer[l].normal_(generator=g)
+        kv.v_buffer[l].normal_(generator=g)
+    prefixes = [alloc.alloc(prefix) for _ in range(n_prefix)]
+    L = prefix + suffix
+    for b in range(B):
+        r2t.req_to_token[b, :prefix] = prefixes[b % n_prefix].int()
+        r2t.req_to_token[b, prefix:L] = alloc.alloc(suffix).int()
+    mcfg = types.SimpleNamespace(num_attention_heads=Hq, head_dim=D, get_num_kv_heads=lambda tp: Hkv)
+    mr = types.SimpleNamespace(device=dev, req_to_token_pool=r2t, token_to_kv_pool=kv, model_config=mcfg, tp_size=1,
+                               server_args=types.SimpleNamespace(triton_attention_num_kv_splits=8))
+    rpi = torch.arange(B, device=dev, dtype=torch.int32)
+    lens = torch.full((B,), L, device=dev, dtype=torch.int32)
+    q = torch.randn(B, Hq * D, device=dev, generator=g).to(dt)
+    mode = types.SimpleNamespace(is_decode_or_idle=lambda: True)
+    fb = types.SimpleNamespace(forward_mode=mode, batch_size=B, req_pool_indices=rpi, seq_lens=lens, seq_lens_sum=B * L,
+                               out_cache_loc=None, token_to_kv_pool=kv)
+    lyr = [types.SimpleNamespace(layer_id=i, tp_q_head_num=Hq, tp_k_head_num=Hkv, tp_v_head_num=Hkv, qk_head_dim=D,
+                                 v_head_dim=D, scaling=1.0 / math.sqrt(D), logit_cap=0.0) for i in range(layers)]
+    out = {}
+    res = {}
+    for name, share in (("shared", True), ("per_request", False)):
+        be = SglkAttnBackend(mr, share_prefix=share)
+        be.init_cuda_graph_state(B)
+        be.init_forward_metadata_capture_cuda_graph(B, B, rpi, lens)
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            for ly in lyr[:2]:
+                be.forward(q, None, None, ly, fb, save_kv_cache=False)
+            st.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=st):
+                for ly in lyr:
+                    res[name] = be.forward(q, None, None, ly, fb, save_kv_cache=False)
+            ts = []
+            for _ in range(5):
+                be.init_forward_metadata_replay_cuda_graph(B, rpi, lens, B * L)
+                a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(st)
+                gr.replay()
+                b_.record(st)
+                st.synchronize()
+                ts.append(a.elapsed_time(b_) * 1e3 / layers)
+        out[f"attention_us_{name}"] = round(sorted(ts)[len(ts) // 2], 2)
+    out["attention_speedup"] = round(out["attention_us_per_request"] / out["attention_us_shared"], 2)
+    out["max_abs_diff"] = round(float((res["shared"].float() - res["per_request"].float()).abs().max()), 5)
+    out["shape"] = f"{n_prefix} prefixes x {per_prefix} requests, {prefix} + {suffix} tokens, groups interleaved, graph replay"
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -442,6 +511,10 @@ def main():
             hit.update(extend_ttft(cfg, B, args.prefix, args.suffix, dev))
         except Exception as e:  # the headline number must survive a failure here
             hit["extend_error"] = str(e)[:200]
+        try:
+            hit["in_batch_prefix"] = in_batch_prefix_attention(cfg, dev)
+        except Exception as e:
+            hit["in_batch_prefix_error"] = str(e)[:200]
         if cfg.quant in ("awq", "bf16"):
             # whole-model time to first token through the radix cache: cold, prefix cached by another user (public
             # nodes), and the same with SafeKV holding the nodes private (the fork's timing side-channel experiment)
