@@ -853,13 +853,13 @@ __device__ __forceinline__ int block_excl_scan_1024(int* v, int* tmp, int n) {
   const int x = t < n ? v[t] : 0;
   tmp[t] = x;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int add = t >= o ? tmp[t - o] : 0;
+  for (int o = 1; o < n; o <<= 1) {  // entries at and beyond n are zero: strides of n and more add nothing below n
+    const int add = (t >= o && t < n) ? tmp[t - o] : 0;
     __syncthreads();
     tmp[t] += add;
     __syncthreads();
   }
-  const int total = tmp[1023];
+  const int total = n > 0 ? tmp[n - 1] : 0;
   if (t < n) v[t] = tmp[t] - x;
   __syncthreads();
   return total;
@@ -942,24 +942,26 @@ __global__ void __launch_bounds__(1024) shared_plan_assemble_kernel(const int32_
   }
   __syncthreads();
   __threadfence_block();  // `order` is read back below
-  // items of group g: (split, column block) in that order, so that the blocks of one split start together
-  if (t < G && my_plen > 0) {
-    const int per_split = cdiv_i(cdiv_i(my_plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
-    const int first_member = pv.order[gsize[t]];
-    for (int k = 0; k < my_aps * my_cbs; ++k) {
-      const int j = ioff[t] + k;
-      if (j >= max_items) break;
-      const int split = k / my_cbs, cb = k % my_cbs;
-      int32_t* it = pv.items + (int64_t)j * kPlanItemInts;
-      it[0] = kv_indptr[first_member];  // every member lists the same slots for the prefix: walk the first one's
-      it[1] = per_split * split;
-      it[2] = min(per_split * (split + 1), my_plen);
-      it[3] = cb;
-      it[4] = split;
-      it[5] = t;
-      it[6] = gsize[t];
-      it[7] = my_size * heads;
-    }
+  // items of group g: (split, column block) in that order, so that the blocks of one split start together; one
+  // thread per item (its group found by a walk over the item offsets: a handful of groups)
+  for (int j = t; j < n_items; j += 1024) {
+    int gi = 0;
+    while (gi + 1 < G && ioff[gi + 1] <= j) ++gi;
+    const int plen = gplen[gi];
+    const int size = pv.group_indptr[gi + 1] - gsize[gi];
+    const int cbs = cdiv_i(size * heads, 64);
+    const int k = j - ioff[gi];
+    const int split = k / cbs, cb = k % cbs;
+    const int per_split = cdiv_i(cdiv_i(plen, prefix_splits), kMinBlockKV) * kMinBlockKV;
+    int32_t* it = pv.items + (int64_t)j * kPlanItemInts;
+    it[0] = kv_indptr[pv.order[gsize[gi]]];  // every member lists the same slots for the prefix: walk the first one's
+    it[1] = per_split * split;
+    it[2] = min(per_split * (split + 1), plen);
+    it[3] = cb;
+    it[4] = split;
+    it[5] = gi;
+    it[6] = gsize[gi];
+    it[7] = size * heads;
   }
   __syncthreads();
   __threadfence_block();

@@ -579,7 +579,18 @@ __global__ void __launch_bounds__(1024) argmax_rows_kernel(const void* __restric
   if constexpr (sizeof(typename Raw<T>::type) == 2) {
     const uint16_t* r = reinterpret_cast<const uint16_t*>(x) + row * row_stride;
     const int nv = ((row_stride % 8) == 0 && aligned16(x)) ? cols / 8 : 0;
-    for (int v = threadIdx.x; v < nv; v += 1024) {
+    // four loads in flight per thread: a row of a large vocabulary is a few trips to memory instead of sixteen
+    int v = threadIdx.x;
+    for (; v + 3 * 1024 < nv; v += 4 * 1024) {
+      short8 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const short8*>(r)[v + 1024 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) take(Conv<T>::to_f32((uint16_t)q[u][j]), 8 * (v + 1024 * u) + j);
+    }
+    for (; v < nv; v += 1024) {
       const short8 q = reinterpret_cast<const short8*>(r)[v];
 #pragma unroll
       for (int j = 0; j < 8; ++j) take(Conv<T>::to_f32((uint16_t)q[j]), 8 * v + j);
