@@ -169,6 +169,68 @@ def measure_decode(dec, args, dev, world, share_prefix, attn):
     return elapsed, graph is not None, mode, stream
 
 
+def tp_report(dec, group, args, dev, world, rank, stream, step_ms):
+    """What the tensor-parallel run actually did: the ranks that took part (rank, device, process), which path each
+    all-reduce call took (peer-to-peer kernel on a registered / unregistered input, or the group's RCCL collective),
+    and the all-reduce's share of the step, measured twice: events around every row-parallel sum of eager steps, and
+    the replayed step against the same graph captured with the sums replaced by local copies."""
+    import socket
+
+    import torch.distributed as dist
+    from sglang_security_amd.benchlib import dist_helpers, timed_steps
+
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "device": torch.cuda.current_device(), "pid": os.getpid(),
+                                  "host": socket.gethostname()})
+    barrier, mx = dist_helpers(world, dev)
+    pairs, orig = [], dec._tp_sum
+
+    def timed_sum():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        orig()
+        b.record(stream)
+        pairs.append((a, b))
+
+    before = dict(group.ar_calls)
+    eager = []
+    with torch.cuda.stream(stream):
+        dec._tp_sum = timed_sum
+        for _ in range(3):
+            pairs.clear()
+            barrier()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s0.record(stream)
+            dec.step()
+            s1.record(stream)
+            stream.synchronize()
+            eager.append((sum(a.elapsed_time(b) for a, b in pairs), s0.elapsed_time(s1), len(pairs)))
+        dec._tp_sum = orig
+        calls = {k: (group.ar_calls[k] - before[k]) // 3 for k in before}
+        ar_ms, step_eager_ms, n_calls = sorted(eager)[1]
+        # the same step with every row-parallel sum replaced by a copy of this rank's product
+        local_ms = None
+        if not args.no_graph:
+            dec._tp_sum = lambda: dec.hidden.copy_(dec.tp_buf)
+            dec.step()
+            stream.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=stream):
+                dec.step()
+            dec._tp_sum = orig
+            local_ms = timed_steps(g.replay, args.steps, 2, torch.cuda.synchronize, barrier, mx) / args.steps * 1e3
+    nbytes = dec.tp_buf.numel() * dec.tp_buf.element_size()
+    out = {"ranks_seen": sorted(seen, key=lambda r: r["rank"]), "devices": len({(r["host"], r["device"]) for r in seen}),
+           "allreduce_calls_per_step": n_calls, "allreduce_bytes_per_call": nbytes, "allreduce_path_per_step": calls,
+           "eager_events": {"allreduce_ms_per_step": round(ar_ms, 4), "step_ms": round(step_eager_ms, 4),
+                            "allreduce_share": round(ar_ms / step_eager_ms, 4),
+                            "allreduce_us_per_call": round(ar_ms * 1e3 / max(n_calls, 1), 2)}}
+    if local_ms is not None:
+        out["graph_replay"] = {"step_ms": round(step_ms, 4), "step_ms_sums_replaced_by_copies": round(local_ms, 4),
+                               "allreduce_share": round(max(0.0, 1.0 - local_ms / step_ms), 4)}
+    return out
+
+
 def gemm_roofline(dec, cfg, B, stream):
     """The dominant kernel (fused AWQ GEMM), timed with events on the launch stream: each projection of all layers
     is launched back to back between one event pair (the device is parked first so that the host has enqueued the
@@ -493,6 +555,8 @@ def main():
     }
     if collective:
         out["config"]["collective"] = collective
+        out["tensor_parallel"] = tp_report(dec, group, args, dev, world, rank, stream, agg["ms_per_step"])
+        dec.check_tp_health()
     # fraction of the HBM roofline for the whole step (unique bytes: weights + lm_head + KV with the prefix once)
     if not args.tiny:
         kv_tok = 2 * cfg.kv_heads * cfg.head_dim * 2 * cfg.layers

@@ -41,6 +41,8 @@ class GroupCoordinator:
             raise SglkError(f"rank {self.rank} is in none of the groups {group_ranks}")
         self.device = torch.device(f"cuda:{local_rank}") if torch.cuda.is_available() else torch.device("cpu")
         self.use_custom_allreduce = use_custom_allreduce
+        # which path each all_reduce_into call took (a benchmark reads the difference over a step)
+        self.ar_calls = {"peer_to_peer_registered": 0, "peer_to_peer_unregistered": 0, "rccl": 0}
         self.ca_comm: Optional[CustomAllreduce] = None
         self.ca_error: Optional[str] = None
         if use_custom_allreduce and self.world_size > 1 and self.device.type == "cuda":
@@ -75,8 +77,11 @@ class GroupCoordinator:
             return out
         if self._custom(inp):
             if registered:
+                self.ar_calls["peer_to_peer_registered"] += 1
                 return self.ca_comm.all_reduce_reg(inp, out)
+            self.ar_calls["peer_to_peer_unregistered"] += 1
             return self.ca_comm.all_reduce_unreg(inp, out)
+        self.ar_calls["rccl"] += 1
         if out.data_ptr() != inp.data_ptr():
             out.copy_(inp)
         dist.all_reduce(out, group=self.device_group)
