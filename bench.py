@@ -204,6 +204,7 @@ def tp_report(dec, group, args, dev, world, rank, stream, step_ms):
             dec.step()
             s1.record(stream)
             stream.synchronize()
+            dec.check_tp_health()
             eager.append((sum(a.elapsed_time(b) for a, b in pairs), s0.elapsed_time(s1), len(pairs)))
         dec._tp_sum = orig
         calls = {k: (group.ar_calls[k] - before[k]) // 3 for k in before}
@@ -214,6 +215,7 @@ def tp_report(dec, group, args, dev, world, rank, stream, step_ms):
             dec._tp_sum = lambda: dec.hidden.copy_(dec.tp_buf)
             dec.step()
             stream.synchronize()
+            dec.check_tp_health()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=stream):
                 dec.step()

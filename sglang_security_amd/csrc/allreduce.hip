@@ -36,7 +36,8 @@ namespace sglk {
 namespace {
 
 constexpr int kMaxRanks = 8;
-constexpr int kMaxBlocks = 64;
+constexpr int kMaxBlocks = 64;       // tickets and slots per rank: the most a launch may use
+constexpr int kDefaultBlocks = 16;   // what a launch uses: the reference's ROCm block_limit (custom_all_reduce_hip.cuh:507-509)
 constexpr int kThreads = 512;
 constexpr int64_t kDefaultTimeoutMs = 30000;
 constexpr int64_t kTicksPerMs = 100000;  // s_memrealtime counts at 100 MHz
@@ -77,9 +78,12 @@ __device__ __forceinline__ bool barrier_all(const Peers& peers, Signal* self, in
     uint32_t* mine = &self->slot[n & 1][blockIdx.x][threadIdx.x];
     const uint64_t t0 = wall_clock64();
     uint32_t polls = 0;
+    // The polls are relaxed loads of uncached memory; the acquire (an invalidate of this GPU's caches) is issued
+    // once, after the peer's ticket has been seen.  An acquire per poll would keep invalidating the caches under
+    // whatever else runs on the chip for as long as the wait lasts (ranks that share one GPU slow the straggler
+    // they wait for).  After a thousand quick polls the wait backs off to long sleeps.
     while (true) {
-      const uint32_t v = RELEASE_ACQUIRE ? __hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
-                                         : __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      const uint32_t v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       // tickets only grow; a peer that is already one barrier ahead wrote the other slot set
       if (v == n) break;
       if ((++polls & 63u) == 0 && wall_clock64() - t0 > watch.ticks) {
@@ -89,8 +93,12 @@ __device__ __forceinline__ bool barrier_all(const Peers& peers, Signal* self, in
         bad = 1;
         break;
       }
-      __builtin_amdgcn_s_sleep(2);
+      if (polls < 1024u)
+        __builtin_amdgcn_s_sleep(2);
+      else
+        __builtin_amdgcn_s_sleep(64);
     }
+    if (RELEASE_ACQUIRE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // "" = system scope
   }
   __syncthreads();
   if (bad) return false;
@@ -134,28 +142,38 @@ __device__ __forceinline__ uint4 pack_vec(const float (&acc)[8]) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// sum of 16-byte vector `i` over all ranks, rank order, fp32
-template <typename T>
+// sum of 16-byte vector `i` over all ranks, rank order, fp32.  W > 0: the group size at compile time, so that the W
+// loads (W - 1 of them cross a link, a couple of microseconds each) are in flight together before the first add;
+// W = 0 takes `world` at run time (one load per trip of the loop).
+template <typename T, int W>
 __device__ __forceinline__ uint4 reduce_vec(const Inputs& in, int world, int64_t i) {
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int r = 0; r < world; ++r) add_vec<T>(acc, reinterpret_cast<const uint4*>(in.ptr[r])[i]);
+  if constexpr (W > 0) {
+    uint4 v[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) v[r] = reinterpret_cast<const uint4*>(in.ptr[r])[i];
+#pragma unroll
+    for (int r = 0; r < W; ++r) add_vec<T>(acc, v[r]);
+  } else {
+    for (int r = 0; r < world; ++r) add_vec<T>(acc, reinterpret_cast<const uint4*>(in.ptr[r])[i]);
+  }
   return pack_vec<T>(acc);
 }
 
 // The peer pointers of an input live in device memory (`slot`, one Inputs record per registered buffer) and not in
 // the kernel arguments: a launch captured into a graph names a record that register_graph_buffers fills in only
 // after the capture has ended (custom_all_reduce_hip.cuh:453-476), so the record is read when the kernel runs.
-template <typename T>
+template <typename T, int W>
 __global__ void __launch_bounds__(kThreads) allreduce_one_stage(const Inputs* __restrict__ slot, Peers peers, Signal* self,
                                                                 void* out, int rank, int world, int64_t nvec, Watch watch) {
   const Inputs in = *slot;
   if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
   for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
-    reinterpret_cast<uint4*>(out)[i] = reduce_vec<T>(in, world, i);
+    reinterpret_cast<uint4*>(out)[i] = reduce_vec<T, W>(in, world, i);
   if (!barrier_all<false>(peers, self, rank, world, watch)) poison(out, nvec);
 }
 
-template <typename T>
+template <typename T, int W>
 __global__ void __launch_bounds__(kThreads) allreduce_two_stage(const Inputs* __restrict__ slot, Peers peers, Signal* self,
                                                                 void* out, int rank, int world, int64_t nvec, Watch watch) {
   const Inputs in = *slot;
@@ -164,34 +182,76 @@ __global__ void __launch_bounds__(kThreads) allreduce_two_stage(const Inputs* __
   uint4* stage = reinterpret_cast<uint4*>(self + 1);
   if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
   for (int64_t i = lo + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < hi; i += (int64_t)gridDim.x * kThreads)
-    stage[i - lo] = reduce_vec<T>(in, world, i);
+    stage[i - lo] = reduce_vec<T, W>(in, world, i);
   if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec);
-  for (int r = 0; r < world; ++r) {
-    // start with the own slice and walk the ring so that the links are used evenly
-    const int src = (rank + r) % world;
-    const int64_t slo = part * src, shi = src == world - 1 ? nvec : slo + part;
-    const uint4* from = reinterpret_cast<const uint4*>(peers.sig[src] + 1);
-    for (int64_t i = slo + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < shi; i += (int64_t)gridDim.x * kThreads)
-      reinterpret_cast<uint4*>(out)[i] = from[i - slo];
+  if constexpr (W > 0) {
+    // one vector of every rank's slice per trip: W loads in flight (W - 1 over the links), then W stores; the own
+    // slice first and the ring order after it, so that the links are used evenly
+    const int64_t longest = nvec - part * (W - 1);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < longest; i += (int64_t)gridDim.x * kThreads) {
+      uint4 v[W];
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        const int src = (rank + r) % W;
+        if (i < part || src == W - 1) v[r] = reinterpret_cast<const uint4*>(peers.sig[src] + 1)[i];
+      }
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        const int src = (rank + r) % W;
+        if (i < part || src == W - 1) reinterpret_cast<uint4*>(out)[part * src + i] = v[r];
+      }
+    }
+  } else {
+    for (int r = 0; r < world; ++r) {
+      const int src = (rank + r) % world;
+      const int64_t slo = part * src, shi = src == world - 1 ? nvec : slo + part;
+      const uint4* from = reinterpret_cast<const uint4*>(peers.sig[src] + 1);
+      for (int64_t i = slo + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < shi; i += (int64_t)gridDim.x * kThreads)
+        reinterpret_cast<uint4*>(out)[i] = from[i - slo];
+    }
   }
 }
 
 // out[r * nvec + i] = rank r's input vector i: every rank's registered input, concatenated in rank order.
+// W as in reduce_vec: with the group size known, one vector from every rank is in flight per trip.
+template <int W>
 __global__ void __launch_bounds__(kThreads) allgather_kernel(const Inputs* __restrict__ slot, Peers peers, Signal* self,
                                                              void* out, int rank, int world, int64_t nvec, Watch watch) {
   const Inputs in = *slot;
   if (!barrier_all<true>(peers, self, rank, world, watch)) return poison(out, nvec * world);
-  for (int r = 0; r < world; ++r) {
-    const int src = (rank + r) % world;
-    const uint4* from = reinterpret_cast<const uint4*>(in.ptr[src]);
-    uint4* to = reinterpret_cast<uint4*>(out) + (int64_t)src * nvec;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
-      to[i] = from[i];
+  if constexpr (W > 0) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads) {
+      uint4 v[W];
+#pragma unroll
+      for (int r = 0; r < W; ++r) v[r] = reinterpret_cast<const uint4*>(in.ptr[r])[i];
+#pragma unroll
+      for (int r = 0; r < W; ++r) reinterpret_cast<uint4*>(out)[(int64_t)r * nvec + i] = v[r];
+    }
+  } else {
+    for (int r = 0; r < world; ++r) {
+      const int src = (rank + r) % world;
+      const uint4* from = reinterpret_cast<const uint4*>(in.ptr[src]);
+      uint4* to = reinterpret_cast<uint4*>(out) + (int64_t)src * nvec;
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kThreads)
+        to[i] = from[i];
+    }
   }
   if (!barrier_all<false>(peers, self, rank, world, watch)) poison(out, nvec * world);
 }
 
 using IpcKey = std::array<uint8_t, sizeof(hipIpcMemHandle_t)>;
+
+// Blocks per launch.  Every block spins in the barriers until all ranks have arrived, so a launch must stay a small
+// part of the chip: with the group size known at compile time each thread keeps one 16-byte load per rank in flight,
+// and 16 blocks of 512 threads hold 1 MiB in flight, more than seven links take.  SGLK_AR_BLOCKS (1..64) overrides.
+int block_limit() {
+  static const int limit = [] {
+    const char* env = getenv("SGLK_AR_BLOCKS");
+    const int v = env ? atoi(env) : kDefaultBlocks;
+    return v >= 1 && v <= kMaxBlocks ? v : kDefaultBlocks;
+  }();
+  return limit;
+}
 
 struct Comm {
   int rank = 0, world = 1, full_xgmi = 1;
@@ -488,16 +548,30 @@ int sglk_ar_all_reduce(int64_t fa, const void* inp, void* out, int64_t numel, in
                (long long)need, (long long)c->staging_bytes);
   }
   const int64_t work = algo == 2 ? (nvec + c->world - 1) / c->world : nvec;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, (work + kThreads - 1) / kThreads));
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(block_limit(), (work + kThreads - 1) / kThreads));
   hipStream_t s = (hipStream_t)stream;
+#define SGLK_AR_LAUNCH(W)                                                                                              \
+  do {                                                                                                                 \
+    if (algo == 1)                                                                                                     \
+      hipLaunchKernelGGL((allreduce_one_stage<T, W>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,  \
+                         c->rank, c->world, nvec, c->watch);                                                           \
+    else                                                                                                               \
+      hipLaunchKernelGGL((allreduce_two_stage<T, W>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,  \
+                         c->rank, c->world, nvec, c->watch);                                                           \
+  } while (0)
+  // the group sizes the reference dispatches on (custom_all_reduce_hip.cuh:555-565) are compiled with the size known;
+  // any other size runs the same kernels with the loops over ranks at run time
+  static const bool generic = getenv("SGLK_AR_GENERIC") != nullptr;
   SGLK_DISPATCH_FLOAT(dtype, T, {
-    if (algo == 1)
-      hipLaunchKernelGGL((allreduce_one_stage<T>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,
-                         c->rank, c->world, nvec, c->watch);
-    else
-      hipLaunchKernelGGL((allreduce_two_stage<T>), dim3(blocks), dim3(kThreads), 0, s, in, c->peers, c->self, out,
-                         c->rank, c->world, nvec, c->watch);
+    switch (generic ? 0 : c->world) {
+      case 2: SGLK_AR_LAUNCH(2); break;
+      case 4: SGLK_AR_LAUNCH(4); break;
+      case 6: SGLK_AR_LAUNCH(6); break;
+      case 8: SGLK_AR_LAUNCH(8); break;
+      default: SGLK_AR_LAUNCH(0); break;
+    }
   });
+#undef SGLK_AR_LAUNCH
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
@@ -518,9 +592,19 @@ int sglk_ar_all_gather(int64_t fa, const void* inp, void* out, int64_t bytes_per
     in = it->second;
   }
   const int64_t nvec = bytes_per_rank / 16;
-  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBlocks, (nvec + kThreads - 1) / kThreads));
-  hipLaunchKernelGGL(allgather_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, in, c->peers, c->self, out,
-                     c->rank, c->world, nvec, c->watch);
+  const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(block_limit(), (nvec + kThreads - 1) / kThreads));
+#define SGLK_AG_LAUNCH(W)                                                                                          \
+  hipLaunchKernelGGL(allgather_kernel<W>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, in, c->peers, c->self, \
+                     out, c->rank, c->world, nvec, c->watch)
+  static const bool generic = getenv("SGLK_AR_GENERIC") != nullptr;
+  switch (generic ? 0 : c->world) {
+    case 2: SGLK_AG_LAUNCH(2); break;
+    case 4: SGLK_AG_LAUNCH(4); break;
+    case 6: SGLK_AG_LAUNCH(6); break;
+    case 8: SGLK_AG_LAUNCH(8); break;
+    default: SGLK_AG_LAUNCH(0); break;
+  }
+#undef SGLK_AG_LAUNCH
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }

@@ -181,6 +181,17 @@ class CustomAllreduce:
         """1 once a barrier wait on this rank has timed out (a host-pinned word the kernels raise; no synchronise)."""
         return int(lib().sglk_ar_stuck(self._ptr)) if self._ptr else 0
 
+    def stuck_detail(self):
+        """After a time-out: [(block, ticket it waited for, the ticket each peer had written for that barrier)], read
+        from this rank's signal block (64 tickets, 2 x 64 x 8 peer slots, 64 stuck words: the layout of `Signal` in
+        allreduce.hip).  A peer whose entry is below the ticket had not arrived."""
+        if self.meta is None:
+            return []
+        raw = self.meta[: 4 * 1153].cpu().numpy().view("uint32")
+        slot, stuck = raw[64:1088].reshape(2, 64, 8), raw[1088:1152]
+        return [(b, int(stuck[b]), [int(v) for v in slot[int(stuck[b]) & 1, b, : self.world_size]])
+                for b in range(64) if stuck[b]]
+
     def check_health(self) -> None:
         """Call after the stream has been synchronised (the end of a decode step, before results leave the GPU).
         A peer that never reached a barrier has left NaN-filled outputs behind: this raises SglkError and disables
@@ -191,7 +202,8 @@ class CustomAllreduce:
         if self.failed:
             raise SglkError(
                 f"peer-to-peer all-reduce: rank {self.rank} waited for a peer longer than the time limit; outputs since "
-                "then are NaN-filled and this communicator is disabled")
+                f"then are NaN-filled and this communicator is disabled (block, ticket, peers' tickets: "
+                f"{self.stuck_detail()[:4]})")
 
     def close(self):
         failed = False
