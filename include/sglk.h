@@ -446,8 +446,10 @@ SGLK_API int sglk_awq_gemm(const void* x, const int32_t* packed, const void* sca
  * sglk_awq_gemm_workspace_bytes() exceeds it are rejected with SGLK_EINVAL.  The call allocates and frees nothing
  * and clears the ticket words itself (a memset node on `stream`).  Every call on one GPU shares that GPU's array:
  * calls that overlap on one GPU (two streams) race -- use sglk_awq_gemm with separate workspaces there.
- * sglk_awq_gemm_static_init() resolves the array's address for the current device ahead of time (otherwise the
- * first call on a device does it). */
+ * The array belongs to the CURRENT device, which must be the one the operands live on (checked: SGLK_EINVAL
+ * otherwise).  sglk_awq_gemm_static_init() does, for the current device, everything a first call would do (the array's
+ * address, the kernels' LDS limits); it is REQUIRED before a call whose stream is being captured -- a first use on a
+ * device under capture is refused with SGLK_EINVAL rather than resolved lazily. */
 SGLK_API int64_t sglk_awq_gemm_static_max_workspace_bytes(void);
 SGLK_API int sglk_awq_gemm_static_init(void);
 SGLK_API int sglk_awq_gemm_static(const void* x, const int32_t* packed, const void* scales,

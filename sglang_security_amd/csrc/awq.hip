@@ -1459,6 +1459,39 @@ WidePlan plan_awq_wide(int M, int N, int K, int group_size, bool partial_mode) {
 
 using namespace sglk;
 
+static constexpr int kMaxDevices = 64;
+
+// Raises a kernel's dynamic-LDS limit once per (kernel, device): the attribute belongs to the device's copy of the
+// code object.  One flag array per kernel, shared by the launch sites and by sglk_awq_gemm_static_init().
+template <auto Kernel>
+static int ensure_lds(int bytes) {
+  static bool done[kMaxDevices];
+  int dev = 0;
+  SGLK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices || !done[dev]) {
+    SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev >= 0 && dev < kMaxDevices) done[dev] = true;
+  }
+  return SGLK_OK;
+}
+
+// Everything the entry point would otherwise do on its first call on a device: the array's address and the LDS
+// limits of every kernel the call can dispatch to.
+template <typename T>
+static int static_prepare_kernels() {
+  if (int rc = ensure_lds<&awq_gemm_wide_kernel<T, false, 1>>(Wide::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_wide_kernel<T, false, 2>>(Wide::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_wide_kernel<T, true, 1>>(Wide::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_wide_kernel<T, true, 2>>(Wide::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_kernel<T, 4, 2, 6>>(GemmGeom<4, 2, 6>::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_kernel<T, 4, 1, 6>>(GemmGeom<4, 1, 6>::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_kernel<T, 4, 1, 4>>(GemmGeom<4, 1, 4>::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_kernel<T, 8, 1, 6>>(GemmGeom<8, 1, 6>::kLds)) return rc;
+  if (int rc = ensure_lds<&awq_gemm_kernel<T, 8, 1, 4>>(GemmGeom<8, 1, 4>::kLds)) return rc;
+  return SGLK_OK;
+}
+
+
 extern "C" {
 
 int sglk_awq_dequantize(const int32_t* qweight, const void* scales, const int32_t* qzeros, void* out, int rows,
@@ -1545,12 +1578,7 @@ static int launch_awq_wide(const WidePlan& wp, const void* x, const int32_t* pac
   dim3 wgrid(N / 128, wp.splits, wp.mblocks);
 #define SGLK_WIDE_LAUNCH(XS, MQ)                                                                                   \
   {                                                                                                                \
-    static bool attr_set = false;                                                                                  \
-    if (!attr_set) {                                                                                               \
-      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_wide_kernel<T, XS, MQ>),                \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));                       \
-      attr_set = true;                                                                                             \
-    }                                                                                                              \
+    if (int rc = ensure_lds<&awq_gemm_wide_kernel<T, XS, MQ>>(Wide::kLds)) return rc;                              \
     hipLaunchKernelGGL((awq_gemm_wide_kernel<T, XS, MQ>), wgrid, dim3(512), Wide::kLds, s, (const uint16_t*)x,     \
                        packed, (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial,    \
                        tickets, M, N, K, wp.stages_per_split, wp.splits, x_stride, out_stride, xsum, xs_stride,    \
@@ -1685,12 +1713,7 @@ int sglk_awq_chain(const sglk_chain_job* jobs, int njobs, void* sync, int M, int
   hipStream_t s = (hipStream_t)stream;
 #define SGLK_CHAIN_LAUNCH(MQ)                                                                                       \
   {                                                                                                                 \
-    static bool attr_set = false;                                                                                   \
-    if (!attr_set) {                                                                                                \
-      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_chain_kernel<T, MQ>),                         \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, Wide::kLds));                        \
-      attr_set = true;                                                                                              \
-    }                                                                                                               \
+    if (int rc = ensure_lds<&awq_chain_kernel<T, MQ>>(Wide::kLds)) return rc;                                       \
     hipLaunchKernelGGL((awq_chain_kernel<T, MQ>), dim3(grid), dim3(512), Wide::kLds, s, cj, M, (int*)sync);         \
   }
   SGLK_DISPATCH_HALF(dtype, T, {
@@ -1727,12 +1750,7 @@ int sglk_awq_gemm_xs(const void* x, const int32_t* packed, const void* scales, c
 #define SGLK_AWQ_LAUNCH(NW, TN, WR)                                                                               \
   {                                                                                                               \
     using GG = GemmGeom<NW, TN, WR>;                                                                              \
-    static bool attr_set = false;                                                                                 \
-    if (!attr_set) {                                                                                              \
-      SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&awq_gemm_kernel<T, NW, TN, WR>),                \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, GG::kLds));                        \
-      attr_set = true;                                                                                            \
-    }                                                                                                             \
+    if (int rc = ensure_lds<&awq_gemm_kernel<T, NW, TN, WR>>(GG::kLds)) return rc;                                \
     hipLaunchKernelGGL((awq_gemm_kernel<T, NW, TN, WR>), grid, dim3(64 * NW), GG::kLds, s, (const uint16_t*)x,    \
                        packed, (const uint16_t*)scales, qzeros, (const uint16_t*)bias, (uint16_t*)out, partial,   \
                        tickets, M, N, K, group_size, p.kb_per_split, p.splits, x_stride, out_stride);             \
@@ -1765,22 +1783,48 @@ int sglk_awq_gemm(const void* x, const int32_t* packed, const void* scales, cons
 // address is looked up once per device (the array's name is only a host-side handle, never a device pointer).
 static constexpr int64_t kStaticWsBytes = (int64_t)kMaxTiles * 4 + ((int64_t)7 << 20);
 static __device__ __align__(256) unsigned char scratch[kStaticWsBytes];
-static constexpr int kMaxDevices = 64;
 static void* g_scratch_ptr[kMaxDevices];
 static std::mutex g_scratch_mu;
 
-static int static_scratch(void** ptr) {
+// The array's address on the CURRENT device.  `operand` (may be null) is a device pointer of the call: its owner
+// must be the current device, because the address handed to the kernel is that device's copy of the array.
+// `stream` (with `launching`) is the stream the call is about to launch on: the first resolution on a device takes a
+// lock and asks the runtime for the symbol, which must not happen while that stream is being captured.
+static int static_scratch(void** ptr, const void* operand = nullptr, hipStream_t stream = nullptr,
+                          bool launching = false) {
   int dev = -1;
   SGLK_HIP(hipGetDevice(&dev));
   SGLK_CHECK(dev >= 0 && dev < kMaxDevices, "awq_gemm_static: device ordinal %d out of range", dev);
-  std::lock_guard<std::mutex> lock(g_scratch_mu);
-  if (!g_scratch_ptr[dev]) {
-    void* p = nullptr;
-    SGLK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-    SGLK_CHECK(p != nullptr, "awq_gemm_static: no device address for the static workspace");
-    g_scratch_ptr[dev] = p;
+  if (operand) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, operand) == hipSuccess && attr.type == hipMemoryTypeDevice)
+      SGLK_CHECK(attr.device == dev,
+                 "awq_gemm_static: the operands live on device %d but device %d is current (hipSetDevice to the "
+                 "operands' device before the call: each GPU has its own static workspace)",
+                 attr.device, dev);
+    else
+      (void)hipGetLastError();  // not a pointer the runtime knows: leave the judgement to the launch
   }
-  *ptr = g_scratch_ptr[dev];
+  void* known = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!known) {
+    if (launching) {
+      hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+      SGLK_HIP(hipStreamIsCapturing(stream, &st));
+      SGLK_CHECK(st == hipStreamCaptureStatusNone,
+                 "awq_gemm_static: first use on device %d while the stream is being captured: call "
+                 "sglk_awq_gemm_static_init() on this device before the capture begins",
+                 dev);
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+      void* p = nullptr;
+      SGLK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+      SGLK_CHECK(p != nullptr, "awq_gemm_static: no device address for the static workspace");
+      __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+    }
+    known = g_scratch_ptr[dev];
+  }
+  *ptr = known;
   return SGLK_OK;
 }
 
@@ -1803,7 +1847,9 @@ int64_t sglk_awq_gemm_static_max_workspace_bytes(void) { return kStaticWsBytes; 
 
 int sglk_awq_gemm_static_init(void) {
   void* p = nullptr;
-  return static_scratch(&p);
+  if (int rc = static_scratch(&p)) return rc;
+  if (int rc = static_prepare_kernels<bf16_t>()) return rc;
+  return static_prepare_kernels<f16_t>();
 }
 
 int sglk_awq_gemm_static(const void* x, const int32_t* packed, const void* scales, const int32_t* qzeros,
@@ -1817,7 +1863,7 @@ int sglk_awq_gemm_static(const void* x, const int32_t* packed, const void* scale
                 "sglk_awq_gemm with a caller-provided workspace",
                 M, N, K, (long long)need, (long long)kStaticWsBytes);
   void* ws = nullptr;
-  const int rc = static_scratch(&ws);
+  const int rc = static_scratch(&ws, out, (hipStream_t)stream, true);
   if (rc != SGLK_OK) return rc;
   // the array keeps the previous call's contents: the ticket words must start at zero
   SGLK_HIP(hipMemsetAsync(ws, 0, (size_t)kMaxTiles * 4, (hipStream_t)stream));

@@ -130,8 +130,10 @@ class GroupCoordinator:
         dist.barrier(group=self.cpu_group)
 
     def check_health(self) -> None:
-        """After a synchronise: raises when the peer-to-peer kernels timed out waiting for a peer.  The communicator is
-        then disabled, so the calls that follow go through RCCL."""
+        """After a synchronise: raises when the peer-to-peer kernels timed out waiting for a peer (outputs since then
+        are NaN-filled).  The communicator is disabled from then on, so later calls are routed to the device group's
+        collective -- which helps when the peer was only late, not when it is gone: a collective over a group with a
+        dead rank blocks like any other.  Treat the error as fatal for the step and rebuild the group."""
         if self.ca_comm is not None:
             self.ca_comm.check_health()
 

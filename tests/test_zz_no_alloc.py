@@ -56,3 +56,57 @@ def test_awq_gemm_static_rejects_oversize():
                                 N, _lib.BF16, None)
     assert rc != 0
     assert b"static" in L.sglk_last_error()
+
+
+_CAPTURE_FIRST = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from sglang_security_amd import _lib, ops
+L = _lib.lib()
+dev = torch.device("cuda:0")
+M, K, N = 64, 4096, 6144
+g = torch.Generator(device=dev).manual_seed(1)
+qw = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K, N // 8), dtype=torch.int32, device=dev, generator=g)
+qz = torch.randint(-(2 ** 31), 2 ** 31 - 1, (K // 128, N // 8), dtype=torch.int32, device=dev, generator=g)
+sc = (torch.rand(K // 128, N, device=dev, generator=g) * 0.01).to(torch.bfloat16)
+x = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+packed = ops.awq_repack(qw)
+want = ops.awq_gemm(x, packed, sc, qz)
+got = torch.zeros_like(want)
+def call(stream):
+    return L.sglk_awq_gemm_static(x.data_ptr(), packed.data_ptr(), sc.data_ptr(), qz.data_ptr(), None, got.data_ptr(), M, N,
+                                  K, 128, x.stride(0), got.stride(0), _lib.BF16, stream.cuda_stream)
+s = torch.cuda.Stream()
+torch.cuda.synchronize()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.stream(s):
+    with torch.cuda.graph(graph, stream=s):
+        rc_first = call(s)                      # nothing resolved on this device yet: must be refused, not resolved
+        msg = L.sglk_last_error().decode()
+assert rc_first != 0 and "sglk_awq_gemm_static_init" in msg, (rc_first, msg)
+assert L.sglk_awq_gemm_static_init() == 0
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.stream(s):
+    with torch.cuda.graph(graph, stream=s):
+        rc = call(s)
+assert rc == 0, L.sglk_last_error()
+graph.replay()
+torch.cuda.synchronize()
+assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+print("ok")
+'''
+
+
+def test_awq_gemm_static_refuses_a_first_use_under_capture(tmp_path):
+    """In a fresh process: a call whose stream is being captured before sglk_awq_gemm_static_init() ran on the device is
+    refused (no lock, no symbol look-up under capture); after the init the captured call replays bit-identical to the
+    workspace form."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "capture_first.py"
+    script.write_text(_CAPTURE_FIRST)
+    r = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
