@@ -149,7 +149,11 @@ def measure_decode(dec, args, dev, world, share_prefix, attn):
     dec.setup_shared_prefix_batch(args.prefix, args.suffix, share=share_prefix)
     mode = "per_request"
     dec.enable_shared_prefix(False)
-    if share_prefix and attn in ("auto", "shared_prefix") and dec.enable_shared_prefix(True):
+    from sglang_security_amd import ops
+
+    c = dec.cfg
+    pays = ops.shared_prefix_pays(c.kv_heads, c.head_dim, c.head_dim, dec.k_pool[0].element_size())
+    if share_prefix and (attn == "shared_prefix" or (attn == "auto" and pays)) and dec.enable_shared_prefix(True):
         mode = "shared_prefix"
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(dev)

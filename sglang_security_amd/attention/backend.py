@@ -22,7 +22,10 @@ the metadata call (eager, graph capture and graph replay alike) finds, on the de
 of requests whose req_to_token rows start with the same pool slots -- the radix-tree hit RadixCache.match_prefix handed
 them -- and lays the step's work out for the kernel, which reads a group's shared part of the KV pool once.  A batch in
 which nobody shares anything is walked per request (the device decides; see ops.decode_attention_shared_planned).
-`share_prefix=False` (or SGLK_SHARE_PREFIX=0) keeps every batch on the per-request kernel.
+The kernel covers head size 128 over 16-bit and fp8 pools and head size 64 over 16-bit pools; left to itself the
+backend uses it where a token's K and V rows are at least 1 KiB per layer (ops.shared_prefix_pays: below that the
+per-request kernels, which find the shared rows in L2, are faster).  `share_prefix=True` (or SGLK_SHARE_PREFIX=1) uses
+it wherever it can run, `share_prefix=False` (or SGLK_SHARE_PREFIX=0) keeps every batch on the per-request kernels.
 """
 from __future__ import annotations
 
@@ -61,11 +64,15 @@ class SglkAttnBackend:
     def __init__(self, model_runner, skip_prefill: bool = False, kv_indptr_buf: Optional[torch.Tensor] = None,
                  share_prefix: Optional[bool] = None):
         self.device = model_runner.device
-        if share_prefix is None:
-            share_prefix = os.environ.get("SGLK_SHARE_PREFIX", "1") != "0"
-        self.share_prefix = bool(share_prefix)
+        # None: share where it pays (ops.shared_prefix_pays); True / SGLK_SHARE_PREFIX=1: wherever the kernel can;
+        # False / SGLK_SHARE_PREFIX=0: never
+        env = os.environ.get("SGLK_SHARE_PREFIX")
+        if share_prefix is None and env is not None:
+            share_prefix = env != "0"
+        self.share_auto = share_prefix is None
+        self.share_prefix = True if share_prefix is None else bool(share_prefix)
         self.kv_pool = getattr(model_runner, "token_to_kv_pool", None)
-        self._pool_16bit = None  # found on first use: an fp8 pool has no one-launch shared-prefix kernel
+        self._pool_kind = None  # found on first use: "16" (fp16 / bf16 pool), "8" (an fp8 format) or "other"
         self.req_to_token = model_runner.req_to_token_pool.req_to_token
         max_bs = self.req_to_token.shape[0]
         self.kv_indptr = kv_indptr_buf if kv_indptr_buf is not None else torch.zeros(
@@ -122,19 +129,29 @@ class SglkAttnBackend:
         return ops.decode_shared_workspace(bs, self.num_head, self.v_head_dim, self.max_kv_splits, self.device)
 
     def _shares(self, bs: int) -> bool:
-        """Whether decode batches of bs requests go through the plan + shared-prefix kernel (16-bit pools of head
-        size 128 have the one-launch kernel; a plan covers up to 1024 requests; 16 splits at most)."""
-        if self._pool_16bit is None:
+        """Whether decode batches of bs requests go through the plan + shared-prefix kernel.  The one-launch kernel
+        takes head size 128 over 16-bit and fp8 pools, and head size 64 (an even number of kv heads, 16-bit pools) as
+        pairs of kv heads; a plan covers up to 1024 requests; 16 splits at most."""
+        if self._pool_kind is None:
             try:
-                self._pool_16bit = self.kv_pool.get_key_buffer(0).dtype in (torch.float16, torch.bfloat16)
+                dt = self.kv_pool.get_key_buffer(0).dtype
+                self._pool_kind = ("16" if dt in (torch.float16, torch.bfloat16)
+                                   else "8" if ops.kv_format_code(dt) else "other")
             except Exception:
-                self._pool_16bit = False
-        return (self.share_prefix and self._pool_16bit and self.head_dim == 128 and self.v_head_dim == 128
-                and 0 < bs <= 1024 and self.max_kv_splits <= 16 and not self.sliding_window_size)
+                self._pool_kind = "other"
+        shape_ok = ((self.head_dim == 128 and self.v_head_dim == 128 and self._pool_kind in ("16", "8"))
+                    or (self.head_dim == 64 and self.v_head_dim == 64 and self.num_kv_head % 2 == 0
+                        and self._pool_kind == "16"))
+        if shape_ok and self.share_auto:
+            shape_ok = ops.shared_prefix_pays(self.num_kv_head, self.head_dim, self.v_head_dim,
+                                              1 if self._pool_kind == "8" else 2)
+        return (self.share_prefix and shape_ok and 0 < bs <= 1024 and self.max_kv_splits <= 16
+                and not self.sliding_window_size)
 
     def _plan_buffer(self, max_bs: int):
         """Room for the plan of any batch of up to max_bs requests (the size is not monotonic in the batch size)."""
-        need = max(int(lib().sglk_decode_shared_plan_bytes(b, self.num_head, self.num_kv_head, self.max_kv_splits))
+        hkv = ops.plan_kv_heads(self.num_kv_head, self.head_dim)
+        need = max(int(lib().sglk_decode_shared_plan_bytes(b, self.num_head, hkv, self.max_kv_splits))
                    for b in range(1, max_bs + 1))
         return torch.zeros(need // 4, dtype=torch.int32, device=self.device)
 
@@ -159,9 +176,11 @@ class SglkAttnBackend:
             attn_logits, attn_lse, num_kv_splits = self._decode_buffers(bs)
             self.get_num_kv_splits(num_kv_splits, forward_batch.seq_lens)
             if spec_info is None and self._shares(bs):
-                plan = ops.decode_shared_plan_buffer(bs, self.num_head, self.num_kv_head, self.max_kv_splits, self.device)
+                plan = ops.decode_shared_plan_buffer(bs, self.num_head, self.num_kv_head, self.max_kv_splits, self.device,
+                                                     head_dim=self.head_dim)
                 ops.decode_shared_plan(self.req_to_token, forward_batch.req_pool_indices, forward_batch.seq_lens, kv_indptr,
-                                       kv_indices, self.num_head, self.num_kv_head, self.max_kv_splits, plan)
+                                       kv_indices, self.num_head, self.num_kv_head, self.max_kv_splits, plan,
+                                       head_dim=self.head_dim)
             self.forward_metadata = ForwardMetadata(attn_logits, attn_lse, None, num_kv_splits, kv_indptr, kv_indices,
                                                     None, shared_plan=plan,
                                                     shared_workspace=self._shared_workspace(bs) if plan is not None else None)
@@ -273,7 +292,8 @@ class SglkAttnBackend:
         if plan is not None:
             ops.decode_metadata_shared(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
                                        self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head,
-                                       self.num_kv_head, self.max_kv_splits, self.device_core_count, plan)
+                                       self.num_kv_head, self.max_kv_splits, self.device_core_count, plan,
+                                       head_dim=self.head_dim)
         else:
             ops.decode_metadata(self.req_to_token, req_pool_indices[:bs], seq_lens[:bs], self.kv_indptr,
                                 self.cuda_graph_kv_indices, self.cuda_graph_num_kv_splits, self.num_head, self.num_kv_head,
@@ -331,7 +351,7 @@ class SglkAttnBackend:
                 raise SglkError("sliding-window layer, but model_runner.sliding_window_size was not set")
             ops.decode_attention_fwd(q3, kb, vb, o3, md.window_kv_indptr, md.window_kv_indices, md.attn_logits, md.attn_lse,
                                      md.window_num_kv_splits, self.max_kv_splits, layer.scaling, layer.logit_cap)
-        elif md.shared_plan is not None and q3.dtype in (torch.float16, torch.bfloat16) and kb.dtype == q3.dtype:
+        elif md.shared_plan is not None and q3.dtype in (torch.float16, torch.bfloat16):
             # the plan's groups, or (decided on the device) the per-request kernels when nobody shares anything
             ops.decode_attention_shared_planned(q3, kb, vb, o3, md.kv_indptr[: q3.shape[0] + 1], md.kv_indices,
                                                 md.shared_plan, md.shared_workspace, self.max_kv_splits, layer.scaling,

@@ -1112,7 +1112,12 @@ __device__ __forceinline__ void rope_wait(const RopeRole& rr, int tok, int* erro
 // every block does, and the prefix blocks loop over the items (their number varies from step to step, the grid of a
 // captured launch does not).
 // RR: rope role (see above; PLAN only): blocks [0, rr.blocks) rotate and write, the attention blocks follow.
-template <typename T, bool ROPE, bool PLAN, bool RR = false>
+// KV: the pool's element type (T, or an fp8 format: rows are then widened through a table on their way into LDS,
+// the tail role parks K rows too, and the launch carries 64 KiB + the table instead of 32 KiB).
+// PAIR: head size 64; Hkv counts PAIRS of neighbouring kv heads (one 128-element row piece), a pair's query heads
+// are those of its first kv head followed by those of its second, a query row sits in the half of the 128-wide
+// operand that faces its own kv head (decode_stage1_mfma128 has the details) and only that half of O is stored.
+template <typename T, bool ROPE, bool PLAN, bool RR = false, typename KV = T, bool PAIR = false>
 __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const void* q, QkvPartials qp, void* k_buffer, void* v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
@@ -1130,9 +1135,20 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int hl = lane & 15, g = lane >> 4;
   const int heads = Hq / Hkv;
+  constexpr bool KV8 = !std::is_same<KV, T>::value;
+  static_assert(!(KV8 || PAIR) || (PLAN && !ROPE && !RR), "fp8 pools and head-size-64 pairs: planned form only");
+  [[maybe_unused]] uint16_t* lut = reinterpret_cast<uint16_t*>(lds_all + 2 * kBlockAttnLds);
+  if constexpr (KV8) {
+    lut[threadIdx.x] = Conv<T>::from_f32(KvElem<KV>::value(threadIdx.x));  // 256 threads, 256 codes
+    __syncthreads();
+  }
   ATTN_STAMP(0);
 
   int bid = blockIdx.x;  // index among the attention blocks
+  // a plan laid out for another geometry (heads per kv head, splits, batch) must not be walked
+  bool geom_bad = false;
+  if constexpr (PLAN)
+    geom_bad = plan_hdr[kPlanHeads] != heads || plan_hdr[kPlanSplits] != prefix_splits || plan_hdr[kPlanB] != B;
   if constexpr (RR) {
     if (bid < rr.blocks) {
       rope_role_block<T>(bid, rr, qp, q_stride_b, k_buffer, v_buffer, k_stride_n, k_stride_h, v_stride_n, v_stride_h, Hq,
@@ -1144,6 +1160,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   if constexpr (PLAN) {
     if (bid < n_prefix_blocks) {
       // ---- prefix block (planned): block index = item * Hkv + kvh; items past the grid are taken in further rounds
+      if (geom_bad) return;  // the tail blocks see the same words: they do not wait and report the error
       const int kvh = bid % Hkv;
       const int items_per_round = n_prefix_blocks / Hkv;
       int j = bid / Hkv;
@@ -1184,12 +1201,24 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
               },
               nullptr, pre);
         } else {
-          st.load_q(0, ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
-                          : nullptr);
-          st.template run<false, true, kPrefixPF>(
-              lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0, t1,
-              qpos, 0, sm_scale, logit_cap, typename BlockAttn<T, 1>::NoHook(), nullptr, pre);
+          const uint16_t* qrow = ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req * q_stride_b + (int64_t)head * q_stride_h
+                                    : nullptr;
+          if constexpr (PAIR)
+            st.load_q_half(0, qrow, ((cb * 64 + c) % heads) >= (heads >> 1) ? 1 : 0);
+          else
+            st.load_q(0, qrow);
+          if constexpr (KV8)  // byte pointers, strides in bytes
+            st.template run<false, true, kPrefixPF, typename BlockAttn<T, 1>::NoHook, true>(
+                lds_all,
+                reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(k_buffer) + (int64_t)kvh * k_stride_h),
+                reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(v_buffer) + (int64_t)kvh * v_stride_h),
+                k_stride_n, v_stride_n, plist, t0, t1, qpos, 0, sm_scale, logit_cap, typename BlockAttn<T, 1>::NoHook(), lut,
+                pre);
+          else
+            st.template run<false, true, kPrefixPF>(
+                lds_all, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+                reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n, plist, t0,
+                t1, qpos, 0, sm_scale, logit_cap, typename BlockAttn<T, 1>::NoHook(), nullptr, pre);
         }
         const float tot = st.total(0);
         ATTN_STAMP(1);
@@ -1319,8 +1348,9 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const int4v rec = *reinterpret_cast<const int4v*>(plan_tail + 4 * (int64_t)b);  // uniform address: one scalar load
     start = rec[0];
     len = rec[1];
-    expect_partials = rec[2];
+    expect_partials = geom_bad ? 0 : rec[2];
     aps = rec[3];
+    if (geom_bad) len = 0;
   } else {
     const int grp = find_group(group_indptr, num_groups, b);
     const int plen = prefix_lens[grp];
@@ -1365,11 +1395,21 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
               reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
               kv_indices + start, s0, s1, sm_scale, logit_cap, ks);
   } else {
-    wa.load_q(head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
-                      : nullptr);
-    wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
-              reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+    const uint16_t* qrow = head_ok ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head * q_stride_h
+                                   : nullptr;
+    if constexpr (PAIR)
+      wa.load_q_half(qrow, head_in_group >= (heads >> 1) ? 1 : 0);
+    else
+      wa.load_q(qrow);
+    if constexpr (KV8)  // K rows are parked too (behind the four V tiles), both widened through the table
+      wa.run8(lds_all + kBlockAttnLds + wid * kTileBytes, vl, lut,
+              reinterpret_cast<const uint8_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+              reinterpret_cast<const uint8_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
               kv_indices + start, s0, s1, sm_scale, logit_cap);
+    else
+      wa.run_kd(vl, reinterpret_cast<const uint16_t*>(k_buffer) + (int64_t)kvh * k_stride_h,
+                reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
+                kv_indices + start, s0, s1, sm_scale, logit_cap);
   }
   {
     // this wave's partial: O[16 heads][128] fp32 over its V tile, log-sum-exp[16] beside it
@@ -1385,7 +1425,8 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   int* const counter = ws.counters + (int64_t)b * Hkv + kvh;
   if (threadIdx.x == 0) {
     const int expect = expect_partials;
-    int failed = 0;
+    int failed = geom_bad ? 1 : 0;
+    if (geom_bad) __hip_atomic_store(ws.error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (expect > 0) {
       const uint64_t t_start = wall_clock64();
       uint32_t polls = 0;
@@ -1453,7 +1494,14 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     }
     const float r0 = failed ? __builtin_nanf("") : acc0 / e_sum;
     const float r1 = failed ? __builtin_nanf("") : acc1 / e_sum;
-    if (ok) {
+    if constexpr (PAIR) {
+      // the head's output is the half of the 128-wide row that faces its own kv head: rows of 64
+      const int half = (ht * 16 + (ok ? hh : 0)) >= (heads >> 1) ? 1 : 0;
+      if (ok && (d >> 6) == half) {
+        st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d - 64 * half, r0);
+        st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d - 64 * half + 1, r1);
+      }
+    } else if (ok) {
       st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d, r0);
       st<T>(o, (int64_t)b * o_stride_b + (int64_t)hq * o_stride_h + d + 1, r1);
     }
@@ -1584,7 +1632,7 @@ static int decode_attention_impl(const void* q, const void* k_buffer, const void
   const bool fast8 = kvf != 0 && D == 128 && Dv == 128 && aligned16(q) && al8(k_buffer) && al8(v_buffer) &&
                      aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
                      (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) && (v_stride_h % 8 == 0);
-  SGLK_CHECK(!gate || fast, "decode_attention: a gated launch needs the 16-bit head-size-128 kernel");
+  SGLK_CHECK(!gate || fast || fast8 || pair64, "decode_attention: a gated launch needs one of the tile kernels");
   if (fast8) {
     const int head_tiles = (group + 15) / 16;
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -1593,7 +1641,8 @@ static int decode_attention_impl(const void* q, const void* k_buffer, const void
       SGLK_DISPATCH_KV(kvf, T, KV, {
         hipLaunchKernelGGL((decode_stage1_mfma128<T, KV>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer, v_buffer,
                            kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles,
-                           q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, 0);
+                           q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, 0,
+                           gate);
       });
     });
   } else if (mla) {
@@ -1639,7 +1688,7 @@ static int decode_attention_impl(const void* q, const void* k_buffer, const void
                        hipLaunchKernelGGL((decode_stage1_mfma128<T>), grid, dim3(64 * kWavesPerBlock), lds, s, q, k_buffer,
                                           v_buffer, kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits,
                                           max_kv_splits, Hq, Hkv / 2, head_tiles, q_stride_b, q_stride_h, k_stride_n,
-                                          (int64_t)128, v_stride_n, (int64_t)128, sm_scale, logit_cap, group));
+                                          (int64_t)128, v_stride_n, (int64_t)128, sm_scale, logit_cap, group, gate));
   } else {
     dim3 grid(B, Hq, max_kv_splits);
     const size_t lds = (size_t)D * sizeof(float);
@@ -1711,7 +1760,9 @@ static int64_t shared_counter_bytes(int B, int Hq) { return ((((int64_t)B * Hq +
 int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits) {
   if (B <= 0 || Hq <= 0 || Dv <= 0 || max_kv_splits <= 0) return 0;
   // counters, then partial outputs + log-sum-exps, then one split count per request (used by the shapes that take
-  // the per-request kernels)
+  // the per-request kernels).  The one-launch kernel keeps partial rows of 128 floats whatever the head size (head
+  // size 64 runs on pairs of kv heads, 128 wide).
+  Dv = std::max(Dv, 128);
   return shared_counter_bytes(B, Hq) + (int64_t)B * Hq * max_kv_splits * (Dv + 1) * (int64_t)sizeof(float) +
          (((int64_t)B * 4 + 255) / 256) * 256;
 }
@@ -1753,14 +1804,27 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
              "decode_attention_shared_prefix: max_kv_splits must be in 1..16");
   if (B == 0) return SGLK_OK;
   auto mult8 = [](int64_t v) { return v % 8 == 0; };
-  const bool fast = (dtype == SGLK_F16 || dtype == SGLK_BF16) && D == 128 && Dv == 128 && (qp || aligned16(q)) &&
+  const int kvf = dtype >> SGLK_KV_SHIFT;  // fp8 pool format, 0: pool elements of the query type
+  const int qdtype = dtype & ((1 << SGLK_KV_SHIFT) - 1);
+  const bool half_q = qdtype == SGLK_F16 || qdtype == SGLK_BF16;
+  const bool fast = kvf == 0 && half_q && D == 128 && Dv == 128 && (qp || aligned16(q)) &&
                     aligned16(k_buffer) && aligned16(v_buffer) && aligned16(workspace) &&
                     (qp || (mult8(q_stride_b) && mult8(q_stride_h))) && mult8(k_stride_n) && mult8(k_stride_h) &&
                     mult8(v_stride_n) && mult8(v_stride_h);
+  // the planned launch also takes fp8 pools of head size 128 (rows widened through a table on their way into LDS) and
+  // head size 64 with an even number of kv heads whose rows are contiguous (pairs of kv heads as one 128-wide head)
+  auto al8 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; };
+  const bool plain_planned = plan && !qp && !rope_src && half_q && q && aligned16(q) && aligned16(workspace) &&
+                             mult8(q_stride_b) && mult8(q_stride_h) && mult8(k_stride_n) && mult8(v_stride_n);
+  const bool fast8 = plain_planned && kvf != 0 && D == 128 && Dv == 128 && al8(k_buffer) && al8(v_buffer) &&
+                     mult8(k_stride_h) && mult8(v_stride_h);
+  const bool pair64 = plain_planned && kvf == 0 && D == 64 && Dv == 64 && Hkv % 2 == 0 && k_stride_h == 64 &&
+                      v_stride_h == 64 && aligned16(k_buffer) && aligned16(v_buffer) && !xsum_out;
   hipStream_t s = (hipStream_t)stream;
-  if (!fast) {
-    // Other shapes (absorbed MLA 576 / 512, head size 64, fp32): the same result from the per-request kernels over the
-    // same lists, with the groups ignored: a group's shared rows are then fetched once per request, from L2 after the
+  if (!fast && !fast8 && !pair64) {
+    // Other shapes (absorbed MLA 576 / 512, fp32, layouts the tile kernels do not take, and everything but the plain
+    // planned form for fp8 pools and head size 64): the same result from the per-request kernels over the same
+    // lists, with the groups ignored: a group's shared rows are then fetched once per request, from L2 after the
     // first.  The workspace holds their partials ([B, Hq, S, Dv] + [B, Hq, S]) and one split count per request.
     if (qp)
       return fail(SGLK_EUNSUP, "decode_attention_shared_prefix_rope: only 16-bit types with head size 128 (got D=%d Dv=%d)",
@@ -1774,6 +1838,10 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
     return sglk_decode_attention_xs(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, logits, lse, ns, max_kv_splits, B, Hq,
                                     Hkv, D, Dv, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h,
                                     o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out, xs_stride, stream);
+  }
+  if (pair64) {  // from here on a pair of kv heads is one kv head of 128 elements
+    Hkv /= 2;
+    k_stride_h = v_stride_h = 128;
   }
   const int heads = Hq / Hkv;
   static const int env_sp = getenv("SGLK_SHARED_SPLITS") ? atoi(getenv("SGLK_SHARED_SPLITS")) : 0;
@@ -1800,7 +1868,9 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
     pv = plan_view(const_cast<int32_t*>(plan), B, plan_max_items(B, heads, prefix_splits));
     SGLK_CHECK(aligned16(plan), "decode_attention_shared_prefix: plan must be 16-byte aligned");
   }
-  const size_t lds = kBlockAttnLds;  // the prefix role's two stages; the tail role's four V tiles fit in the same bytes
+  // the prefix role's two stages; the tail role's four V tiles fit in the same bytes (fp8 pools: four K tiles and the
+  // code table behind them)
+  const size_t lds = fast8 ? 2 * kBlockAttnLds + kKv8LutBytes : kBlockAttnLds;
   static_assert(kWavesPerBlock * kTileBytes <= kBlockAttnLds, "LDS of the prefix role must cover the tail role");
   RopeRole rr{};
   if (rope_src) {
@@ -1823,7 +1893,31 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
                                         col_blocks, B, Hq, Hkv, head_tiles, q_stride_b, q_stride_h, k_stride_n,          \
                                         k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o, o_stride_b,          \
                                         o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8), rr))
-  if (rope_src) {
+  dtype = qdtype;
+#define SGLK_SHARED_LAUNCH_KV(KVT, PAIRV)                                                                               \
+  hipLaunchKernelGGL((decode_shared_fused_kernel<T, false, true, false, KVT, PAIRV>), dim3(n_prefix + n_tail), dim3(256), \
+                     lds, s, q, QkvPartials{}, k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G,   \
+                     pv.hdr, pv.tail, pv.items, ws, prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles,          \
+                     q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o,      \
+                     o_stride_b, o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8), rr)
+  if (fast8) {
+    static bool lds_set[64][4][2];  // per device: the attribute belongs to the device's copy of the code object
+    int dev = 0;
+    SGLK_HIP(hipGetDevice(&dev));
+    SGLK_DISPATCH_HALF(dtype, T, {
+      SGLK_DISPATCH_KV(kvf, T, KV, {
+        bool& done = lds_set[dev & 63][kvf & 3][dtype == SGLK_F16 ? 1 : 0];
+        if (!done) {  // 64.5 KiB of dynamic LDS: above the default limit
+          SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_shared_fused_kernel<T, false, true, false, KV, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          done = true;
+        }
+        SGLK_SHARED_LAUNCH_KV(KV, false);
+      });
+    });
+  } else if (pair64) {
+    SGLK_DISPATCH_HALF(dtype, T, SGLK_SHARED_LAUNCH_KV(T, true));
+  } else if (rope_src) {
     SGLK_DISPATCH_HALF(dtype, T,
                        hipLaunchKernelGGL((decode_shared_fused_kernel<T, false, true, true>),
                                           dim3(rr.blocks + n_prefix + n_tail), dim3(256), lds, s, q, *rope_src, k_buffer,
@@ -1847,6 +1941,7 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
     SGLK_SHARED_LAUNCH(false, false, QkvPartials{});
   }
 #undef SGLK_SHARED_LAUNCH
+#undef SGLK_SHARED_LAUNCH_KV
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
@@ -1990,9 +2085,13 @@ int sglk_decode_attention_shared_planned(const void* q, const void* k_buffer, co
     // kernels, whose split counts follow the sequence lengths and the CU count.  Whether that is so is known on the
     // device only, and a captured launch sequence cannot change: both forms are launched, and the blocks of the one
     // the plan does not select leave at once (the word both read is the plan's item count).
+    // (the shapes launch_shared_prefix takes on its one-launch kernel; any other shape runs the per-request kernels
+    // there anyway)
     const int kvf = dtype >> SGLK_KV_SHIFT;
-    const bool tile = kvf == 0 && ((dtype & ((1 << SGLK_KV_SHIFT) - 1)) == SGLK_F16 || (dtype & ((1 << SGLK_KV_SHIFT) - 1)) == SGLK_BF16) &&
-                      D == 128 && Dv == 128;
+    const int qd = dtype & ((1 << SGLK_KV_SHIFT) - 1);
+    const bool tile = (qd == SGLK_F16 || qd == SGLK_BF16) &&
+                      ((D == 128 && Dv == 128) || (kvf == 0 && D == 64 && Dv == 64 && Hkv % 2 == 0 && k_stride_h == 64 &&
+                                                   v_stride_h == 64 && !xsum_out));
     if (tile) {
       SGLK_CHECK(workspace, "decode_attention_shared_planned: null pointer");
       float* logits = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));

@@ -227,6 +227,19 @@ struct BlockAttn {
     }
   }
 
+  // a 64-element query row in half `half` of the 128-wide operand, zeros in the other half (pairs of 64-wide kv heads
+  // walked as one 128-wide row: the product then is the row's own head's)
+  __device__ __forceinline__ void load_q_half(int c, const uint16_t* qrow, int half) {
+    const int g = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (qrow && (ks >> 1) == half)
+        qf[c][ks] = *reinterpret_cast<const short8*>(qrow + 32 * (ks & 1) + 8 * g);
+      else
+        qf[c][ks] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+  }
+
   // Stream tokens [t_begin, t_end) (block-uniform, non-empty).  GATHER: token t lives in pool row idx[t],
   // else in row t of kbase/vbase.  CAUSAL: column tile c of this lane sees token t only if t <= qpos[c];
   // wave_qmax is the largest qpos of the wave (tiles wholly above it are skipped by the wave).

@@ -698,9 +698,10 @@ class LlamaDecoder:
             # group_indptr / group_prefix; "legacy": the kernel reads group_indptr / group_prefix itself, per layer
             self.plan_mode = getattr(self, "plan_mode", None) or os.environ.get("SGLK_SHARED_PLAN", "derived")
             self.shared_plan = None
-            if self.plan_mode != "legacy" and c.head_dim == 128 and self.B <= 1024:
+            pair64 = c.head_dim == 64 and c.kv_heads % 2 == 0   # pairs of kv heads as one 128-wide head
+            if self.plan_mode != "legacy" and (c.head_dim == 128 or pair64) and self.B <= 1024:
                 self.shared_plan = ops.decode_shared_plan_buffer(self.B, c.q_heads, c.kv_heads, self.max_kv_splits,
-                                                                 self.device)
+                                                                 self.device, head_dim=c.head_dim)
         return self.shared
 
     def _metadata(self):
@@ -710,13 +711,14 @@ class LlamaDecoder:
         if plan is not None and self.plan_mode == "derived":
             ops.decode_metadata_shared(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr,
                                        self.kv_indices, self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits,
-                                       self.cu_count, plan)
+                                       self.cu_count, plan, head_dim=c.head_dim)
             return
         ops.decode_metadata(self.req_to_token, self.req_pool_indices, self.seq_lens, self.kv_indptr, self.kv_indices,
                             self.num_kv_splits, c.q_heads, c.kv_heads, self.max_kv_splits, self.cu_count)
         if plan is not None:
             ops.decode_shared_plan_from_groups(self.kv_indptr, self.kv_indices, self.group_indptr, self.group_prefix,
-                                               self.B, c.q_heads, c.kv_heads, self.max_kv_splits, plan)
+                                               self.B, c.q_heads, c.kv_heads, self.max_kv_splits, plan,
+                                               head_dim=c.head_dim)
 
     def attention(self, li, q_view, o_view, sm_scale, xsum_out=None):
         if getattr(self, "shared", False) and getattr(self, "shared_plan", None) is not None:

@@ -78,9 +78,23 @@ def decode_metadata(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indi
         "decode_metadata")
 
 
-def decode_shared_plan_buffer(B, Hq, Hkv, max_kv_splits, device) -> torch.Tensor:
+def plan_kv_heads(Hkv: int, head_dim: int) -> int:
+    """The kv head count a plan is laid out for: with head size 64 the shared-prefix kernel walks PAIRS of neighbouring
+    kv heads as one 128-wide head (an even number of kv heads), so a plan for it counts pairs."""
+    return Hkv // 2 if (head_dim == 64 and Hkv % 2 == 0) else Hkv
+
+
+def shared_prefix_pays(Hkv: int, head_dim: int, v_head_dim: int, itemsize: int) -> bool:
+    """Whether sharing a prefix in the one-launch kernel is worth its longer dependency chain (prefix blocks ->
+    counter -> merge): it trades that chain for fetching the prefix rows once per group, which pays when a token's K and
+    V rows are large.  Measured at batch 64, 1024 shared + 128 private tokens: Llama-3-8B (4 KiB of K + V per token and
+    layer) gains 12 % of the step, Qwen2-0.5B (512 bytes) loses 9 %; the line is drawn at 1 KiB."""
+    return Hkv * (head_dim + v_head_dim) * itemsize >= 1024
+
+
+def decode_shared_plan_buffer(B, Hq, Hkv, max_kv_splits, device, head_dim=128) -> torch.Tensor:
     """An int32 buffer for the per-step plan of the shared-prefix decode kernel (up to B requests)."""
-    n = int(lib().sglk_decode_shared_plan_bytes(B, Hq, Hkv, max_kv_splits))
+    n = int(lib().sglk_decode_shared_plan_bytes(B, Hq, plan_kv_heads(Hkv, head_dim), max_kv_splits))
     if n <= 0:
         raise SglkError("decode_shared_plan_buffer: bad shape")
     return torch.zeros(n // 4, dtype=torch.int32, device=device)
@@ -93,11 +107,13 @@ def _plan_room(plan, B, Hq, Hkv, max_kv_splits, what):
 
 
 def decode_shared_plan(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, Hq, Hkv, max_kv_splits, plan,
-                       min_share=0):
+                       min_share=0, head_dim=128):
     """Find the groups of requests that share their first slots and lay the step's work out for
-    decode_attention_shared_planned (device work only: no host synchronisation, fixed addresses)."""
+    decode_attention_shared_planned (device work only: no host synchronisation, fixed addresses).  head_dim: the
+    model's head size (64: the plan counts pairs of kv heads, see plan_kv_heads)."""
     _need_gpu(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, plan)
     B = seq_lens.shape[0]
+    Hkv = plan_kv_heads(Hkv, head_dim)
     _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_shared_plan")
     check(lib().sglk_decode_shared_plan(
         _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices), _ptr(seq_lens),
@@ -105,8 +121,10 @@ def decode_shared_plan(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_i
         _stream(seq_lens)), "decode_shared_plan")
 
 
-def decode_shared_plan_from_groups(kv_indptr, kv_indices, group_indptr, prefix_lens, B, Hq, Hkv, max_kv_splits, plan):
+def decode_shared_plan_from_groups(kv_indptr, kv_indices, group_indptr, prefix_lens, B, Hq, Hkv, max_kv_splits, plan,
+                                   head_dim=128):
     _need_gpu(kv_indptr, kv_indices, group_indptr, prefix_lens, plan)
+    Hkv = plan_kv_heads(Hkv, head_dim)
     _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_shared_plan_from_groups")
     check(lib().sglk_decode_shared_plan_from_groups(
         _ptr(kv_indptr), _ptr(kv_indices), _ptr(group_indptr), _ptr(prefix_lens), group_indptr.shape[0] - 1, B, Hq, Hkv,
@@ -114,9 +132,17 @@ def decode_shared_plan_from_groups(kv_indptr, kv_indices, group_indptr, prefix_l
 
 
 def decode_metadata_shared(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits, num_head,
-                           num_kv_head, max_kv_splits, device_core_count, plan, min_share=0):
+                           num_kv_head, max_kv_splits, device_core_count, plan, min_share=0, head_dim=128):
     """decode_metadata + decode_shared_plan in one call."""
     _need_gpu(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits, plan)
+    if plan_kv_heads(num_kv_head, head_dim) != num_kv_head:
+        # the split counts follow the model's kv heads, the plan counts pairs of them
+        decode_metadata(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_kv_splits, num_head,
+                        num_kv_head, max_kv_splits, device_core_count)
+        if seq_lens.shape[0]:
+            decode_shared_plan(req_to_token, req_pool_indices, seq_lens, kv_indptr, kv_indices, num_head, num_kv_head,
+                               max_kv_splits, plan, min_share, head_dim)
+        return
     _plan_room(plan, seq_lens.shape[0], num_head, num_kv_head, max_kv_splits, "decode_metadata_shared")
     check(lib().sglk_decode_metadata_shared(
         _ptr(req_to_token), req_to_token.stride(0), _ptr(req_pool_indices), _is64(req_pool_indices),
@@ -148,7 +174,7 @@ def decode_attention_shared_planned(q, k_buffer, v_buffer, o, kv_indptr, kv_indi
     need = decode_shared_workspace_bytes(B, Hq, Dv, max_kv_splits)
     if workspace.numel() * workspace.element_size() < need:
         raise SglkError(f"decode_attention_shared_planned: workspace too small ({need} bytes needed)")
-    _plan_room(plan, B, Hq, Hkv, max_kv_splits, "decode_attention_shared_planned")
+    _plan_room(plan, B, Hq, plan_kv_heads(Hkv, D), max_kv_splits, "decode_attention_shared_planned")
     check(lib().sglk_decode_attention_shared_planned(
         _ptr(q), _ptr(k_buffer), _ptr(v_buffer), _ptr(o), _ptr(kv_indptr), _ptr(kv_indices), _ptr(plan), _ptr(workspace),
         max_kv_splits, B, Hq, Hkv, D, Dv, q.stride(0), q.stride(1), k_buffer.stride(0), k_buffer.stride(1),

@@ -421,6 +421,69 @@ def test_shared_prefix_other_shapes(dtype, Hq, Hkv, D, Dv):
     assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
 
 
+def _group_batch_d(groups, Hq, Hkv, D, dtype, seed):
+    """_group_batch for another head size."""
+    q, kb, vb, ptr, ind, gi, pls = _group_batch(groups, Hq, Hkv, dtype, seed)
+    gen = torch.Generator().manual_seed(seed + 1000)
+    n = kb.shape[0]
+    return (torch.randn(q.shape[0], Hq, D, generator=gen).to(dtype), torch.randn(n, Hkv, D, generator=gen).to(dtype),
+            torch.randn(n, Hkv, D, generator=gen).to(dtype), ptr, ind, gi, pls)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("groups,Hq,Hkv,max_splits", [
+    ([(6, 130, 1, 50), (1, 0, 3, 9), (5, 64, 1, 200)], 14, 2, 8),      # Qwen2-0.5B heads: 7 per kv head, one pair
+    ([(40, 96, 1, 20)], 16, 4, 4),                                     # two pairs, more columns than one block
+    ([(3, 70, 1, 40), (2, 33, 0, 0)], 64, 2, 3),                       # 64 heads per pair: four head tiles
+])
+def test_shared_prefix_planned_head_size_64(dtype, groups, Hq, Hkv, max_splits):
+    """Head size 64 on the one-launch kernel: pairs of kv heads walked as one 128-wide head, the plan laid out for the
+    pairs (ops.plan_kv_heads).  Against the oracle and against the per-request kernels on the same lists."""
+    import oracle
+
+    ops = _ops()
+    D = 64
+    q, kb, vb, ptr, ind, gi, pls = _group_batch_d(groups, Hq, Hkv, D, dtype, seed=Hq + Hkv)
+    B = q.shape[0]
+    sm = 1.0 / math.sqrt(D)
+    want = oracle.decode_attention(q, kb, vb, ptr, ind, torch.ones(B, dtype=torch.int32), sm)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV, head_dim=D)
+    ops.decode_shared_plan_from_groups(ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV), B, Hq, Hkv, max_splits, plan,
+                                       head_dim=D)
+    assert ops.decode_shared_plan_read(plan, B)["n_items"] > 0
+    o = _run_planned(ops, q, kb, vb, ptr, ind, plan, max_splits, dtype, sm).float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o).all()
+    assert (o - want).abs().max().item() < tol
+    o2 = torch.empty(B, Hq, D, dtype=dtype, device=DEV)
+    al = torch.empty(B, Hq, max_splits, D, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, max_splits, dtype=torch.float32, device=DEV)
+    ns = torch.full((B,), max_splits, dtype=torch.int32, device=DEV)
+    ops.decode_attention_fwd(q.to(DEV), kb.to(DEV), vb.to(DEV), o2, ptr.to(DEV), ind.to(DEV), al, lse, ns, max_splits, sm, 0.0)
+    assert (o - o2.float().cpu()).abs().max().item() < tol
+    # with the per-request kernels beside it (the form the backend launches): the plan has items, they leave at once
+    o_g = _run_planned(ops, q, kb, vb, ptr, ind, plan, max_splits, dtype, sm, num_kv_splits=ns).float().cpu()
+    assert torch.equal(o_g, o)
+
+
+def test_shared_prefix_planned_rejects_a_plan_of_another_geometry():
+    """A plan laid out for other heads per kv head must not be walked: NaN rows and the workspace's error word, not a
+    wrong answer (here: a head-size-64 launch on a plan that counts single kv heads)."""
+    ops = _ops()
+    dtype, D, Hq, Hkv, S = torch.bfloat16, 64, 16, 4, 4
+    q, kb, vb, ptr, ind, gi, pls = _group_batch_d([(6, 70, 1, 20)], Hq, Hkv, D, dtype, seed=5)
+    B = q.shape[0]
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, S, DEV)          # room and layout for 4 kv heads of 4 heads
+    ops.decode_shared_plan_from_groups(ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV), B, Hq, Hkv, S, plan)
+    o = torch.zeros(B, Hq, D, dtype=dtype, device=DEV)
+    ws = ops.decode_shared_workspace(B, Hq, D, S, DEV)
+    ops.decode_attention_shared_planned(q.to(DEV), kb.to(DEV), vb.to(DEV), o, ptr.to(DEV), ind.to(DEV), plan, ws, S,
+                                        1.0 / math.sqrt(D))
+    torch.cuda.synchronize()
+    assert torch.isnan(o.float()).all()
+    assert ops.decode_shared_workspace_status(ws, B, Hq) == 1
+
+
 # ------------------------------------------------------------------------------------------ aiter call surface
 @pytest.mark.parametrize("dtype,D", [(torch.bfloat16, 128), (torch.float16, 128), (torch.float32, 64)])
 @pytest.mark.parametrize("causal", [True, False])

@@ -66,16 +66,19 @@ def test_pools_and_set_kv_buffer():
 
 @pytest.mark.parametrize("graph_state", [False, True])
 @pytest.mark.parametrize("share", [True, False])
-def test_backend_decode_matches_oracle(graph_state, share):
+@pytest.mark.parametrize("Hq,Hkv,D,pool_dtype", [(16, 4, 128, torch.bfloat16), (14, 2, 64, torch.bfloat16),
+                                                (16, 4, 128, torch.float8_e4m3fn), (16, 4, 128, torch.float8_e5m2fnuz)])
+def test_backend_decode_matches_oracle(graph_state, share, Hq, Hkv, D, pool_dtype):
     """Radix-style batch (shared 100-token prefix + private tails) through init_forward_metadata / forward_decode with
     nothing but the reference's own arguments: the backend finds the group on the device (share=True: the shared-prefix
-    kernel runs) or is told to keep to the per-request kernel; eager and fixed-address (graph) metadata."""
+    kernel runs) or is told to keep to the per-request kernel; eager and fixed-address (graph) metadata.  Llama heads,
+    Qwen2-0.5B's (head size 64: pairs of kv heads), and fp8 pools."""
     import oracle
     from sglang_security_amd import ops
     from sglang_security_amd.attention import SglkAttnBackend
 
-    Hq, Hkv, D, B = 16, 4, 128, 5
-    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    B = 5
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D, dtype=pool_dtype)
     g = torch.Generator().manual_seed(0)
     prefix = alloc.alloc(100)
     lens, slots_new = [], []
@@ -86,7 +89,7 @@ def test_backend_decode_matches_oracle(graph_state, share):
         r2t.req_to_token[b, 100:L] = tail.int()
         lens.append(L)
         slots_new.append(int(tail[-1]))
-    for layer_buf in (kv.k_buffer[0], kv.v_buffer[0]):
+    for layer_buf in (kv.get_key_buffer(0), kv.get_value_buffer(0)):
         layer_buf.copy_(torch.randn(layer_buf.shape, generator=g).to(torch.bfloat16))
     seq_lens = torch.tensor(lens, device=DEV)
     q = torch.randn(B, Hq * D, generator=g).to(torch.bfloat16).to(DEV)
@@ -111,11 +114,13 @@ def test_backend_decode_matches_oracle(graph_state, share):
         assert plan["prefix_lens"] == [100] and plan["n_items"] > 0
     o = be.forward(q, k_new, v_new, layer, fb)
     # oracle over the pool AFTER the write of the new token
-    kb, vb = kv.k_buffer[0].cpu(), kv.v_buffer[0].cpu()
-    assert torch.equal(kb[slots_new], k_new.cpu().view(B, Hkv, D))
+    kb, vb = kv.get_key_buffer(0).cpu(), kv.get_value_buffer(0).cpu()
+    assert torch.equal(kb[slots_new].view(torch.uint8), k_new.cpu().view(B, Hkv, D).to(pool_dtype).view(torch.uint8))
     ptr = torch.zeros(B + 1, dtype=torch.int32)
     ptr[1:] = torch.cumsum(torch.tensor(lens), 0)
     ind = torch.cat([r2t.req_to_token[b, : lens[b]].cpu() for b in range(B)])
+    if pool_dtype != torch.bfloat16:      # the oracle sees an fp8 pool through the values its codes stand for
+        kb, vb = kb.float().to(torch.bfloat16), vb.float().to(torch.bfloat16)
     want = oracle.decode_attention(q.cpu().view(B, Hq, D), kb, vb, ptr, ind, torch.ones(B, dtype=torch.int32), layer.scaling)
     assert (o.float().cpu().view(B, Hq, D) - want).abs().max().item() < 2e-2
     if share:

@@ -199,6 +199,78 @@ def test_shared_prefix_entry_fp8_pool(fmt):
 
 @pytest.mark.parametrize("fmt", list(FORMATS))
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Hq,Hkv,prefix,max_splits", [(24, 32, 8, 200, 8), (5, 28, 4, 33, 4), (70, 8, 8, 64, 2)])
+def test_shared_prefix_planned_fp8_pool_vs_oracle(fmt, dtype, B, Hq, Hkv, prefix, max_splits):
+    """The one-launch shared-prefix kernel over an fp8 pool (head size 128): groups found on the device from the
+    request table, prefix rows streamed once per group and widened through the code table, against the C oracle run on
+    the decoded pool and against the per-request kernels over the same lists."""
+    import oracle
+
+    ops = _ops()
+    D = 128
+    q, kb8, vb8, kf, vf, ptr, ind, seq = _batch(B, Hq, Hkv, D, D, prefix, dtype, fmt, seed=B + Hq)
+    # the request table _batch built its lists from
+    lens = seq.tolist()
+    r2t = torch.zeros(B, max(lens) + 4, dtype=torch.int32)
+    for b in range(B):
+        r2t[b, : lens[b]] = ind[int(ptr[b]): int(ptr[b + 1])]
+    qd, kd, vd = q.to(DEV), kb8.to(DEV), vb8.to(DEV)
+    ptr_d = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    ind_d = torch.zeros(int(ptr[-1]), dtype=torch.int32, device=DEV)
+    ns = torch.zeros(B, dtype=torch.int32, device=DEV)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV)
+    ops.decode_metadata_shared(r2t.to(DEV), torch.arange(B, device=DEV), seq.to(DEV), ptr_d, ind_d, ns, Hq, Hkv, max_splits,
+                               256, plan)
+    torch.cuda.synchronize()
+    view = ops.decode_shared_plan_read(plan, B)
+    assert view["n_items"] > 0 and view["prefix_lens"][0] == prefix
+    sm = 1.0 / math.sqrt(D)
+    want = oracle.decode_attention(q, kf, vf, ptr, ind, torch.ones(B, dtype=torch.int32), sm)
+    ws = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
+    outs = []
+    for gate in (None, ns, None):          # alone, with the per-request kernels beside it, and again on the workspace
+        o = torch.full((B, Hq, D), float("nan"), dtype=dtype, device=DEV)
+        ops.decode_attention_shared_planned(qd, kd, vd, o, ptr_d, ind_d, plan, ws, max_splits, sm, 0.0, None, gate)
+        torch.cuda.synchronize()
+        assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    o = outs[0].float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o).all()
+    assert (o - want).abs().max().item() < tol
+    plain = _decode(ops, qd, kd, vd, ptr_d, ind_d, ns, max_splits, sm).float().cpu()
+    assert (o - plain).abs().max().item() < tol
+
+
+def test_shared_prefix_planned_fp8_pool_nobody_shares():
+    """A batch in which nothing is shared, planned launch with the per-request kernels beside it: the plan holds no
+    item, the one-launch kernel's blocks leave, and the rows are the per-request kernels', bit for bit."""
+    ops = _ops()
+    B, Hq, Hkv, D, S = 7, 32, 8, 128, 8
+    q, kb8, vb8, _, _, ptr, ind, seq = _batch(B, Hq, Hkv, D, D, 0, torch.bfloat16, "e4m3fn", seed=9)
+    lens = seq.tolist()
+    r2t = torch.zeros(B, max(lens) + 4, dtype=torch.int32)
+    for b in range(B):
+        r2t[b, : lens[b]] = ind[int(ptr[b]): int(ptr[b + 1])]
+    qd, kd, vd = q.to(DEV), kb8.to(DEV), vb8.to(DEV)
+    ptr_d = torch.zeros(B + 1, dtype=torch.int32, device=DEV)
+    ind_d = torch.zeros(int(ptr[-1]), dtype=torch.int32, device=DEV)
+    ns = torch.zeros(B, dtype=torch.int32, device=DEV)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, S, DEV)
+    ops.decode_metadata_shared(r2t.to(DEV), torch.arange(B, device=DEV), seq.to(DEV), ptr_d, ind_d, ns, Hq, Hkv, S, 256, plan)
+    assert ops.decode_shared_plan_read(plan, B)["n_items"] == 0
+    sm = 1.0 / math.sqrt(D)
+    ws = ops.decode_shared_workspace(B, Hq, D, S, DEV)
+    o = torch.full((B, Hq, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.decode_attention_shared_planned(qd, kd, vd, o, ptr_d, ind_d, plan, ws, S, sm, 0.0, None, ns)
+    torch.cuda.synchronize()
+    plain = _decode(ops, qd, kd, vd, ptr_d, ind_d, ns, S, sm)
+    assert torch.equal(o, plain)
+
+
+@pytest.mark.parametrize("fmt", list(FORMATS))
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("Hq,Hkv,D", [(8, 2, 128), (6, 3, 64)])
 def test_extend_attention_fp8_pool_vs_oracle(fmt, dtype, Hq, Hkv, D):
     """Extend over a cached prefix held in an fp8 pool, new tokens in the model's type (the prefix stage reads bytes, the
@@ -342,6 +414,7 @@ def test_backend_decode_and_extend_over_fp8_pool():
     import types
 
     import oracle
+    from sglang_security_amd import ops as ops_mod
     from sglang_security_amd.attention import SglkAttnBackend
     from test_gpu_backend import _Mode, _layer, _runner
 
@@ -405,10 +478,11 @@ def test_backend_decode_and_extend_over_fp8_pool():
     want_d = oracle.decode_attention(qd.cpu().view(B, Hq, D), pool_k, pool_v, ptr, ind, torch.ones(B, dtype=torch.int32),
                                      layer.scaling)
     assert (od.float().cpu().view(B, Hq, D) - want_d).abs().max().item() < 2e-2
-    # an fp8 pool has no one-launch shared-prefix kernel: the backend lays no plan out and keeps to the per-request
-    # kernels, which read the pool's bytes
-    assert be.forward_metadata.shared_plan is None
-    # the shared-prefix entry point itself, handed the groups, routes an fp8 pool per request: the same numbers
+    # head size 128: the backend laid a plan out, and its one-launch kernel read the fp8 pool (rows widened through
+    # the code table)
+    assert be.forward_metadata.shared_plan is not None
+    assert ops_mod.decode_shared_plan_read(be.forward_metadata.shared_plan, B)["n_items"] > 0
+    # the group-array entry point, handed the groups, routes an fp8 pool per request: the same numbers
     from sglang_security_amd import ops
 
     md = be.forward_metadata
