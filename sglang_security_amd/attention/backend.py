@@ -22,9 +22,9 @@ the metadata call (eager, graph capture and graph replay alike) finds, on the de
 of requests whose req_to_token rows start with the same pool slots -- the radix-tree hit RadixCache.match_prefix handed
 them -- and lays the step's work out for the kernel, which reads a group's shared part of the KV pool once.  A batch in
 which nobody shares anything is walked per request (the device decides; see ops.decode_attention_shared_planned).
-The kernel covers head size 128 over 16-bit and fp8 pools and head size 64 over 16-bit pools; left to itself the
-backend uses it where a token's K and V rows are at least 1 KiB per layer (ops.shared_prefix_pays: below that the
-per-request kernels, which find the shared rows in L2, are faster).  `share_prefix=True` (or SGLK_SHARE_PREFIX=1) uses
+The kernel covers head size 128 over 16-bit and fp8 pools, head size 64 over 16-bit pools and (as two launches)
+absorbed MLA; left to itself the backend uses it where it measured faster (ops.shared_prefix_pays: a token's K and V
+rows of at least 1 KiB per layer, not MLA -- elsewhere the per-request kernels, which find the shared rows in L2, win).  `share_prefix=True` (or SGLK_SHARE_PREFIX=1) uses
 it wherever it can run, `share_prefix=False` (or SGLK_SHARE_PREFIX=0) keeps every batch on the per-request kernels.
 """
 from __future__ import annotations
@@ -130,8 +130,9 @@ class SglkAttnBackend:
 
     def _shares(self, bs: int) -> bool:
         """Whether decode batches of bs requests go through the plan + shared-prefix kernel.  The one-launch kernel
-        takes head size 128 over 16-bit and fp8 pools, and head size 64 (an even number of kv heads, 16-bit pools) as
-        pairs of kv heads; a plan covers up to 1024 requests; 16 splits at most."""
+        takes head size 128 over 16-bit and fp8 pools, head size 64 (an even number of kv heads, 16-bit pools) as
+        pairs of kv heads, and absorbed MLA (576 / 512, 16-bit pool) in a two-launch form; a plan covers up to 1024
+        requests; 16 splits at most."""
         if self._pool_kind is None:
             try:
                 dt = self.kv_pool.get_key_buffer(0).dtype
@@ -141,6 +142,8 @@ class SglkAttnBackend:
                 self._pool_kind = "other"
         shape_ok = ((self.head_dim == 128 and self.v_head_dim == 128 and self._pool_kind in ("16", "8"))
                     or (self.head_dim == 64 and self.v_head_dim == 64 and self.num_kv_head % 2 == 0
+                        and self._pool_kind == "16")
+                    or (self.head_dim == 576 and self.v_head_dim == 512 and self.num_kv_head == 1
                         and self._pool_kind == "16"))
         if shape_ok and self.share_auto:
             shape_ok = ops.shared_prefix_pays(self.num_kv_head, self.head_dim, self.v_head_dim,

@@ -488,17 +488,184 @@ static constexpr int kMlaScoreBytes = 4 * 2 * 64 * 16;   // four waves' partial 
 // operand read out of it then serve twice the heads).
 // CAP: the logit cap (tanh) compiled in; a run-time test per score splits the tile loop into blocks the scheduler
 // cannot interleave.
+// The tile loop of the absorbed-MLA kernels: a block of four waves multiplies HT tiles of 16 query columns (lane hl of
+// tile t holds the column whose query row is qrow[t]; nullptr: a column that does not exist) against tokens
+// [s0, s1) (non-empty) of the slot list idx, whose latent rows are at kbase + slot * k_stride_n.  On return m / lsum /
+// oacc hold the running maximum (log2 domain), this lane's share of the sum and this wave's 128 output elements
+// (wave w: elements [128 w, 128 w + 128)) per tile.
+template <typename T, int HT, bool CAP>
+struct MlaRun {
+  float m[HT], lsum[HT];
+  float4v oacc[HT][8];
+
+  __device__ __forceinline__ void run(char* lds, const uint16_t* const (&qrow)[HT], const uint16_t* kbase,
+                                      int64_t k_stride_n, const int32_t* idx, int s0, int s1, float sm_scale,
+                                      float logit_cap) {
+    char* tile = lds;
+    float4v* sbuf = reinterpret_cast<float4v*>(lds + kMlaTileBytes);  // [HT][4 waves][2 halves][64 lanes]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int hl = lane & 15, g = lane >> 4;
+    // Q^T operand of this wave's k-steps wid, wid + 4, ...: lane (hl, g) holds q[column][32*ks + 8*g .. +8)
+    constexpr int kSteps = kMlaD / 32;  // 18
+    short8 qf[HT][5];
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int ks = wid + 4 * i;
+        if (qrow[t] && ks < kSteps)
+          qf[t][i] = *reinterpret_cast<const short8*>(qrow[t] + 32 * ks + 8 * g);
+        else
+          qf[t][i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
+      }
+    }
+    const float LOG2E = 1.4426950408889634f;
+    const float qk_scale = CAP ? sm_scale : sm_scale * LOG2E;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) {
+      m[t] = -INFINITY, lsum[t] = 0.f;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) oacc[t][n] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // tile fetch: eight threads per row, thread (row, sub) takes 16-byte pieces sub, sub + 8, ..., sub + 64
+    const int frow = threadIdx.x >> 3, fsub = threadIdx.x & 7;
+    // FD tiles are in flight (registers) while one is multiplied (two measured no faster than one, with or without
+    // the slots read ahead: the step is not bound by the way to the rows and back)
+    constexpr int FD = 1;
+    int4v kreg[FD][9];
+    // a row's slot is read one tile before its bytes are requested (slot and bytes are two dependent trips to memory)
+    auto slot_of = [&](int t0) {
+      int tok = t0 + frow;
+      tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
+      return idx[tok];
+    };
+    auto fetch = [&](int4v(&kr)[9], int slot) {
+      const uint16_t* row = kbase + (int64_t)slot * k_stride_n + fsub * 8;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) kr[j] = *reinterpret_cast<const int4v*>(row + 64 * j);
+    };
+    int slot_next = 0;
+    auto park = [&](const int4v(&kr)[9]) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) *reinterpret_cast<int4v*>(tile + frow * kMlaPitch + (fsub + 8 * j) * 16) = kr[j];
+    };
+
+    auto step = [&](int4v(&kr)[9], int t0) {
+      __syncthreads();  // every wave is done with the previous tile
+      park(kr);
+      __syncthreads();
+      if (t0 + FD * kTile < s1) {  // later tiles' rows fly while this one is multiplied
+        fetch(kr, slot_next);
+        slot_next = slot_of(t0 + (FD + 1) * kTile);
+      }
+      // ---- this wave's share of S^T = K . Q^T: a K operand read serves every column tile
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float4v sacc[HT];
+#pragma unroll
+        for (int t = 0; t < HT; ++t) sacc[t] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          // k-steps past the row (waves 2 and 3 in their fifth round) multiply the row's last step by the zeros their
+          // q registers hold there: no branch in the tile loop
+          const int ks = min(wid + 4 * i, kSteps - 1);
+          const short8 kf = *reinterpret_cast<const short8*>(tile + (16 * hh + hl) * kMlaPitch + (4 * ks + g) * 16);
+#pragma unroll
+          for (int t = 0; t < HT; ++t) sacc[t] = Mfma16<T>::mma(kf, qf[t][i], sacc[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < HT; ++t) sbuf[((t * 4 + wid) * 2 + hh) * 64 + lane] = sacc[t];
+      }
+      __syncthreads();
+      // ---- full scores (same sum order in every wave), scale / cap / mask, online softmax (exp2 domain)
+      short8 pf[HT];  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        float sv[8];
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          float4v tot = sbuf[((t * 4) * 2 + hh) * 64 + lane];
+#pragma unroll
+          for (int w = 1; w < 4; ++w) tot += sbuf[((t * 4 + w) * 2 + hh) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sc = tot[r] * qk_scale;
+            if constexpr (CAP) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
+            const int tok = t0 + 16 * hh + 4 * g + r;
+            sc = tok < s1 ? sc : -INFINITY;
+            sv[hh * 4 + r] = sc;
+            tmax = fmaxf(tmax, sc);
+          }
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m[t], tmax);  // finite: token t0 of this tile is always valid
+        const float alpha = exp2f(m[t] - m_new);
+        m[t] = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float p = exp2f(sv[j] - m_new);
+          psum += p;
+          pf[t][j] = (short)Conv<T>::from_f32(p);
+        }
+        lsum[t] = lsum[t] * alpha + psum;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) oacc[t][n] *= alpha;
+      }
+      // ---- O^T += V^T . P^T over this wave's 128 output elements, V read transposed out of the K rows
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int byte_in_row = 256 * wid + 32 * n + 8 * (hl & 3);
+        const short4v lo = lds_read_tr16(tile + (4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
+        const short4v hi = lds_read_tr16(tile + (16 + 4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
+        const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int t = 0; t < HT; ++t) oacc[t][n] = Mfma16<T>::mma(vf, pf[t], oacc[t][n]);
+      }
+    };
+
+#pragma unroll
+    for (int f = 0; f < FD; ++f)
+      if (s0 + f * kTile < s1) fetch(kreg[f], slot_of(s0 + f * kTile));
+    slot_next = slot_of(s0 + FD * kTile);
+    for (int t0 = s0; t0 < s1; t0 += FD * kTile) {
+#pragma unroll
+      for (int f = 0; f < FD; ++f)
+        if (t0 + f * kTile < s1) step(kreg[f], t0 + f * kTile);  // block-uniform
+    }
+  }
+
+  // tile t's partial (normalised O[512] + log-sum-exp) into row `ob` of [rows][512] / [rows]
+  __device__ __forceinline__ void store(int t, bool ok, int64_t ob, float* __restrict__ logits, float* __restrict__ lse) const {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    float ls = lsum[t];
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    if (ok) {
+      const float inv = 1.0f / ls;
+      float* dst = logits + ob * kMlaDv + 128 * wid;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[t][n] * inv;
+      if (wid == 0 && g == 0) lse[ob] = (m[t] + log2f(ls)) * 0.6931471805599453f;
+    }
+  }
+};
+
 template <typename T, int HT, bool CAP>
 __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
     const void* __restrict__ q, const void* __restrict__ kv_buffer, const int32_t* __restrict__ kv_indptr,
     const int32_t* __restrict__ kv_indices, float* __restrict__ attn_logits, float* __restrict__ attn_lse,
     const int32_t* __restrict__ num_kv_splits, int max_kv_splits, int Hq, int Hkv, int head_tiles, int64_t q_stride_b,
-    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, float sm_scale, float logit_cap) {
+    int64_t q_stride_h, int64_t k_stride_n, int64_t k_stride_h, float sm_scale, float logit_cap,
+    const int32_t* __restrict__ gate = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* tile = lds;
-  float4v* sbuf = reinterpret_cast<float4v*>(lds + kMlaTileBytes);  // [HT][4 waves][2 halves][64 lanes]
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int hl = lane & 15, g = lane >> 4;
+  if (gate && *gate != 0) return;  // see decode_stage1_mfma128
+  const int lane = threadIdx.x & 63;
+  const int hl = lane & 15;
   const int b = blockIdx.x;
   const int kvh = blockIdx.y / head_tiles, ht = blockIdx.y - kvh * head_tiles;
   const int split = blockIdx.z;
@@ -511,164 +678,21 @@ __global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) decode_stage1_mla(
   if (s1 <= s0) return;  // block-uniform
   bool head_ok[HT];
   int head[HT];
+  const uint16_t* qrow[HT];
 #pragma unroll
   for (int t = 0; t < HT; ++t) {
     const int head_in_group = (ht * HT + t) * 16 + hl;
     head_ok[t] = head_in_group < group;
     head[t] = kvh * group + head_in_group;
+    qrow[t] = head_ok[t] ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head[t] * q_stride_h
+                         : nullptr;
   }
-
-  // Q^T operand of this wave's k-steps wid, wid + 4, ...: lane (hl, g) holds q[head][32*ks + 8*g .. +8)
-  constexpr int kSteps = kMlaD / 32;  // 18
-  short8 qf[HT][5];
+  MlaRun<T, HT, CAP> r;
+  r.run(lds, qrow, reinterpret_cast<const uint16_t*>(kv_buffer) + (int64_t)kvh * k_stride_h, k_stride_n,
+        kv_indices + start, s0, s1, sm_scale, logit_cap);
 #pragma unroll
-  for (int t = 0; t < HT; ++t) {
-    const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head[t] * q_stride_h;
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int ks = wid + 4 * i;
-      if (head_ok[t] && ks < kSteps)
-        qf[t][i] = *reinterpret_cast<const short8*>(qp + 32 * ks + 8 * g);
-      else
-        qf[t][i] = short8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-  }
-  const float LOG2E = 1.4426950408889634f;
-  const float qk_scale = CAP ? sm_scale : sm_scale * LOG2E;
-  float m[HT], lsum[HT];
-  float4v oacc[HT][8];
-#pragma unroll
-  for (int t = 0; t < HT; ++t) {
-    m[t] = -INFINITY, lsum[t] = 0.f;
-#pragma unroll
-    for (int n = 0; n < 8; ++n) oacc[t][n] = float4v{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // tile fetch: eight threads per row, thread (row, sub) takes 16-byte pieces sub, sub + 8, ..., sub + 64
-  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(kv_buffer) + (int64_t)kvh * k_stride_h;
-  const int32_t* idx = kv_indices + start;
-  const int frow = threadIdx.x >> 3, fsub = threadIdx.x & 7;
-  // FD tiles are in flight (registers) while one is multiplied (two measured no faster than one, with or without
-  // the slots read ahead: the step is not bound by the way to the rows and back)
-  constexpr int FD = 1;
-  int4v kreg[FD][9];
-  // a row's slot is read one tile before its bytes are requested (slot and bytes are two dependent trips to memory)
-  auto slot_of = [&](int t0) {
-    int tok = t0 + frow;
-    tok = tok < s1 ? tok : s0;  // rows past the end re-read a valid slot; their scores are masked
-    return idx[tok];
-  };
-  auto fetch = [&](int4v(&kr)[9], int slot) {
-    const uint16_t* row = kbase + (int64_t)slot * k_stride_n + fsub * 8;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) kr[j] = *reinterpret_cast<const int4v*>(row + 64 * j);
-  };
-  int slot_next = 0;
-  auto park = [&](const int4v(&kr)[9]) {
-#pragma unroll
-    for (int j = 0; j < 9; ++j) *reinterpret_cast<int4v*>(tile + frow * kMlaPitch + (fsub + 8 * j) * 16) = kr[j];
-  };
-
-  auto step = [&](int4v(&kr)[9], int t0) {
-    __syncthreads();  // every wave is done with the previous tile
-    park(kr);
-    __syncthreads();
-    if (t0 + FD * kTile < s1) {  // later tiles' rows fly while this one is multiplied
-      fetch(kr, slot_next);
-      slot_next = slot_of(t0 + (FD + 1) * kTile);
-    }
-    // ---- this wave's share of S^T = K . Q^T: a K operand read serves every head tile
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float4v sacc[HT];
-#pragma unroll
-      for (int t = 0; t < HT; ++t) sacc[t] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        // k-steps past the row (waves 2 and 3 in their fifth round) multiply the row's last step by the zeros their
-        // q registers hold there: no branch in the tile loop
-        const int ks = min(wid + 4 * i, kSteps - 1);
-        const short8 kf = *reinterpret_cast<const short8*>(tile + (16 * hh + hl) * kMlaPitch + (4 * ks + g) * 16);
-#pragma unroll
-        for (int t = 0; t < HT; ++t) sacc[t] = Mfma16<T>::mma(kf, qf[t][i], sacc[t]);
-      }
-#pragma unroll
-      for (int t = 0; t < HT; ++t) sbuf[((t * 4 + wid) * 2 + hh) * 64 + lane] = sacc[t];
-    }
-    __syncthreads();
-    // ---- full scores (same sum order in every wave), scale / cap / mask, online softmax (exp2 domain)
-    short8 pf[HT];  // P^T operand: k-slot j <-> token (j < 4 ? 4g + j : 16 + 4g + j - 4), as the S^T registers stand
-#pragma unroll
-    for (int t = 0; t < HT; ++t) {
-      float sv[8];
-      float tmax = -INFINITY;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        float4v tot = sbuf[((t * 4) * 2 + hh) * 64 + lane];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) tot += sbuf[((t * 4 + w) * 2 + hh) * 64 + lane];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sc = tot[r] * qk_scale;
-          if constexpr (CAP) sc = logit_cap * tanhf(sc / logit_cap) * LOG2E;
-          const int tok = t0 + 16 * hh + 4 * g + r;
-          sc = tok < s1 ? sc : -INFINITY;
-          sv[hh * 4 + r] = sc;
-          tmax = fmaxf(tmax, sc);
-        }
-      }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m[t], tmax);  // finite: token t0 of this tile is always valid
-      const float alpha = exp2f(m[t] - m_new);
-      m[t] = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float p = exp2f(sv[j] - m_new);
-        psum += p;
-        pf[t][j] = (short)Conv<T>::from_f32(p);
-      }
-      lsum[t] = lsum[t] * alpha + psum;
-#pragma unroll
-      for (int n = 0; n < 8; ++n) oacc[t][n] *= alpha;
-    }
-    // ---- O^T += V^T . P^T over this wave's 128 output elements, V read transposed out of the K rows
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const int byte_in_row = 256 * wid + 32 * n + 8 * (hl & 3);
-      const short4v lo = lds_read_tr16(tile + (4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
-      const short4v hi = lds_read_tr16(tile + (16 + 4 * g + (hl >> 2)) * kMlaPitch + byte_in_row);
-      const short8 vf = short8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-      for (int t = 0; t < HT; ++t) oacc[t][n] = Mfma16<T>::mma(vf, pf[t], oacc[t][n]);
-    }
-  };
-
-#pragma unroll
-  for (int f = 0; f < FD; ++f)
-    if (s0 + f * kTile < s1) fetch(kreg[f], slot_of(s0 + f * kTile));
-  slot_next = slot_of(s0 + FD * kTile);
-  for (int t0 = s0; t0 < s1; t0 += FD * kTile) {
-#pragma unroll
-    for (int f = 0; f < FD; ++f)
-      if (t0 + f * kTile < s1) step(kreg[f], t0 + f * kTile);  // block-uniform
-  }
-
-#pragma unroll
-  for (int t = 0; t < HT; ++t) {
-    float ls = lsum[t];
-    ls += __shfl_xor(ls, 16, 64);
-    ls += __shfl_xor(ls, 32, 64);
-    if (head_ok[t]) {
-      const float inv = 1.0f / ls;
-      const int64_t ob = ((int64_t)b * Hq + head[t]) * max_kv_splits + split;
-      float* dst = attn_logits + ob * kMlaDv + 128 * wid;
-#pragma unroll
-      for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(dst + 16 * n + 4 * g) = oacc[t][n] * inv;
-      if (wid == 0 && g == 0) attn_lse[ob] = (m[t] + log2f(ls)) * 0.6931471805599453f;
-    }
-  }
+  for (int t = 0; t < HT; ++t)
+    r.store(t, head_ok[t], ((int64_t)b * Hq + head[t]) * max_kv_splits + split, attn_logits, attn_lse);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1518,6 +1542,127 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Shared-prefix decode for absorbed MLA (latent rows of 576, values = their first 512 elements), driven by the same
+// per-step plan, in two launches:
+//   mla_shared_stage1  prefix blocks: half an item's 64 (request, head) columns -- two tiles of 16 -- against the
+//                      item's slice of the group's shared rows, which are fetched once per 32 columns whatever
+//                      request they belong to (the per-request kernel fetches them once per request and head tile);
+//                      tail blocks: (request, head tile, split w < 4) over the request's private remainder.
+//                      Partials go to rows [(b * Hq + head) * slots + s], s = prefix split, or prefix_splits + w.
+//   mla_shared_merge   one block per (request, head): the partials of its live slots, in slot order.
+// No block waits for another: the second launch is the hand-over.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kMlaTailSplits = 4;
+
+template <typename T, int HT, bool CAP>
+__global__ void __launch_bounds__(256, HT == 1 ? 3 : 2) mla_shared_stage1(
+    const void* __restrict__ q, const void* __restrict__ kv_buffer, const int32_t* __restrict__ kv_indices,
+    const int32_t* __restrict__ plan_hdr, const int32_t* __restrict__ plan_tail, const int32_t* __restrict__ plan_items,
+    float* __restrict__ logits, float* __restrict__ lse, int* __restrict__ error, int prefix_splits, int n_prefix_blocks,
+    int B, int Hq, int head_tiles, int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_n, float sm_scale,
+    float logit_cap, int gated) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63;
+  const int hl = lane & 15;
+  const int heads = Hq;  // one latent "kv head"
+  const int slots = prefix_splits + kMlaTailSplits;
+  if (plan_hdr[kPlanHeads] != heads || plan_hdr[kPlanSplits] != prefix_splits || plan_hdr[kPlanB] != B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;  // the merge sees the same words and writes NaN
+  }
+  const int n_items = plan_hdr[kPlanNItems];
+  if (gated && n_items == 0) return;  // nobody shares anything: the per-request kernels launched beside this one run
+  const uint16_t* kbase = reinterpret_cast<const uint16_t*>(kv_buffer);
+  constexpr int kColsPerBlock = 16 * HT;          // 64 columns of an item over 64 / kColsPerBlock blocks
+  constexpr int kParts = 64 / kColsPerBlock;
+  MlaRun<T, HT, CAP> r;
+  if ((int)blockIdx.x < n_prefix_blocks) {
+    const int part = blockIdx.x % kParts;
+    const int items_per_round = n_prefix_blocks / kParts;
+    for (int j = blockIdx.x / kParts; j < n_items; j += items_per_round) {  // block-uniform
+      const int32_t* it = plan_items + (int64_t)j * kPlanItemInts;
+      const int list_off = it[0], t0 = it[1], t1 = it[2], cb = it[3], split = it[4];
+      const uint16_t* qrow[HT];
+      int req[HT], head[HT];
+#pragma unroll
+      for (int t = 0; t < HT; ++t) {
+        const int c = part * kColsPerBlock + 16 * t + hl;
+        req[t] = it[16 + c];
+        head[t] = (cb * 64 + c) % heads;
+        qrow[t] = req[t] >= 0 ? reinterpret_cast<const uint16_t*>(q) + (int64_t)req[t] * q_stride_b + (int64_t)head[t] * q_stride_h
+                              : nullptr;
+      }
+      // a part of the item without a live column has nothing to do (the last item of a group)
+      const int first = it[16 + part * kColsPerBlock];  // owners are sorted: dead columns come last
+      if (first < 0 || t1 <= t0) continue;              // block-uniform
+      r.run(lds, qrow, kbase, k_stride_n, kv_indices + list_off, t0, t1, sm_scale, logit_cap);
+#pragma unroll
+      for (int t = 0; t < HT; ++t)
+        r.store(t, req[t] >= 0, ((int64_t)req[t] * Hq + head[t]) * slots + split, logits, lse);
+      __syncthreads();  // the next item's first tile is parked over this one's
+    }
+    return;
+  }
+  int i = blockIdx.x - n_prefix_blocks;
+  const int w = i % kMlaTailSplits;
+  i /= kMlaTailSplits;
+  const int ht = i % head_tiles, b = i / head_tiles;
+  const int4v rec = *reinterpret_cast<const int4v*>(plan_tail + 4 * (int64_t)b);
+  const int start = rec[0], len = rec[1];
+  const int splits = tail_splits(len, kMlaTailSplits);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int s0 = per_split * w, s1 = min(s0 + per_split, len);
+  if (w >= splits || s1 <= s0) return;  // block-uniform
+  const uint16_t* qrow[HT];
+  bool ok[HT];
+  int head[HT];
+#pragma unroll
+  for (int t = 0; t < HT; ++t) {
+    head[t] = (ht * HT + t) * 16 + hl;
+    ok[t] = head[t] < heads;
+    qrow[t] = ok[t] ? reinterpret_cast<const uint16_t*>(q) + (int64_t)b * q_stride_b + (int64_t)head[t] * q_stride_h : nullptr;
+  }
+  r.run(lds, qrow, kbase, k_stride_n, kv_indices + start, s0, s1, sm_scale, logit_cap);
+#pragma unroll
+  for (int t = 0; t < HT; ++t) r.store(t, ok[t], ((int64_t)b * Hq + head[t]) * slots + prefix_splits + w, logits, lse);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(128) mla_shared_merge(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                        void* __restrict__ o, const int32_t* __restrict__ plan_hdr,
+                                                        const int32_t* __restrict__ plan_tail, int prefix_splits, int B,
+                                                        int Hq, int64_t o_stride_b, int64_t o_stride_h, int gated) {
+  const int b = blockIdx.x, h = blockIdx.y;
+  const bool bad = plan_hdr[kPlanHeads] != Hq || plan_hdr[kPlanSplits] != prefix_splits || plan_hdr[kPlanB] != B;
+  if (!bad && gated && plan_hdr[kPlanNItems] == 0) return;
+  const int4v rec = *reinterpret_cast<const int4v*>(plan_tail + 4 * (int64_t)b);
+  const int len = rec[1], aps = rec[3];
+  const int splits = tail_splits(len, kMlaTailSplits);
+  const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
+  const int slots = prefix_splits + kMlaTailSplits;
+  const int64_t base = ((int64_t)b * Hq + h) * slots;
+  const int d = 4 * threadIdx.x;  // 128 threads x 4 elements = 512
+  float e_sum = 0.f, e_max = -INFINITY;
+  float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < slots; ++s) {
+    const bool live = s < prefix_splits ? s < aps : (s - prefix_splits < splits && per_split * (s - prefix_splits) < len);
+    if (live) {
+      const float4v tv = *reinterpret_cast<const float4v*>(logits + (base + s) * kMlaDv + d);
+      const float tl = lse[base + s];
+      const float n_max = fmaxf(tl, e_max);
+      const float old = expf(e_max - n_max), wgt = expf(tl - n_max);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fmaf(wgt, tv[r], acc[r] * old);
+      e_sum = fmaf(e_sum, old, wgt);
+      e_max = n_max;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    st<T>(o, (int64_t)b * o_stride_b + (int64_t)h * o_stride_h + d + r, bad ? __builtin_nanf("") : acc[r] / e_sum);
+}
+
 }  // namespace sglk
 
 using namespace sglk;
@@ -1632,7 +1777,7 @@ static int decode_attention_impl(const void* q, const void* k_buffer, const void
   const bool fast8 = kvf != 0 && D == 128 && Dv == 128 && aligned16(q) && al8(k_buffer) && al8(v_buffer) &&
                      aligned16(attn_logits) && (q_stride_b % 8 == 0) && (q_stride_h % 8 == 0) && (k_stride_n % 8 == 0) &&
                      (k_stride_h % 8 == 0) && (v_stride_n % 8 == 0) && (v_stride_h % 8 == 0);
-  SGLK_CHECK(!gate || fast || fast8 || pair64, "decode_attention: a gated launch needs one of the tile kernels");
+  SGLK_CHECK(!gate || fast || fast8 || pair64 || mla, "decode_attention: a gated launch needs one of the tile kernels");
   if (fast8) {
     const int head_tiles = (group + 15) / 16;
     dim3 grid(B, Hkv * head_tiles, (max_kv_splits + kWavesPerBlock - 1) / kWavesPerBlock);
@@ -1652,7 +1797,7 @@ static int decode_attention_impl(const void* q, const void* k_buffer, const void
 #define SGLK_MLA_LAUNCH(HT, CAP)                                                                                         \
   hipLaunchKernelGGL((decode_stage1_mla<T, HT, CAP>), grid, dim3(256), kMlaTileBytes + HT * kMlaScoreBytes, s, q, k_buffer, \
                      kv_indptr, kv_indices, attn_logits, attn_lse, num_kv_splits, max_kv_splits, Hq, Hkv, head_tiles,      \
-                     q_stride_b, q_stride_h, k_stride_n, k_stride_h, sm_scale, logit_cap)
+                     q_stride_b, q_stride_h, k_stride_n, k_stride_h, sm_scale, logit_cap, gate)
       SGLK_DISPATCH_HALF(dtype, T, {
         if (logit_cap > 0.f)
           SGLK_MLA_LAUNCH(2, true);
@@ -1763,6 +1908,7 @@ int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_spl
   // the per-request kernels).  The one-launch kernel keeps partial rows of 128 floats whatever the head size (head
   // size 64 runs on pairs of kv heads, 128 wide).
   Dv = std::max(Dv, 128);
+  if (Dv == kMlaDv) max_kv_splits += kMlaTailSplits;  // the absorbed-MLA form keeps the remainders' partials there too
   return shared_counter_bytes(B, Hq) + (int64_t)B * Hq * max_kv_splits * (Dv + 1) * (int64_t)sizeof(float) +
          (((int64_t)B * 4 + 255) / 256) * 256;
 }
@@ -1821,8 +1967,45 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
   const bool pair64 = plain_planned && kvf == 0 && D == 64 && Dv == 64 && Hkv % 2 == 0 && k_stride_h == 64 &&
                       v_stride_h == 64 && aligned16(k_buffer) && aligned16(v_buffer) && !xsum_out;
   hipStream_t s = (hipStream_t)stream;
+  // absorbed MLA (one latent kv head, values a view of the key rows): the plan's items through the MLA tile kernel
+  const bool mla = plain_planned && kvf == 0 && D == kMlaD && Dv == kMlaDv && Hkv == 1 && v_buffer == k_buffer &&
+                   v_stride_n == k_stride_n && aligned16(k_buffer) && !xsum_out;
+  if (mla) {
+    SGLK_CHECK(B <= kPlanMaxB, "decode_attention_shared_prefix: a plan covers at most %d requests", kPlanMaxB);
+    SGLK_CHECK(aligned16(plan), "decode_attention_shared_prefix: plan must be 16-byte aligned");
+    const int heads = Hq;
+    const int splits = shared_prefix_splits(B, heads, 1, max_kv_splits);
+    const int slots = splits + kMlaTailSplits;
+    const int col_blocks = (B * heads + 63) / 64;
+    constexpr int HT = 2;
+    const int n_prefix = (64 / (16 * HT)) * splits * col_blocks;
+    const int head_tiles = (heads + 16 * HT - 1) / (16 * HT);
+    const int n_tail = B * head_tiles * kMlaTailSplits;
+    const PlanView pv = plan_view(const_cast<int32_t*>(plan), B, plan_max_items(B, heads, splits));
+    int* error = reinterpret_cast<int*>(workspace) + (int64_t)B * Hq;
+    float* logits = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
+    float* lse = logits + (int64_t)B * Hq * slots * kMlaDv;
+    const size_t lds = kMlaTileBytes + HT * kMlaScoreBytes;
+#define SGLK_MLA_SHARED(CAP)                                                                                            \
+  hipLaunchKernelGGL((mla_shared_stage1<T, HT, CAP>), dim3(n_prefix + n_tail), dim3(256), lds, s, q, k_buffer, kv_indices, \
+                     pv.hdr, pv.tail, pv.items, logits, lse, error, splits, n_prefix, B, Hq, head_tiles, q_stride_b,       \
+                     q_stride_h, k_stride_n, sm_scale, logit_cap, gated ? 1 : 0)
+    SGLK_DISPATCH_HALF(qdtype, T, {
+      if (logit_cap > 0.f)
+        SGLK_MLA_SHARED(true);
+      else
+        SGLK_MLA_SHARED(false);
+    });
+#undef SGLK_MLA_SHARED
+    SGLK_LAUNCH_CHECK();
+    SGLK_DISPATCH_HALF(qdtype, T,
+                       hipLaunchKernelGGL((mla_shared_merge<T>), dim3(B, Hq), dim3(128), 0, s, logits, lse, o, pv.hdr, pv.tail,
+                                          splits, B, Hq, o_stride_b, o_stride_h, gated ? 1 : 0));
+    SGLK_LAUNCH_CHECK();
+    return SGLK_OK;
+  }
   if (!fast && !fast8 && !pair64) {
-    // Other shapes (absorbed MLA 576 / 512, fp32, layouts the tile kernels do not take, and everything but the plain
+    // Other shapes (fp32, absorbed MLA without a plan, layouts the tile kernels do not take, and everything but the plain
     // planned form for fp8 pools and head size 64): the same result from the per-request kernels over the same
     // lists, with the groups ignored: a group's shared rows are then fetched once per request, from L2 after the
     // first.  The workspace holds their partials ([B, Hq, S, Dv] + [B, Hq, S]) and one split count per request.
@@ -2090,8 +2273,10 @@ int sglk_decode_attention_shared_planned(const void* q, const void* k_buffer, co
     const int kvf = dtype >> SGLK_KV_SHIFT;
     const int qd = dtype & ((1 << SGLK_KV_SHIFT) - 1);
     const bool tile = (qd == SGLK_F16 || qd == SGLK_BF16) &&
-                      ((D == 128 && Dv == 128) || (kvf == 0 && D == 64 && Dv == 64 && Hkv % 2 == 0 && k_stride_h == 64 &&
-                                                   v_stride_h == 64 && !xsum_out));
+                      ((D == 128 && Dv == 128) ||
+                       (kvf == 0 && D == 64 && Dv == 64 && Hkv % 2 == 0 && k_stride_h == 64 && v_stride_h == 64 && !xsum_out) ||
+                       (kvf == 0 && D == kMlaD && Dv == kMlaDv && Hkv == 1 && v_buffer == k_buffer && v_stride_n == k_stride_n &&
+                        !xsum_out));
     if (tile) {
       SGLK_CHECK(workspace, "decode_attention_shared_planned: null pointer");
       float* logits = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));

@@ -466,6 +466,53 @@ def test_shared_prefix_planned_head_size_64(dtype, groups, Hq, Hkv, max_splits):
     assert torch.equal(o_g, o)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("groups,Hq,max_splits,cap", [
+    ([(6, 130, 1, 50), (1, 0, 3, 9), (5, 64, 1, 200)], 16, 8, 0.0),     # a TP = 8 rank's 16 heads
+    ([(3, 70, 1, 40), (2, 33, 0, 0)], 128, 4, 0.0),                      # all 128 heads: eight tiles per request
+    ([(9, 96, 1, 20)], 8, 4, 30.0),                                      # fewer heads than a tile; logit cap
+    ([(2, 40, 1, 9)] * 19, 16, 8, 0.0),                                  # many small groups: items over several rounds
+])
+def test_shared_prefix_planned_absorbed_mla(dtype, groups, Hq, max_splits, cap):
+    """Absorbed MLA (latent rows of 576, values = their first 512 elements) through the plan: a group's shared rows
+    are multiplied once per 32 (request, head) columns, whatever request the columns belong to.  Against the oracle,
+    against the per-request kernels, and with those launched beside it (the form the backend uses)."""
+    import oracle
+
+    ops = _ops()
+    D, Dv = 576, 512
+    q, kb, _, ptr, ind, gi, pls = _group_batch_d(groups, Hq, 1, D, dtype, seed=Hq + len(groups))
+    q = (q.float() * 0.5).to(dtype)
+    B = q.shape[0]
+    sm = 1.0 / math.sqrt(192)
+    want = oracle.decode_attention(q, kb, kb[..., :Dv].contiguous(), ptr, ind, torch.ones(B, dtype=torch.int32), sm, cap)
+    kd = kb.to(DEV)
+    vd = kd[..., :Dv]
+    plan = ops.decode_shared_plan_buffer(B, Hq, 1, max_splits, DEV)
+    ops.decode_shared_plan_from_groups(ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV), B, Hq, 1, max_splits, plan)
+    assert ops.decode_shared_plan_read(plan, B)["n_items"] > 0
+    ws = ops.decode_shared_workspace(B, Hq, Dv, max_splits, DEV)
+    ns = torch.full((B,), max_splits, dtype=torch.int32, device=DEV)
+    outs = []
+    for gate in (None, ns, None):
+        o = torch.full((B, Hq, Dv), float("nan"), dtype=dtype, device=DEV)
+        ops.decode_attention_shared_planned(q.to(DEV), kd, vd, o, ptr.to(DEV), ind.to(DEV), plan, ws, max_splits, sm, cap,
+                                            None, gate)
+        torch.cuda.synchronize()
+        assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    o = outs[0].float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o).all()
+    assert (o - want.float()).abs().max().item() < tol
+    o2 = torch.empty(B, Hq, Dv, dtype=dtype, device=DEV)
+    al = torch.empty(B, Hq, max_splits, Dv, dtype=torch.float32, device=DEV)
+    lse = torch.empty(B, Hq, max_splits, dtype=torch.float32, device=DEV)
+    ops.decode_attention_fwd(q.to(DEV), kd, vd, o2, ptr.to(DEV), ind.to(DEV), al, lse, ns, max_splits, sm, cap)
+    assert (o - o2.float().cpu()).abs().max().item() < tol
+
+
 def test_shared_prefix_planned_rejects_a_plan_of_another_geometry():
     """A plan laid out for other heads per kv head must not be walked: NaN rows and the workspace's error word, not a
     wrong answer (here: a head-size-64 launch on a plan that counts single kv heads)."""

@@ -488,6 +488,57 @@ def test_mla_pool_and_decode():
     assert (o.float().cpu() - want).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("share", [None, True])
+def test_backend_mla_decode_shared_prefix(share):
+    """The backend over an MLA latent pool: left to itself it keeps absorbed MLA on the per-request kernels (the
+    plan-driven form measured slower), share_prefix=True routes the batch through the plan; both against the oracle."""
+    import oracle
+    from sglang_security_amd import ops
+    from sglang_security_amd.attention import SglkAttnBackend
+    from sglang_security_amd.mem_cache.memory_pool import MLATokenToKVPool, ReqToTokenPool
+
+    Hq, B, P = 16, 5, 70
+    r2t = ReqToTokenPool(8, 512, DEV)
+    pool = MLATokenToKVPool(1024, 1, torch.bfloat16, 512, 64, 1, DEV)
+    g = torch.Generator().manual_seed(8)
+    kb = pool.get_key_buffer(0)
+    kb.copy_((torch.randn(kb.shape, generator=g) * 0.5).to(torch.bfloat16))
+    lens, nxt = [], 1 + P
+    for b in range(B):
+        t = 3 + 11 * b
+        r2t.req_to_token[b, :P] = torch.arange(1, 1 + P, dtype=torch.int32)
+        r2t.req_to_token[b, P:P + t] = torch.arange(nxt, nxt + t, dtype=torch.int32)
+        nxt += t
+        lens.append(P + t)
+    cfg = types.SimpleNamespace(num_attention_heads=Hq, head_dim=576, v_head_dim=512, get_num_kv_heads=lambda tp: 1)
+    mr = types.SimpleNamespace(device=DEV, req_to_token_pool=r2t, token_to_kv_pool=pool, model_config=cfg, tp_size=1,
+                               server_args=types.SimpleNamespace(triton_attention_num_kv_splits=8))
+    seq_lens = torch.tensor(lens, device=DEV)
+    fb = types.SimpleNamespace(forward_mode=_Mode(True), batch_size=B, req_pool_indices=torch.arange(B, device=DEV),
+                               seq_lens=seq_lens, seq_lens_sum=sum(lens), out_cache_loc=None, token_to_kv_pool=pool)
+    be = SglkAttnBackend(mr, share_prefix=share)
+    be.init_forward_metadata(fb)
+    md = be.forward_metadata
+    assert (md.shared_plan is not None) == (share is True)
+    if share:
+        view = ops.decode_shared_plan_read(md.shared_plan, B)
+        assert view["prefix_lens"] == [P] and view["n_items"] > 0
+    layer = types.SimpleNamespace(layer_id=0, tp_q_head_num=Hq, tp_k_head_num=1, tp_v_head_num=1, qk_head_dim=576,
+                                  v_head_dim=512, scaling=1.0 / math.sqrt(192), logit_cap=0.0)
+    q = (torch.randn(B, Hq * 576, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+    o = be.forward(q, None, None, layer, fb, save_kv_cache=False)
+    torch.cuda.synchronize()
+    ptr = torch.zeros(B + 1, dtype=torch.int32)
+    ptr[1:] = torch.cumsum(torch.tensor(lens), 0)
+    ind = torch.cat([r2t.req_to_token[b, : lens[b]].cpu() for b in range(B)])
+    kc = kb.cpu()
+    want = oracle.decode_attention(q.cpu().view(B, Hq, 576), kc, kc[..., :512].contiguous(), ptr, ind,
+                                   torch.ones(B, dtype=torch.int32), layer.scaling)
+    assert (o.float().cpu().view(B, Hq, 512) - want.float()).abs().max().item() < 2e-2
+    if share:
+        assert ops.decode_shared_workspace_status(md.shared_workspace, B, Hq) == 0
+
+
 class _SpecMode:
     def __init__(self, name):
         self._n = name

@@ -18,6 +18,7 @@ ap.add_argument("--splits", type=int, default=8)
 ap.add_argument("--pools", type=int, default=4)
 ap.add_argument("--iters", type=int, default=32)
 ap.add_argument("--generic", action="store_true", help="separate value copy: the generic kernel")
+ap.add_argument("--prefix", type=int, default=0, help="the first PREFIX tokens of every request are the same pool rows")
 args = ap.parse_args()
 dev = "cuda"
 B, Hq, L = args.batch, args.heads, args.ctx
@@ -28,6 +29,10 @@ vals = [p[..., :512].contiguous() if args.generic else p[..., :512] for p in poo
 q = torch.randn(B, Hq, 576, device=dev, generator=gen).to(torch.bfloat16)
 o = torch.empty(B, Hq, 512, dtype=torch.bfloat16, device=dev)
 ind = (torch.randperm(ntok - 1, device=dev, generator=gen)[:B * L] + 1).to(torch.int32)
+if args.prefix:
+    ind = ind.view(B, L)
+    ind[:, :args.prefix] = ind[0, :args.prefix].clone()
+    ind = ind.reshape(-1).contiguous()
 ptr = (torch.arange(B + 1, dtype=torch.int32) * L).to(dev)
 ns = torch.zeros(B, dtype=torch.int32, device=dev)
 ops.get_num_kv_splits(ns, torch.full((B,), L, device=dev), Hq, 1, args.splits, 256)
