@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <cstddef>
 #include <mutex>
 #include <vector>
 
@@ -48,6 +49,10 @@ struct Signal {
   alignas(128) uint32_t stuck[kMaxBlocks];                 // non-zero: a wait of this block timed out
   alignas(128) uint32_t failed;                            // sticky: some wait on this rank timed out
 };
+
+// distributed/custom_all_reduce.py (stuck_detail) reads these words through the meta buffer after a time-out
+static_assert(offsetof(Signal, slot) == 256 && offsetof(Signal, stuck) == 4352 && offsetof(Signal, failed) == 4608,
+              "Signal layout is read by the Python diagnostics");
 
 struct Watch {
   uint32_t* host_flag;  // host-pinned word, device address
