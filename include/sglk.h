@@ -120,10 +120,11 @@ SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const vo
  * are counters: they must be ZERO when the workspace is first used (sglk_decode_shared_workspace_init clears
  * them; a zero-filled allocation does too) and every call leaves them zero.  Calls that overlap in time need
  * workspaces of their own.
- * The one-launch kernel covers 16-bit types with head size 128.  Every other shape sglk_decode_attention accepts
- * (absorbed MLA 576 / 512 with the values a view of the key rows, head size 64, fp32) is routed to the per-request
- * kernels over the same lists with max_kv_splits splits per request, their partials in the workspace: the same result,
- * a group's shared rows fetched once per request (from L2 after the first). */
+ * The one-launch kernel of the group-array entry points covers 16-bit types with head size 128.  Every other shape
+ * sglk_decode_attention accepts (absorbed MLA 576 / 512 with the values a view of the key rows, head size 64, fp8
+ * pools, fp32) is routed there to the per-request kernels over the same lists with max_kv_splits splits per request,
+ * their partials in the workspace: the same result, a group's shared rows fetched once per request (from L2 after the
+ * first).  The planned entry point below covers more shapes on the one-launch kernel. */
 /* The per-step plan of the shared-prefix kernel.  A decode step calls the kernel once per layer over the same
  * request table, so the groups, every request's remainder range and every prefix block's slot range, column owners
  * and first pool slots are resolved once per step, ON THE DEVICE, into `plan` (sglk_decode_shared_plan_bytes() bytes,
@@ -140,11 +141,17 @@ SGLK_API int sglk_decode_attention(const void* q, const void* k_buffer, const vo
  *   sglk_decode_metadata_shared: sglk_decode_metadata followed by sglk_decode_shared_plan, one call for the
  *     backend's init_forward_metadata / ..._replay_cuda_graph (triton_backend.py:281-337,627-730).
  *   sglk_decode_attention_shared_planned: the kernel of sglk_decode_attention_shared_prefix_xs driven by a plan
- *     (same workspace, same result).  Its grid depends on B and the head counts only, never on the groups.
- *     num_kv_splits (may be NULL): the per-request split counts of sglk_decode_metadata.  When given, the per-request
- *     kernels of sglk_decode_attention are launched as well, and a word of the plan decides ON THE DEVICE which of
- *     the two forms works and which leaves at once: a batch in which no group shares anything is walked per request
- *     with those split counts (what a caller that cannot read the plan back, such as a captured graph, needs). */
+ *     (same workspace, same result).  Its grid depends on B and the head counts only, never on the groups, and it
+ *     serves every batch by itself: a request that shares nothing walks its whole context as its "remainder", over
+ *     up to max_kv_splits / 4 blocks of four waves where the launch has room for them.  One-launch shapes: 16-bit
+ *     queries with head size 128 over 16-bit or fp8 pools (dtype | SGLK_KV_* << 8), and head size 64 with an even
+ *     number of kv heads whose rows are contiguous -- then the plan must have been laid out with num_kv_head / 2
+ *     (pairs of kv heads are walked as one 128-wide head).  Absorbed MLA (576 / 512, one latent head) runs the plan's
+ *     items on the MLA tile kernel plus a merge launch.  The kernel refuses a plan laid out for another batch size,
+ *     head count or split count (NaN rows and the workspace's error word).  Other shapes: per-request kernels.
+ *     num_kv_splits (may be NULL): the per-request split counts of sglk_decode_metadata; used by the absorbed-MLA form
+ *     only, whose per-request kernels are launched beside the plan-driven ones, a word of the plan deciding ON THE
+ *     DEVICE which of the two works (no group shares anything: per request) -- what a captured graph needs. */
 SGLK_API int64_t sglk_decode_shared_plan_bytes(int B, int Hq, int Hkv, int max_kv_splits);
 SGLK_API int sglk_decode_shared_plan(const int32_t* req_to_token, int64_t row_stride,
                                      const void* req_pool_indices, int idx_is64, const void* seq_lens,

@@ -20,8 +20,8 @@ It reads the same fields of the objects the reference passes around:
 Decode batches take the shared-prefix kernel without being told anything beyond what the reference backend is told:
 the metadata call (eager, graph capture and graph replay alike) finds, on the device and at fixed addresses, the groups
 of requests whose req_to_token rows start with the same pool slots -- the radix-tree hit RadixCache.match_prefix handed
-them -- and lays the step's work out for the kernel, which reads a group's shared part of the KV pool once.  A batch in
-which nobody shares anything is walked per request (the device decides; see ops.decode_attention_shared_planned).
+them -- and lays the step's work out for the kernel, which reads a group's shared part of the KV pool once.  Requests
+that share nothing walk their whole context in the same launch (ops.decode_attention_shared_planned).
 The kernel covers head size 128 over 16-bit and fp8 pools, head size 64 over 16-bit pools and (as two launches)
 absorbed MLA; left to itself the backend uses it where it measured faster (ops.shared_prefix_pays: a token's K and V
 rows of at least 1 KiB per layer, not MLA -- elsewhere the per-request kernels, which find the shared rows in L2, win).  `share_prefix=True` (or SGLK_SHARE_PREFIX=1) uses
@@ -355,7 +355,7 @@ class SglkAttnBackend:
             ops.decode_attention_fwd(q3, kb, vb, o3, md.window_kv_indptr, md.window_kv_indices, md.attn_logits, md.attn_lse,
                                      md.window_num_kv_splits, self.max_kv_splits, layer.scaling, layer.logit_cap)
         elif md.shared_plan is not None and q3.dtype in (torch.float16, torch.bfloat16):
-            # the plan's groups, or (decided on the device) the per-request kernels when nobody shares anything
+            # one launch for the whole batch: the plan's groups, and whole contexts for requests that share nothing
             ops.decode_attention_shared_planned(q3, kb, vb, o3, md.kv_indptr[: q3.shape[0] + 1], md.kv_indices,
                                                 md.shared_plan, md.shared_workspace, self.max_kv_splits, layer.scaling,
                                                 layer.logit_cap, num_kv_splits=md.num_kv_splits)

@@ -379,6 +379,21 @@ __device__ __forceinline__ int tail_splits(int len, int max_splits) {
   return min(max(cdiv_i(len, 32), 1), max_splits);
 }
 
+// Tail blocks of a request's private remainder in the planned shared-prefix kernel: one block of four waves up to 512
+// tokens (W's 128-token remainders: one tile per wave), more where the remainder is long -- a request that shares
+// nothing walks its whole context here and must not do so on four waves.
+// `first_blocks` = the launch's tail blocks at one per remainder: once those alone fill the chip (three blocks of four
+// waves per CU), further blocks only add the hand-over between them (measured, 64 requests of 1152 tokens that
+// share nothing: 65 us with one block per remainder, 75 us with two).
+static constexpr int kTailTokensPerBlock = 512;
+static constexpr int kTailBlocksToFill = 768;
+__host__ __device__ inline int tail_blocks(int len, int tmax, int first_blocks) {
+  int t = (len + kTailTokensPerBlock - 1) / kTailTokensPerBlock;
+  const int room = kTailBlocksToFill / (first_blocks > 0 ? first_blocks : 1);
+  t = t < room ? t : room;
+  return t < 1 ? 1 : (t < tmax ? t : tmax);
+}
+
 // pair64 > 0: head size 64.  Two neighbouring kv heads of 64 elements are one 128-element pool row piece (the launcher
 // checks that they are contiguous) and are walked as ONE kv head of 128: Hkv counts such pairs, a pair's query heads are
 // the pair64 heads of its first kv head followed by the pair64 heads of its second.  A query row is placed in the half
@@ -1005,11 +1020,14 @@ __global__ void __launch_bounds__(1024) shared_plan_assemble_kernel(const int32_
 }
 
 struct SharedWs {
-  float* part_o;    // [B * Hq][prefix_splits][128]
-  float* part_lse;  // [B * Hq][prefix_splits]
-  int* counters;    // [B * Hkv] (low half: prefix partials landed, high half: tail blocks done)
+  float* part_o;    // [B * Hq][slots][128]: prefix splits first, then the wave splits of remainders that span blocks
+  float* part_lse;  // [B * Hq][slots]
+  int* counters;    // [B * Hkv] (low half: prefix partials landed, high half: merging tail blocks done)
   int* error;       // raised by a tail block whose wait ran out
-  int rows;         // B * Hq * prefix_splits (the host keeps rows * 512 below 2^31: byte offsets are 32-bit)
+  int* tickets;     // [B * Hkv * head_tiles]: tail blocks of a (request, kv head, head tile) that have published
+  int slots;        // prefix_splits + kWavesPerBlock * tail_tmax
+  int tail_tmax;    // most tail blocks per (request, kv head, head tile)
+  int rows;         // B * Hq * slots (the host keeps rows * 512 below 2^31: byte offsets are 32-bit)
   __device__ __forceinline__ auto rsrc_o() const {
     return __builtin_amdgcn_make_buffer_rsrc(part_o, 0, rows * 512, 0x00020000);
   }
@@ -1141,7 +1159,9 @@ __device__ __forceinline__ void rope_wait(const RopeRole& rr, int tok, int* erro
 // PAIR: head size 64; Hkv counts PAIRS of neighbouring kv heads (one 128-element row piece), a pair's query heads
 // are those of its first kv head followed by those of its second, a query row sits in the half of the 128-wide
 // operand that faces its own kv head (decode_stage1_mfma128 has the details) and only that half of O is stored.
-template <typename T, bool ROPE, bool PLAN, bool RR = false, typename KV = T, bool PAIR = false>
+// MT: remainders may span several tail blocks (a launch whose first tail blocks already fill the chip is compiled
+// without that path: it needs registers the single-block form spills for).
+template <typename T, bool ROPE, bool PLAN, bool RR = false, typename KV = T, bool PAIR = false, bool MT = false>
 __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const void* q, QkvPartials qp, void* k_buffer, void* v_buffer,
     const int32_t* __restrict__ kv_indptr, const int32_t* __restrict__ kv_indices,
@@ -1160,7 +1180,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
   const int hl = lane & 15, g = lane >> 4;
   const int heads = Hq / Hkv;
   constexpr bool KV8 = !std::is_same<KV, T>::value;
-  static_assert(!(KV8 || PAIR) || (PLAN && !ROPE && !RR), "fp8 pools and head-size-64 pairs: planned form only");
+  static_assert(!(KV8 || PAIR || MT) || (PLAN && !ROPE && !RR), "fp8 pools, head-size-64 pairs, multi-block remainders: planned form only");
   [[maybe_unused]] uint16_t* lut = reinterpret_cast<uint16_t*>(lds_all + 2 * kBlockAttnLds);
   if constexpr (KV8) {
     lut[threadIdx.x] = Conv<T>::from_f32(KvElem<KV>::value(threadIdx.x));  // 256 threads, 256 codes
@@ -1248,7 +1268,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
         ATTN_STAMP(1);
         if (ok) {
           const float inv = 1.0f / tot;
-          const int ob = (req * Hq + head) * prefix_splits + split;
+          const int ob = (req * Hq + head) * ws.slots + split;
           const auto ro = ws.rsrc_o();
 #pragma unroll
           for (int n = 0; n < 8; ++n)
@@ -1324,7 +1344,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     ATTN_STAMP(1);
     if (ok) {
       const float inv = 1.0f / tot;
-      const int ob = (req * Hq + head) * prefix_splits + split;
+      const int ob = (req * Hq + head) * ws.slots + split;
       const auto ro = ws.rsrc_o();
 #pragma unroll
       for (int n = 0; n < 8; ++n)
@@ -1347,7 +1367,12 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
 
   // ---- tail block: index = (b * Hkv + kvh) * head_tiles + ht (the kv heads of one request are neighbours in dispatch
   // order: together they fetch whole pool rows)
+  // (the first block of every remainder before anybody's second: for short remainders the later blocks have nothing
+  // to do and leave; at the end of the grid they are not in the way of blocks with work)
   int i = bid - n_prefix_blocks;
+  const int per_round = B * Hkv * head_tiles;
+  const int tb = i / per_round;  // which of the remainder's tail blocks
+  i -= tb * per_round;
   const int ht = i % head_tiles;
   i /= head_tiles;
   const int kvh = i % Hkv, b = i / Hkv;
@@ -1383,9 +1408,12 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     aps = active_prefix_splits(plen, prefix_splits);
     expect_partials = prefix_blocks_of(b - group_indptr[grp], heads) * aps;
   }
-  const int splits = tail_splits(len, kWavesPerBlock);
+  const int n_tb = MT ? tail_blocks(len, ws.tail_tmax, per_round) : 1;  // block-uniform
+  if (tb >= n_tb) return;
+  const int splits = tail_splits(len, kWavesPerBlock * n_tb);
   const int per_split = cdiv_i(cdiv_i(len, splits), kMinBlockKV) * kMinBlockKV;
-  const int s0 = per_split * wid;
+  const int wg = tb * kWavesPerBlock + wid;  // this wave's split of the remainder
+  const int s0 = per_split * wg;
   const int s1 = max(min(s0 + per_split, len), s0);
   const bool active = s1 > s0;  // wave-uniform
   const int head_in_group = ht * 16 + hl;
@@ -1435,16 +1463,41 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
                 reinterpret_cast<const uint16_t*>(v_buffer) + (int64_t)kvh * v_stride_h, k_stride_n, v_stride_n,
                 kv_indices + start, s0, s1, sm_scale, logit_cap);
   }
-  {
+  const float wave_lsum = wa.total();
+  const float wave_inv = active ? 1.0f / wave_lsum : 0.f;
+  const float wave_lse = active ? (wa.m + log2f(wave_lsum)) * 0.6931471805599453f : -INFINITY;
+  if (!MT || n_tb == 1) {
     // this wave's partial: O[16 heads][128] fp32 over its V tile, log-sum-exp[16] beside it
-    const float lsum = wa.total();
     float* po = reinterpret_cast<float*>(vl);
-    const float inv = active ? 1.0f / lsum : 0.f;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(po + hl * 128 + 16 * n + 4 * g) = wa.oacc[n] * inv;
-    if (g == 0) tail_lse[wid][hl] = active ? (wa.m + log2f(lsum)) * 0.6931471805599453f : -INFINITY;
+    for (int n = 0; n < 8; ++n) *reinterpret_cast<float4v*>(po + hl * 128 + 16 * n + 4 * g) = wa.oacc[n] * wave_inv;
+    if (g == 0) tail_lse[wid][hl] = wave_lse;
+    ATTN_STAMP(1);
+  } else {
+    // The remainder spans blocks: every block publishes its waves' partials (write-through, as the prefix blocks do) and
+    // draws a ticket; the block that draws the last one merges everything, the others are done.
+    if (head_ok) {
+      const int ob = (b * Hq + head) * ws.slots + prefix_splits + wg;
+      const auto ro = ws.rsrc_o();
+#pragma unroll
+      for (int n = 0; n < 8; ++n)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(uint4v, wa.oacc[n] * wave_inv), ro,
+                                               ob * 512 + (16 * n + 4 * g) * 4, 0, kSc1);
+      if (g == 0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, wave_lse), ws.rsrc_lse(), ob * 4, 0, kSc1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every store of this wave has been acknowledged
+    __syncthreads();
+    ATTN_STAMP(1);
+    if (threadIdx.x == 0) {
+      int* const tk = ws.tickets + ((int64_t)b * Hkv + kvh) * head_tiles + ht;
+      const int drawn = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_failed = drawn == n_tb - 1 ? 0 : -1;
+      if (drawn == n_tb - 1) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
+    }
+    __syncthreads();
+    if (wait_failed < 0) return;  // block-uniform: another block merges
+    __syncthreads();              // wait_failed is written again below
   }
-  ATTN_STAMP(1);
   // ---- wait for the pair's prefix partials
   int* const counter = ws.counters + (int64_t)b * Hkv + kvh;
   if (threadIdx.x == 0) {
@@ -1479,7 +1532,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
     const bool ok = hh < heads_here;
     const int d = 2 * lane;
     const int hq = kvh * heads + ht * 16 + (ok ? hh : 0);
-    const int row0 = (b * Hq + hq) * prefix_splits;
+    const int row0 = (b * Hq + hq) * ws.slots;
     float2v tv[kSharedMaxSplits];
     float tl[kSharedMaxSplits];
 #pragma unroll
@@ -1494,17 +1547,7 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
       }
     }
     float e_max = -INFINITY, e_sum = 0.f, acc0 = 0.f, acc1 = 0.f;
-#pragma unroll
-    for (int sp = 0; sp < kSharedMaxSplits + kWavesPerBlock; ++sp) {
-      float2v v;
-      float l;
-      if (sp < kSharedMaxSplits) {
-        v = tv[sp];
-        l = tl[sp];
-      } else {
-        v = *reinterpret_cast<const float2v*>(lds_all + (sp - kSharedMaxSplits) * kTileBytes + ((ok ? hh : 0) * 128 + d) * 4);
-        l = tail_lse[sp - kSharedMaxSplits][ok ? hh : 0];
-      }
+    auto fold = [&](float2v v, float l) {
       if (l > -INFINITY) {
         const float n_max = fmaxf(l, e_max);
         const float old = expf(e_max - n_max), w = expf(l - n_max);
@@ -1514,6 +1557,32 @@ __global__ void __launch_bounds__(256, 3) decode_shared_fused_kernel(
         acc1 = fmaf(w, v[1], acc1 * old);
         e_sum = fmaf(e_sum, old, w);
         e_max = n_max;
+      }
+    };
+#pragma unroll
+    for (int sp = 0; sp < kSharedMaxSplits; ++sp) fold(tv[sp], tl[sp]);
+    if (!MT || n_tb == 1) {  // the remainder's four partials are this block's own, in LDS
+#pragma unroll
+      for (int w4 = 0; w4 < kWavesPerBlock; ++w4)
+        fold(*reinterpret_cast<const float2v*>(lds_all + w4 * kTileBytes + ((ok ? hh : 0) * 128 + d) * 4),
+             tail_lse[w4][ok ? hh : 0]);
+    } else {          // published by n_tb blocks: one more trip, in split order
+      for (int w0 = 0; w0 < kWavesPerBlock * n_tb; w0 += kWavesPerBlock) {  // block-uniform
+        float2v uv[kWavesPerBlock];
+        float ul[kWavesPerBlock];
+#pragma unroll
+        for (int w4 = 0; w4 < kWavesPerBlock; ++w4) {
+          const int r = row0 + prefix_splits + w0 + w4;
+          if (ok && !failed) {
+            uv[w4] = __builtin_bit_cast(float2v, (uint2v)__builtin_amdgcn_raw_buffer_load_b64(ro, r * 512 + d * 4, 0, kSc1));
+            ul[w4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rl, r * 4, 0, kSc1));
+          } else {
+            uv[w4] = float2v{0.f, 0.f};
+            ul[w4] = -INFINITY;
+          }
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < kWavesPerBlock; ++w4) fold(uv[w4], ul[w4]);
       }
     }
     const float r0 = failed ? __builtin_nanf("") : acc0 / e_sum;
@@ -1900,7 +1969,10 @@ int sglk_decode_attention(const void* q, const void* k_buffer, const void* v_buf
 
 // Workspace of the shared-prefix path: [counters: B * Hq int32 + one error word, rounded up to 256 bytes]
 // [O partials: B * Hq * max_kv_splits * Dv fp32][log-sum-exp: B * Hq * max_kv_splits fp32].
-static int64_t shared_counter_bytes(int B, int Hq) { return ((((int64_t)B * Hq + 1) * 4 + 255) / 256) * 256; }
+// counters [B * Hq] (B * Hkv used), the error word, then the tail tickets [B * Hq] (B * Hkv * head_tiles used)
+static int64_t shared_counter_bytes(int B, int Hq) { return ((((int64_t)2 * B * Hq + 2) * 4 + 255) / 256) * 256; }
+// most tail blocks per (request, kv head, head tile) of the planned kernel: as many wave splits as max_kv_splits allows
+static int shared_tail_tmax(int max_kv_splits) { return std::max(1, max_kv_splits / kWavesPerBlock); }
 
 int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_splits) {
   if (B <= 0 || Hq <= 0 || Dv <= 0 || max_kv_splits <= 0) return 0;
@@ -1908,7 +1980,10 @@ int64_t sglk_decode_shared_workspace_bytes(int B, int Hq, int Dv, int max_kv_spl
   // the per-request kernels).  The one-launch kernel keeps partial rows of 128 floats whatever the head size (head
   // size 64 runs on pairs of kv heads, 128 wide).
   Dv = std::max(Dv, 128);
-  if (Dv == kMlaDv) max_kv_splits += kMlaTailSplits;  // the absorbed-MLA form keeps the remainders' partials there too
+  if (Dv == kMlaDv)
+    max_kv_splits += kMlaTailSplits;  // the absorbed-MLA form keeps the remainders' partials there too
+  else
+    max_kv_splits += kWavesPerBlock * shared_tail_tmax(max_kv_splits);  // remainders that span blocks publish theirs
   return shared_counter_bytes(B, Hq) + (int64_t)B * Hq * max_kv_splits * (Dv + 1) * (int64_t)sizeof(float) +
          (((int64_t)B * 4 + 255) / 256) * 256;
 }
@@ -2034,17 +2109,28 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
   int prefix_splits = shared_prefix_splits(B, heads, Hkv, max_kv_splits);
   if (env_sp > 0 && !plan) prefix_splits = std::min(env_sp, max_kv_splits);  // (a plan was built for its own count)
   SharedWs ws;
-  const int64_t rows = (int64_t)B * Hq * prefix_splits;
+  // remainders may span blocks in the plain planned form only (the forms that write the new K / V rows in a tail block
+  // keep one block per remainder)
+  static const int env_tmax = getenv("SGLK_TAIL_TMAX") ? atoi(getenv("SGLK_TAIL_TMAX")) : 0;
+  ws.tail_tmax = (plan && !qp && !rope_src) ? shared_tail_tmax(max_kv_splits) : 1;
+  if (env_tmax > 0) ws.tail_tmax = std::min(ws.tail_tmax, env_tmax);
+  // tail_blocks() gives no remainder more blocks than the chip has room for beside everybody's first: a launch whose
+  // first blocks fill it takes the kernel compiled without the multi-block path
+  ws.tail_tmax = std::max(1, std::min(ws.tail_tmax, kTailBlocksToFill / std::max(1, B * Hkv * ((Hq / Hkv + 15) / 16))));
+  const bool multi_tail = ws.tail_tmax > 1;
+  ws.slots = prefix_splits + kWavesPerBlock * ws.tail_tmax;
+  const int64_t rows = (int64_t)B * Hq * ws.slots;
   SGLK_CHECK(rows * 512 < ((int64_t)1 << 31), "decode_attention_shared_prefix: B * Hq * max_kv_splits too large");
   SGLK_CHECK(heads <= kTailDone / 64, "decode_attention_shared_prefix: too many query heads per kv head");
   ws.rows = (int)rows;
   ws.counters = reinterpret_cast<int*>(workspace);
   ws.error = ws.counters + (int64_t)B * Hq;
+  ws.tickets = ws.error + 1;
   ws.part_o = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
   ws.part_lse = ws.part_o + rows * 128;
   // planned: one round of blocks for a batch that is one group; more items (many small groups) take further rounds
   const int n_prefix = (plan ? 1 : G) * prefix_splits * col_blocks * Hkv;
-  const int n_tail = B * Hkv * head_tiles;
+  const int n_tail = B * Hkv * head_tiles * ws.tail_tmax;
   PlanView pv{};
   if (plan) {
     SGLK_CHECK(B <= kPlanMaxB, "decode_attention_shared_prefix: a plan covers at most %d requests", kPlanMaxB);
@@ -2077,12 +2163,19 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
                                         k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o, o_stride_b,          \
                                         o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8), rr))
   dtype = qdtype;
-#define SGLK_SHARED_LAUNCH_KV(KVT, PAIRV)                                                                               \
-  hipLaunchKernelGGL((decode_shared_fused_kernel<T, false, true, false, KVT, PAIRV>), dim3(n_prefix + n_tail), dim3(256), \
-                     lds, s, q, QkvPartials{}, k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr, prefix_lens, G,   \
-                     pv.hdr, pv.tail, pv.items, ws, prefix_splits, n_prefix, col_blocks, B, Hq, Hkv, head_tiles,          \
-                     q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale, logit_cap, o,      \
-                     o_stride_b, o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8), rr)
+#define SGLK_SHARED_LAUNCH_MT(KVT, PAIRV, MTV)                                                                          \
+  hipLaunchKernelGGL((decode_shared_fused_kernel<T, false, true, false, KVT, PAIRV, MTV>), dim3(n_prefix + n_tail),     \
+                     dim3(256), lds, s, q, QkvPartials{}, k_buffer, v_buffer, kv_indptr, kv_indices, group_indptr,       \
+                     prefix_lens, G, pv.hdr, pv.tail, pv.items, ws, prefix_splits, n_prefix, col_blocks, B, Hq, Hkv,     \
+                     head_tiles, q_stride_b, q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, sm_scale,       \
+                     logit_cap, o, o_stride_b, o_stride_h, xsum_out, xs_stride, (gated ? 1 : 0) | (env_delay << 8), rr)
+#define SGLK_SHARED_LAUNCH_KV(KVT, PAIRV) \
+  do {                                    \
+    if (multi_tail)                       \
+      SGLK_SHARED_LAUNCH_MT(KVT, PAIRV, true);  \
+    else                                  \
+      SGLK_SHARED_LAUNCH_MT(KVT, PAIRV, false); \
+  } while (0)
   if (fast8) {
     static bool lds_set[64][4][2];  // per device: the attribute belongs to the device's copy of the code object
     int dev = 0;
@@ -2091,7 +2184,9 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
       SGLK_DISPATCH_KV(kvf, T, KV, {
         bool& done = lds_set[dev & 63][kvf & 3][dtype == SGLK_F16 ? 1 : 0];
         if (!done) {  // 64.5 KiB of dynamic LDS: above the default limit
-          SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_shared_fused_kernel<T, false, true, false, KV, false>),
+          SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_shared_fused_kernel<T, false, true, false, KV, false, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          SGLK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_shared_fused_kernel<T, false, true, false, KV, false, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           done = true;
         }
@@ -2119,12 +2214,13 @@ static int launch_shared_prefix(const void* q, const QkvPartials* qp, void* k_bu
       SGLK_SHARED_LAUNCH(true, false, *qp);
     }
   } else if (plan) {
-    SGLK_SHARED_LAUNCH(false, true, QkvPartials{});
+    SGLK_DISPATCH_HALF(dtype, T, SGLK_SHARED_LAUNCH_KV(T, false));
   } else {
     SGLK_SHARED_LAUNCH(false, false, QkvPartials{});
   }
 #undef SGLK_SHARED_LAUNCH
 #undef SGLK_SHARED_LAUNCH_KV
+#undef SGLK_SHARED_LAUNCH_MT
   SGLK_LAUNCH_CHECK();
   return SGLK_OK;
 }
@@ -2263,21 +2359,20 @@ int sglk_decode_attention_shared_planned(const void* q, const void* k_buffer, co
                                          float sm_scale, float logit_cap, int dtype, float* xsum_out, int64_t xs_stride,
                                          const int32_t* num_kv_splits, void* stream) {
   SGLK_CHECK(q && plan, "decode_attention_shared_planned: null pointer");
+  // The one-launch kernel serves every batch by itself: requests that share nothing walk their whole context as a
+  // "remainder", over as many tail blocks as the chip has room for (measured against the per-request kernels on
+  // batches in which nobody shares: between 6 % faster and 9 % slower; two more launches per layer that leave at once
+  // for every batch that does share would cost 4 us each time).  Only the absorbed-MLA form, whose plan-driven kernels
+  // are slower than the per-request ones, keeps the pair: with num_kv_splits both are launched and the plan's item
+  // count -- a device word both read -- decides which of the two leaves at once, so that a captured launch sequence
+  // serves either kind of batch.
+  bool gated = false;
   if (num_kv_splits) {
-    // A batch in which nobody shares anything (the plan holds no prefix item) is better served by the per-request
-    // kernels, whose split counts follow the sequence lengths and the CU count.  Whether that is so is known on the
-    // device only, and a captured launch sequence cannot change: both forms are launched, and the blocks of the one
-    // the plan does not select leave at once (the word both read is the plan's item count).
-    // (the shapes launch_shared_prefix takes on its one-launch kernel; any other shape runs the per-request kernels
-    // there anyway)
     const int kvf = dtype >> SGLK_KV_SHIFT;
     const int qd = dtype & ((1 << SGLK_KV_SHIFT) - 1);
-    const bool tile = (qd == SGLK_F16 || qd == SGLK_BF16) &&
-                      ((D == 128 && Dv == 128) ||
-                       (kvf == 0 && D == 64 && Dv == 64 && Hkv % 2 == 0 && k_stride_h == 64 && v_stride_h == 64 && !xsum_out) ||
-                       (kvf == 0 && D == kMlaD && Dv == kMlaDv && Hkv == 1 && v_buffer == k_buffer && v_stride_n == k_stride_n &&
-                        !xsum_out));
-    if (tile) {
+    const bool mla_shape = (qd == SGLK_F16 || qd == SGLK_BF16) && kvf == 0 && D == kMlaD && Dv == kMlaDv && Hkv == 1 &&
+                           v_buffer == k_buffer && v_stride_n == k_stride_n && !xsum_out;
+    if (mla_shape) {
       SGLK_CHECK(workspace, "decode_attention_shared_planned: null pointer");
       float* logits = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + shared_counter_bytes(B, Hq));
       float* lse = logits + (int64_t)B * Hq * max_kv_splits * Dv;
@@ -2286,12 +2381,13 @@ int sglk_decode_attention_shared_planned(const void* q, const void* k_buffer, co
                                          v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale, logit_cap, dtype, xsum_out,
                                          xs_stride, stream, plan + kPlanNItems))
         return rc;
+      gated = true;
     }
   }
   return launch_shared_prefix(q, nullptr, const_cast<void*>(k_buffer), const_cast<void*>(v_buffer), o, kv_indptr,
                               kv_indices, nullptr, nullptr, 0, plan, workspace, max_kv_splits, B, Hq, Hkv, D, Dv, q_stride_b,
                               q_stride_h, k_stride_n, k_stride_h, v_stride_n, v_stride_h, o_stride_b, o_stride_h, sm_scale,
-                              logit_cap, dtype, xsum_out, xs_stride, stream, num_kv_splits != nullptr);
+                              logit_cap, dtype, xsum_out, xs_stride, stream, gated);
 }
 
 int sglk_decode_attention_shared_planned_rope(const float* qkv_partials, int splits, int64_t part_stride,

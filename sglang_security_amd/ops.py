@@ -169,9 +169,10 @@ def decode_shared_plan_read(plan, B):
 
 def decode_attention_shared_planned(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, plan, workspace, max_kv_splits,
                                     sm_scale, logit_cap=0.0, xsum_out=None, num_kv_splits=None):
-    """decode_attention_shared_prefix with the groups and the work layout taken from a per-step plan.  With
-    num_kv_splits the per-request kernels are launched beside it and the plan decides on the device which of the two
-    runs (no group shares anything: per request)."""
+    """decode_attention_shared_prefix with the groups and the work layout taken from a per-step plan.  The launch
+    serves every batch (requests that share nothing walk their whole context as remainders); num_kv_splits matters to
+    the absorbed-MLA form only, whose per-request kernels are then launched beside it, the plan deciding on the device
+    which of the two runs."""
     _need_gpu(q, k_buffer, v_buffer, o, kv_indptr, kv_indices, plan, workspace)
     B, Hq, D = q.shape
     Hkv, Dv = v_buffer.shape[1], v_buffer.shape[2]

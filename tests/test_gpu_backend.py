@@ -127,17 +127,17 @@ def test_backend_decode_matches_oracle(graph_state, share, Hq, Hkv, D, pool_dtyp
         assert ops.decode_shared_workspace_status(md.shared_workspace, B, Hq) == 0
 
 
-def test_backend_decode_nobody_shares_takes_the_per_request_kernels():
-    """A batch whose requests share nothing: the plan holds no prefix item, and the launch sequence (which a captured
-    graph could not change) hands the batch to the per-request kernels on the device -- same numbers as the oracle."""
+def test_backend_decode_nobody_shares():
+    """A batch whose requests share nothing: the plan holds no prefix item, and the same launch (which a captured graph
+    could not change) walks every request's whole context as its remainder -- same numbers as the oracle."""
     import oracle
     from sglang_security_amd import ops
     from sglang_security_amd.attention import SglkAttnBackend
 
     Hq, Hkv, D, B = 8, 2, 128, 3
-    mr, r2t, kv, alloc = _runner(Hq, Hkv, D)
+    mr, r2t, kv, alloc = _runner(Hq, Hkv, D, max_ctx=1536)
     g = torch.Generator().manual_seed(5)
-    lens = [70, 33, 129]
+    lens = [70, 33, 1290]        # the last one long enough to span two tail blocks
     for b in range(B):
         r2t.req_to_token[b, : lens[b]] = alloc.alloc(lens[b]).int()
     for buf in (kv.k_buffer[0], kv.v_buffer[0]):
