@@ -47,8 +47,10 @@ def test_host_only_calls():
     assert L.sglk_version() > 0
     assert L.sglk_ar_meta_size() > 0 and L.sglk_ipc_handle_bytes() == 64
     assert L.sglk_awq_gemm_workspace_bytes(64, 4096, 4096) > 0
-    # counters (+ error word, rounded to 256), partials + log-sum-exps, one split count per request (rounded to 256)
-    assert L.sglk_decode_shared_workspace_bytes(64, 32, 128, 8) == (64 * 32 * 4 + 256) + 64 * 32 * 8 * 129 * 4 + 256
+    # counters + error word + tail tickets (rounded to 256), partials + log-sum-exps of 8 prefix splits and 2 x 4
+    # remainder splits, one split count per request (rounded to 256)
+    assert L.sglk_decode_shared_workspace_bytes(64, 32, 128, 8) == ((2 * 64 * 32 + 2) * 4 + 255) // 256 * 256 + \
+        64 * 32 * (8 + 8) * 129 * 4 + 256
     # argument validation happens before any GPU call
     rc = L.sglk_rmsnorm(None, None, None, 1, 128, 128, 128, 1e-6, 0, 2, None)
     assert rc == -1 and b"null" in L.sglk_last_error().lower()
