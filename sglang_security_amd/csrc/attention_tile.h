@@ -582,30 +582,6 @@ struct WaveAttn {
     }
   }
 
-  // The same with two tiles in flight (64 more registers): short ranges, where the first round trip to memory is
-  // most of the time, start both of their tiles at once.
-  __device__ __forceinline__ void run2(char* kl, char* vl, const uint16_t* kbase, const uint16_t* vbase,
-                                       int64_t k_stride_n, int64_t v_stride_n, const int32_t* idx, int s0, int s1,
-                                       float sm_scale, float logit_cap) {
-    if (s1 <= s0) return;
-    Rows other;
-    int slots = load_slots(idx, s0, s0, s1);
-    int slots_next = s0 + 2 * kTile < s1 ? load_slots(idx, s0 + 2 * kTile, s0, s1) : 0;
-    fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots, 0);
-    if (s0 + kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, slots, kTile);
-    for (int t0 = s0; t0 < s1; t0 += 2 * kTile) {
-      const bool more = t0 + 2 * kTile < s1;  // another pair of tiles follows: its slots are in slots_next
-      park(rows, kl, vl);
-      if (more) fetch(rows, kbase, vbase, k_stride_n, v_stride_n, slots_next, 0);
-      step(kl, vl, t0, s1, true, sm_scale, logit_cap);
-      if (t0 + kTile >= s1) break;
-      park(other, kl, vl);
-      if (t0 + 3 * kTile < s1) fetch(other, kbase, vbase, k_stride_n, v_stride_n, slots_next, kTile);
-      if (t0 + 4 * kTile < s1) slots_next = load_slots(idx, t0 + 4 * kTile, s0, s1);
-      step(kl, vl, t0 + kTile, s1, true, sm_scale, logit_cap);
-    }
-  }
-
   // ---- fp8 pools ---------------------------------------------------------------------------------------------
   // A pool row of 128 one-byte elements travels as 8-byte pieces (16 lanes per row) and is widened to T on its way into
   // the LDS tile, through a 256-entry table the block builds once (lut[code] = the code's exact value in T: every
