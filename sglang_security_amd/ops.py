@@ -89,7 +89,7 @@ def shared_prefix_pays(Hkv: int, head_dim: int, v_head_dim: int, itemsize: int) 
     counter -> merge): it trades that chain for fetching the prefix rows once per group, which pays when a token's K and
     V rows are large.  Measured at batch 64, 1024 shared + 128 private tokens: Llama-3-8B (4 KiB of K + V per token and
     layer) gains 12 % of the step, Qwen2-0.5B (512 bytes) loses 9 %; the line is drawn at 1 KiB.  Absorbed MLA
-    (576 / 512) never: its plan-driven form is 13-18 % slower than the per-request kernels at 16 and at 128 heads (the
+    (576 / 512) never: its plan-driven form is 13-33 % slower than the per-request kernels at 16 and at 128 heads (the
     shared rows come from L2 either way, and the remainders' extra 512-wide partials cost more than the fetches saved)."""
     if head_dim == 576 and v_head_dim == 512:
         return False

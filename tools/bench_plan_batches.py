@@ -85,6 +85,12 @@ def batch(groups, lone):
     return rows
 
 
+if os.environ.get("ONLY") == "groups":
+    run("64 x (1024 shared + 128)", batch([(64, 1024, 128)], []))
+    run("10 groups x 32 x (1024 + 128)", batch([(32, 1024, 128)] * 10, []))
+    run("4 groups x 32 x (2048 + 64)", batch([(32, 2048, 64)] * 4, []))
+    run("128 x (1024 + 128)", batch([(128, 1024, 128)], []))
+    sys.exit(0)
 run("64 x (1024 shared + 128)", batch([(64, 1024, 128)], []))
 run("64 lone x 1152", batch([], [1152] * 64))
 run("1 lone x 1152", batch([], [1152]))
