@@ -96,6 +96,29 @@ def test_extend_matches_torch(T, gemm, quant):
     assert h.tree.total_size() == T
 
 
+def test_overlapped_dequantisation_gives_the_same_bits():
+    """The library path dequantises projection i + 1 on a second stream under the product of projection i; the
+    result is the one of the two in sequence, on the first extend and on a second one that re-uses the buffers."""
+    from sglang_security_amd.prefill_runner import PrefixCacheHarness
+
+    dec = _tiny("awq")
+    a = PrefixCacheHarness(dec, 4096, 2048, None, overlap_dequant=True)
+    b = PrefixCacheHarness(dec, 4096, 2048, None, overlap_dequant=False)
+    for T in (300, 517, 256):
+        ids = torch.randint(0, dec.cfg.vocab, (T,), generator=torch.Generator().manual_seed(T)).tolist()
+        ta, _, _ = a.serve_first_token(ids, None)
+        tb, _, _ = b.serve_first_token(ids, None)
+        torch.cuda.synchronize()
+        assert a.model._ring is not None and b.model._ring is None
+        assert torch.equal(a.model.hidden[:T], b.model.hidden[:T])
+        assert torch.equal(a.model.residual[:T], b.model.residual[:T])
+        assert int(ta.item()) == int(tb.item())
+        for h in (a, b):
+            h.tree.reset()
+            h.alloc.clear()
+            h.req_pool.clear()
+
+
 def test_prefix_hit_equals_recompute():
     """A request whose first 1024 tokens are served from the radix cache ends in the same hidden state (within bf16
     accumulation noise) and the same first token as the same request computed from scratch."""
