@@ -518,6 +518,43 @@ def test_shared_prefix_planned_absorbed_mla(dtype, groups, Hq, max_splits, cap):
     assert (o - o2.float().cpu()).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D,Hq,Hkv,max_splits", [(128, 32, 8, 16), (128, 8, 2, 8), (64, 14, 2, 16), (128, 32, 8, 4)])
+def test_shared_prefix_planned_long_remainders_vs_oracle(dtype, D, Hq, Hkv, max_splits):
+    """Remainders of more than 512 tokens are spread over several tail blocks (up to max_splits / 4 of them) whose
+    partial results the last one to finish merges with the group's prefix partials: requests that share nothing next
+    to a group with long private parts, a length that ends exactly on a block's boundary, short requests in the same
+    launch.  Against the oracle; a second launch on the same workspace gives the same bits (the tickets are back at
+    zero, the merge order does not depend on which block came last)."""
+    import oracle
+
+    ops = _ops()
+    groups = [(3, 100, 520, 1500), (1, 0, 2048, 2048), (2, 0, 1, 40), (4, 64, 1000, 1100), (1, 0, 513, 513),
+              (1, 0, 1024, 1024)]
+    q, kb, vb, ptr, ind, gi, pls = _group_batch_d(groups, Hq, Hkv, D, dtype, seed=D + Hq)
+    B = q.shape[0]
+    sm = 1.0 / math.sqrt(D)
+    want = oracle.decode_attention(q, kb, vb, ptr, ind, torch.ones(B, dtype=torch.int32), sm)
+    plan = ops.decode_shared_plan_buffer(B, Hq, Hkv, max_splits, DEV, head_dim=D)
+    ops.decode_shared_plan_from_groups(ptr.to(DEV), ind.to(DEV), gi.to(DEV), pls.to(DEV), B, Hq, Hkv, max_splits, plan,
+                                       head_dim=D)
+    ws = ops.decode_shared_workspace(B, Hq, D, max_splits, DEV)
+    dev = (q.to(DEV), kb.to(DEV), vb.to(DEV))
+    outs = []
+    for _ in range(3):
+        o = torch.full((B, Hq, D), float("nan"), dtype=dtype, device=DEV)
+        ops.decode_attention_shared_planned(*dev, o, ptr.to(DEV), ind.to(DEV), plan, ws, max_splits, sm, 0.0, None, None)
+        torch.cuda.synchronize()
+        assert ops.decode_shared_workspace_status(ws, B, Hq) == 0
+        outs.append(o)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    assert torch.equal(outs[0].view(torch.int16), outs[2].view(torch.int16))
+    o = outs[0].float().cpu()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert torch.isfinite(o).all()
+    assert (o - want).abs().max().item() < tol
+
+
 def test_shared_prefix_planned_rejects_a_plan_of_another_geometry():
     """A plan laid out for other heads per kv head must not be walked: NaN rows and the workspace's error word, not a
     wrong answer (here: a head-size-64 launch on a plan that counts single kv heads)."""
