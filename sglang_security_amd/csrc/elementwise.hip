@@ -561,7 +561,9 @@ __global__ void __launch_bounds__(256) act_and_mul_xs_kernel(void* __restrict__ 
 }
 
 // Greedy token: index of the first maximum of every row (torch.argmax, sampler.py greedy path).  One block per row,
-// eight elements per load for 16-bit rows.
+// eight elements per load for 16-bit rows.  The scan is bound by vector instructions, so a thread's own elements (which
+// it visits in ascending order) take one strict comparison each and NaNs are only noted; a row that holds one (a NaN
+// wins, as in torch) is scanned again with the full rule.
 template <typename T>
 __global__ void __launch_bounds__(1024) argmax_rows_kernel(const void* __restrict__ x, int64_t* __restrict__ out, int cols,
                                                            int64_t row_stride) {
@@ -570,34 +572,52 @@ __global__ void __launch_bounds__(1024) argmax_rows_kernel(const void* __restric
   const int64_t row = blockIdx.x;
   float best = -INFINITY;
   int idx = 0x7fffffff;
-  auto take = [&](float v, int i) {
-    if (v > best || (v == best && i < idx) || (v != v && !(best != best))) {  // a NaN wins, as in torch
+  bool any_nan = false;
+  auto take = [&](float v, int i) {  // a NaN wins, as in torch; among equals (and among NaNs) the lowest index
+    const bool vn = v != v, bn = best != best;
+    if (vn ? (!bn || i < idx) : (!bn && (v > best || (v == best && i < idx)))) {
       best = v;
       idx = i;
     }
   };
-  if constexpr (sizeof(typename Raw<T>::type) == 2) {
-    const uint16_t* r = reinterpret_cast<const uint16_t*>(x) + row * row_stride;
-    const int nv = ((row_stride % 8) == 0 && aligned16(x)) ? cols / 8 : 0;
-    // four loads in flight per thread: a row of a large vocabulary is a few trips to memory instead of sixteen
-    int v = threadIdx.x;
-    for (; v + 3 * 1024 < nv; v += 4 * 1024) {
-      short8 q[4];
+  auto scan = [&](auto&& visit) {
+    if constexpr (sizeof(typename Raw<T>::type) == 2) {
+      const uint16_t* r = reinterpret_cast<const uint16_t*>(x) + row * row_stride;
+      const int nv = ((row_stride % 8) == 0 && aligned16(x)) ? cols / 8 : 0;
+      // four loads in flight per thread: a row of a large vocabulary is a few trips to memory instead of sixteen
+      int v = threadIdx.x;
+      for (; v + 3 * 1024 < nv; v += 4 * 1024) {
+        short8 q[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const short8*>(r)[v + 1024 * u];
+        for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const short8*>(r)[v + 1024 * u];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) take(Conv<T>::to_f32((uint16_t)q[u][j]), 8 * (v + 1024 * u) + j);
+          for (int j = 0; j < 8; ++j) visit(Conv<T>::to_f32((uint16_t)q[u][j]), 8 * (v + 1024 * u) + j);
+      }
+      for (; v < nv; v += 1024) {
+        const short8 q = reinterpret_cast<const short8*>(r)[v];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) visit(Conv<T>::to_f32((uint16_t)q[j]), 8 * v + j);
+      }
+      for (int i = nv * 8 + threadIdx.x; i < cols; i += 1024) visit(Conv<T>::to_f32(r[i]), i);
+    } else {
+      for (int i = threadIdx.x; i < cols; i += 1024) visit(ld<T>(x, row * row_stride + i), i);
     }
-    for (; v < nv; v += 1024) {
-      const short8 q = reinterpret_cast<const short8*>(r)[v];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) take(Conv<T>::to_f32((uint16_t)q[j]), 8 * v + j);
+  };
+  // ascending indices within a thread: the first of equal values stays with a strict comparison (a row of nothing
+  // but -inf keeps the sentinel and ends at index 0)
+  scan([&](float v, int i) {
+    any_nan |= v != v;
+    if (v > best) {
+      best = v;
+      idx = i;
     }
-    for (int i = nv * 8 + threadIdx.x; i < cols; i += 1024) take(Conv<T>::to_f32(r[i]), i);
-  } else {
-    for (int i = threadIdx.x; i < cols; i += 1024) take(ld<T>(x, row * row_stride + i), i);
+  });
+  if (__syncthreads_or(any_nan)) {  // block-uniform
+    best = -INFINITY;
+    idx = 0x7fffffff;
+    scan(take);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

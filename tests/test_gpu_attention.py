@@ -127,6 +127,32 @@ def test_argmax_rows(dtype, rows, cols):
     assert torch.equal(out2, torch.argmax(view, dim=-1))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_argmax_rows_special_values(dtype):
+    """Rows the fast scan hands to the full rule, or that never beat the start value: NaNs (the first one wins, whatever
+    its sign and whatever else the row holds), nothing but -inf (index 0), a maximum of zero met first as -0.0 and
+    later as +0.0 (equal: the first stays), +inf twice."""
+    ops = _ops()
+    cols = 40000
+    x = -torch.rand(8, cols, generator=torch.Generator().manual_seed(3)) - 1.0
+    x[0, 777] = float("nan")
+    x[0, 30001] = float("nan")
+    x[0, 5] = float("inf")
+    x[1, :] = float("-inf")
+    x[2, 9000] = -0.0
+    x[2, 20000] = 0.0
+    x[3, 12345] = float("inf")
+    x[3, 39999] = float("inf")
+    x[4, cols - 1] = -float("nan")
+    x[5, :] = float("-inf")
+    x[5, 31111] = -3.0e38
+    x = x.to(dtype).to(DEV)
+    out = torch.empty(8, dtype=torch.int64, device=DEV)
+    ops.argmax(x, out)
+    assert out.tolist()[:6] == [777, 0, 9000, 12345, cols - 1, 31111]
+    assert torch.equal(out[6:], torch.argmax(x[6:], dim=-1))
+
+
 def _run_decode(ops, g, dtype, max_splits=8, splits=None):
     q = g["q"].to(dtype).to(DEV)
     kb, vb = g["k_buffer"].to(dtype).to(DEV), g["v_buffer"].to(dtype).to(DEV)
